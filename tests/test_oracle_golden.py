@@ -1,0 +1,226 @@
+"""CPU: the oracle (oracle/favae_oracle.py) reproduces every golden vector that oracle/gen_golden.py
+captured from the reference implementation.  This is what "pins" the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import favae_oracle as O
+
+torch.set_num_threads(8)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, rtol=2e-5, name=""):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    assert err < rtol, f"{name}: max-rel {err:.3e} >= {rtol}"
+
+
+def leafify(P):
+    for k in P:
+        if P[k].dtype.is_floating_point and not O.is_buffer(k):
+            P[k].requires_grad_(True)
+    return P
+
+
+BLOCK_CASES = {
+    "res_same": ("res", (64, 64)), "res_short": ("res", (32, 96)), "nonres": ("nonres", (64, 64)),
+    "nonres_g4": ("nonres4", (8, 8)), "attn": ("attn", (64,)), "down": ("down", (32,)), "down_odd": ("down", (32,)),
+    "up": ("up", (32,)),
+}
+
+
+def _block_params(kind, dims):
+    s = {}
+    if kind in ("res", "nonres", "nonres4"):
+        ci, co = dims
+        s["blk.block.0.weight"] = (ci,); s["blk.block.0.bias"] = (ci,)
+        s["blk.block.2.weight"] = (co, ci, 3, 3); s["blk.block.2.bias"] = (co,)
+        s["blk.block.3.weight"] = (co,); s["blk.block.3.bias"] = (co,)
+        s["blk.block.6.weight"] = (co, co, 3, 3); s["blk.block.6.bias"] = (co,)
+        if ci != co:
+            s["blk.shortcut.weight"] = (co, ci, 1, 1); s["blk.shortcut.bias"] = (co,)
+    elif kind == "attn":
+        c = dims[0]
+        s["blk.norm.weight"] = (c,); s["blk.norm.bias"] = (c,)
+        s["blk.attn.in_proj_weight"] = (3 * c, c); s["blk.attn.in_proj_bias"] = (3 * c,)
+        s["blk.attn.out_proj.weight"] = (c, c); s["blk.attn.out_proj.bias"] = (c,)
+    else:
+        c = dims[0]
+        s["blk.conv.weight"] = (c, c, 3, 3); s["blk.conv.bias"] = (c,)
+    return {k: O.det_value(k, shp) for k, shp in s.items()}
+
+
+@pytest.mark.parametrize("name", list(BLOCK_CASES))
+def test_blocks(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "blocks.npz"))
+    kind, dims = BLOCK_CASES[name]
+    P = leafify(_block_params(kind, dims))
+    x = T(g[f"{name}.x"]).requires_grad_(True)
+    if kind == "res":
+        y = O.resnet_block(P, "blk", x)
+    elif kind == "nonres":
+        y = O.resnet_block(P, "blk", x, residual=False)
+    elif kind == "nonres4":
+        y = O.resnet_block(P, "blk", x, residual=False, num_groups=4)
+    elif kind == "attn":
+        y = O.attn_block(P, "blk", x)
+    elif kind == "down":
+        y = O.downsample(P, "blk", x)
+    else:
+        y = O.upsample(P, "blk", x)
+    (y * T(g[f"{name}.gy"])).sum().backward()
+    close(y, g[f"{name}.y"], name=name + ".y")
+    close(x.grad, g[f"{name}.gx"], name=name + ".gx")
+    for k in P:
+        if P[k].grad is not None:
+            close(P[k].grad, g[f"{name}.g.{k[4:]}"], rtol=1e-4, name=name + ".g." + k)
+
+
+def test_blur(golden_dir):
+    g = np.load(os.path.join(golden_dir, "blur.npz"))
+    tags = sorted({k.split(".")[0] for k in g.files})
+    assert len(tags) == 4
+    for tag in tags:
+        k = int(tag.split("_")[0][1:])
+        x = T(g[f"{tag}.x"]).requires_grad_(True)
+        s = torch.tensor(float(g[f"{tag}.sigma"]), requires_grad=True)
+        close(O.gaussian_kernel1d(k, s), g[f"{tag}.k1d"], name=tag + ".k1d")
+        y = O.gaussian_blur(x, s, k)
+        (y * T(g[f"{tag}.gy"])).sum().backward()
+        close(y, g[f"{tag}.y"], name=tag + ".y")
+        close(x.grad, g[f"{tag}.gx"], name=tag + ".gx")
+        close(s.grad, g[f"{tag}.gsig"][1], rtol=1e-4, name=tag + ".gsig")
+
+
+def test_gaussian_kernel_known_values():
+    # k1d(9, sigma=3) = [.0630,.0929,.1226,.1449,.1532,...]
+    k = O.gaussian_kernel1d(9, torch.tensor(3.0))
+    ref = torch.tensor([0.0630, 0.0929, 0.1226, 0.1449, 0.1532, 0.1449, 0.1226, 0.0929, 0.0630])
+    assert float((k - ref).abs().max()) < 6e-5
+
+
+VQ_CASES = [("c64", 32, None, 64, (2, 32, 4, 4), 2), ("proj", 3, 16, 48, (2, 3, 6, 6), 2), ("c1024", 256, None, 1024, (2, 256, 8, 8), 1)]
+
+
+@pytest.mark.parametrize("case", VQ_CASES, ids=[c[0] for c in VQ_CASES])
+def test_vq(golden_dir, case):
+    g = np.load(os.path.join(golden_dir, "vq.npz"))
+    tag, dim, cdim, C, shp, steps = case
+    cfg = O.OracleConfig(codebook_size=C, n_embed=dim, codebook_dim=cdim, commitment_weight=0.7)
+    shapes = {k: v for k, v in O.param_shapes(cfg, with_disc=False).items() if k.startswith("quantizer.")}
+    P = leafify({k: O.det_value(k, s) for k, s in shapes.items()})
+    n = int(np.prod(shp))
+    for s in range(steps):
+        z = (1.5 * (2 * O._hash_uniform(n, int(g[f"{tag}.s{s}.zseed"])).reshape(shp) - 1)).float().requires_grad_(True)
+        gq = (2 * O._hash_uniform(n, 8).reshape(shp) - 1).float()
+        q, ind, loss, _ = O.vector_quantize_forward(P, z, cfg, training=True)
+        ((q * gq).sum() + 3.0 * loss.sum()).backward()
+        assert np.array_equal(ind.numpy(), g[f"{tag}.s{s}.ind"]), "indices must be bit-exact"
+        close(loss, g[f"{tag}.s{s}.loss"], name="loss")
+        close(q[:, :8, :2, :2], g[f"{tag}.s{s}.q_slice"], name="q")
+        close(q.double().sum(), g[f"{tag}.s{s}.q_sum"], rtol=1e-4, name="q_sum")
+        close(z.grad[:, :8, :2, :2], g[f"{tag}.s{s}.gz_slice"], name="gz")
+        close(P["quantizer._codebook.embed"][0, :16, :8], g[f"{tag}.s{s}.embed_slice"], name="embed")
+        close(P["quantizer._codebook.embed"].double().abs().sum(), g[f"{tag}.s{s}.embed_abs"], rtol=1e-6, name="embed_abs")
+        close(P["quantizer._codebook.cluster_size"], g[f"{tag}.s{s}.cluster"], name="cluster")
+        for k in P:
+            if P[k].grad is not None:
+                close(P[k].grad, g[f"{tag}.s{s}.g.{k[len('quantizer.'):]}"], rtol=1e-4, name=k)
+                P[k].grad = None
+    z = (2 * O._hash_uniform(n, 999).reshape(shp) - 1).float()
+    q, ind, loss, _ = O.vector_quantize_forward(P, z, cfg, training=False)
+    assert np.array_equal(ind.numpy(), g[f"{tag}.eval.ind"])
+    assert float(loss) == 0.0 and float(g[f"{tag}.eval.loss"][0]) == 0.0
+    close(q[:, :8, :2, :2], g[f"{tag}.eval.q_slice"], name="eval.q")
+    zq = O.get_codebook_entry(P, ind.reshape(shp[0], -1), (shp[0], shp[2], shp[3], cdim or dim))
+    close(zq[:, :8, :2, :2], g[f"{tag}.entry_slice"], name="entry")
+
+
+def test_hinge(golden_dir):
+    g = np.load(os.path.join(golden_dir, "hinge.npz"))
+    real, fake = T(g["real"]), T(g["fake"])
+    close(-fake.mean(), g["g"], name="hinge_g")                                 # losses/hinge.py:15
+    d = 0.5 * (torch.relu(1 - real).mean() + torch.relu(1 + fake).mean())       # losses/hinge.py:31-33
+    close(d, g["d"], name="hinge_d")
+
+
+MODEL_CFGS = {
+    "cfg1_96": dict(codebook_size=1024, variant="gauss_resblock", kernel_size=9),
+    "f4_same_conv_32": dict(codebook_size=512, n_embed=3, ch_mult=(1, 2, 4), attn_resolutions=(), codebook_dim=32,
+                            kernel_size=3, variant="same_conv_gauss", num_groups=3),
+    "nonpair_conv_80": dict(codebook_size=256, variant="non_pair_conv", kernel_size=5, dsl_init_sigma=2.0),
+}
+
+
+def _check_model_case(g, tag, cfg, with_disc=False):
+    B, H, W, seed = [int(v) for v in g[tag + ".shape"]]
+    P = leafify(O.det_state(cfg, with_disc=with_disc))
+    x = O.det_input(B, H, W, seed)
+    sc = O.StepConfig(codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, with_disc_forward=with_disc)
+    r = O.step_losses(P, x, cfg, sc)
+    r["loss_g"].sum().backward()
+    out = r["out"]
+    p = tag + "."
+    assert np.array_equal(out["indices"].numpy(), g[p + "indices"]), "codebook indices must be bit-exact"
+    xr = out["x_recon"]
+    close(xr[:, :, ::max(1, xr.shape[2] // 8), ::max(1, xr.shape[3] // 8)], g[p + "x_recon_slice"], rtol=1e-4, name="x_recon")
+    close(xr.double().abs().sum(), g[p + "x_recon_abs"], rtol=1e-5, name="x_recon_abs")
+    for k, ok in (("loss_q", "loss_quant"), ("loss_l1", "loss_l1"), ("loss_ffl", "loss_ffl"), ("loss_dsl", "loss_dsl"), ("loss_g", "loss_g")):
+        close(r[ok].reshape(-1), g[p + k], rtol=1e-5, name=k)
+    close(torch.stack([v.reshape(()) for v in r["loss_dsl_levels"]]), g[p + "loss_dsl_levels"], rtol=1e-4, name="dsl levels")
+    for i in range(4):
+        close(out["enc_feats"][i].double().abs().sum(), g[p + f"enc_feat{i}_abs"], rtol=1e-5, name=f"enc_feat{i}")
+    # dec feats were summarised in decoder order (before the in-place reverse of vqgan_losses.py:20)
+    dec = list(reversed(out["dec_feats"]))
+    for i in range(4):
+        close(dec[i].double().abs().sum(), g[p + f"dec_feat{i}_abs"], rtol=1e-5, name=f"dec_feat{i}")
+    close(P["quantizer._codebook.embed"].double().abs().sum(), g[p + "embed_after_abs"], rtol=1e-6, name="embed")
+    close(P["quantizer._codebook.cluster_size"], g[p + "cluster_after"], name="cluster")
+    n = 0
+    for k in P:
+        key = p + "g." + k + ".head"
+        if key in g.files:
+            close(P[k].grad.reshape(-1)[:16], g[key], rtol=5e-3, name="g." + k)
+            close(P[k].grad.double().abs().sum(), g[p + "g." + k + ".abs"], rtol=1e-3, name="gabs." + k)
+            n += 1
+    assert n >= 8
+    return P, r
+
+
+@pytest.mark.parametrize("tag", list(MODEL_CFGS))
+def test_model_cases(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "models.npz"))
+    _check_model_case(g, tag, O.OracleConfig(**MODEL_CFGS[tag]))
+
+
+def test_param_inventory_matches_reference_count():
+    # 371 state_dict entries for the f=16 Res-FCM model (incl. discriminator)
+    cfg = O.OracleConfig(codebook_size=1024, variant="gauss_resblock")
+    shapes = O.param_shapes(cfg, with_disc=True)
+    assert len(shapes) == 371
+    enc = sum(int(np.prod(s)) for k, s in shapes.items() if k.startswith("encoder."))
+    dec = sum(int(np.prod(s)) for k, s in shapes.items() if k.startswith("decoder."))
+    assert enc == 29363972 and dec == 53369991
+
+
+@pytest.mark.slow
+def test_cfg1_full_256(golden_dir):
+    """BASELINE config 1 (f=16, codebook 1024, 256x256, batch 2): ~40 s of CPU."""
+    path = os.path.join(golden_dir, "cfg1_256.npz")
+    g = np.load(path)
+    cfg = O.OracleConfig(**MODEL_CFGS["cfg1_96"])
+    P, r = _check_model_case(g, "cfg1_256", cfg, with_disc=True)
+    lf = r["out"]["logits_fake"]
+    close(lf.double().abs().sum(), g["cfg1_256.logits_fake_abs"], rtol=1e-5, name="logits_fake")
+    close(P["discriminator.features.3.running_mean"], g["cfg1_256.bn_running_mean"], rtol=1e-5, name="bn")
+    with torch.no_grad():
+        for k in ("encoder.conv_in.weight", "decoder.final.2.weight", "encoder.sigmas", "decoder.sigmas"):
+            m = torch.zeros_like(P[k]); v = torch.zeros_like(P[k])
+            O.adam_update(P[k], P[k].grad, m, v, 1, 4.5e-6 * 2, (0.5, 0.9), 1e-8)
+            close(P[k].reshape(-1)[:16], g[f"cfg1_256.adam.{k}.head"], rtol=1e-6, name="adam." + k)
