@@ -1,0 +1,60 @@
+// Shared device/host helpers for libfavae_hip (gfx950 / CDNA4 only: wave = 64 lanes, fp32 MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/favae_hip.h"
+
+#define FAVAE_CHECK_LAUNCH()                                   \
+    do {                                                       \
+        hipError_t e__ = hipGetLastError();                    \
+        if (e__ != hipSuccess) return FAVAE_ERR_LAUNCH;        \
+    } while (0)
+
+#define FAVAE_REQUIRE(cond)                                    \
+    do {                                                       \
+        if (!(cond)) return FAVAE_ERR_BAD_ARG;                 \
+    } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); `red` is >= 4 doubles of LDS. Result valid in every thread.
+__device__ __forceinline__ double block_sum_d256(double v, double* red) {
+    v = wave_sum_d(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + __expf(-y)); }
+
+// XCD-aware bijective remap of a 1-D block id: each of the 8 XCDs (private L2) gets a contiguous chunk of logical
+// tile ids so that neighbouring tiles (shared halo rows / shared A panels) hit the same L2.  (guide T1, bijective form)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    const int q = nwg / nx, r = nwg % nx;
+    const int xcd = bid % nx, k = bid / nx;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}

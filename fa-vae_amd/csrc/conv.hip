@@ -1,0 +1,624 @@
+// Implicit-GEMM convolution family for gfx950 on the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32.
+//
+//   forward / data-gradient : out[m][co] = sum_{tap,ci} T(x)[gather(m,tap)][ci] * w[co][tap][ci]   (+bias +resid)
+//   weight-gradient         : dw[co][tap][ci] = sum_m dy[m][co] * T(x)[gather(m,tap)][ci]           (split-K over m)
+//
+// m runs over output pixels (n,oh,ow) in NHWC order, T() is the fused GroupNorm/BatchNorm affine + activation of the
+// layer in front of the conv (models/codec.py:38-46), gather() folds zero padding, stride, nearest-x2 upsampling
+// (codec.py:17) or x2 zero-dilation (data gradient of the stride-2 Downsample conv, codec.py:26-29).
+//
+// Tiling (one workgroup = 4 waves = 256 threads):
+//   fwd : BM=128 output pixels x BN in {128,64,32} output channels, BK=16 input channels per (tap) step.
+//         LDS tiles are [row][BK+4] (k contiguous, +4 floats of padding => conflict-free ds_read_b128): a lane reads
+//         4 consecutive k of its row with ONE ds_read_b128 and feeds 4 MFMAs (lanes 0-31 carry k 0..3, lanes 32-63
+//         carry k 4..7 of each 8-wide k group; A and B use the same split so the products pair up).
+//   wgrad: 128(co) x 128(ci) per tap, 16 pixels per step, LDS tiles [k][row] read with conflict-free ds_read_b32.
+//   Global loads are 16 B per lane along the channel dimension (NHWC => fully coalesced), register-staged and
+//   double-buffered through LDS so that the loads of step i+1 are in flight during the MFMAs of step i.
+//   blockIdx is remapped XCD-aware: tiles that share input rows / halos land on the same XCD's L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 16;
+constexpr int LDK = BK + 4;   // padded row length (floats) of the [row][k] LDS tiles
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* resid;
+    const float* scale;
+    const float* shift;
+    float* y;
+    int N, Hin, Win, Cin, Hout, Wout, Cout;
+    int KH, KW, stride, pad, gather, act, aff_stride;
+    int M;            // N*Hout*Wout
+    int tiles_m, tiles_n;
+    int kchunks;      // ceil(Cin/BK)
+    int vec;          // Cin % 4 == 0 (16-byte channel loads legal)
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == FAVAE_ACT_SILU) return silu_f(v);
+    if (act == FAVAE_ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
+    return v;
+}
+
+// Resolve output pixel (oh,ow) + tap (kh,kw) to an input pixel; returns false for padding / dilation holes.
+__device__ __forceinline__ bool gather_src(const ConvArgs& a, int oh, int ow, int kh, int kw, int& sh, int& sw) {
+    int vh = oh * a.stride + kh - a.pad;
+    int vw = ow * a.stride + kw - a.pad;
+    if (a.gather == FAVAE_GATHER_PLAIN) {
+        sh = vh; sw = vw;
+        return (unsigned)vh < (unsigned)a.Hin && (unsigned)vw < (unsigned)a.Win;
+    } else if (a.gather == FAVAE_GATHER_UPSAMPLE2) {
+        sh = vh >> 1; sw = vw >> 1;
+        return (unsigned)vh < (unsigned)(2 * a.Hin) && (unsigned)vw < (unsigned)(2 * a.Win);
+    } else {  // zero-dilated x2: only even virtual coordinates carry data
+        sh = vh >> 1; sw = vw >> 1;
+        return vh >= 0 && vw >= 0 && !(vh & 1) && !(vw & 1) && sh < a.Hin && sw < a.Win;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward / data-gradient kernel
+// ---------------------------------------------------------------------------------------------------------------
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int MI = WTM / 32, NI = WTN / 32;
+    constexpr int A_LD = (BM * BK / 4) / 256;                         // float4 loads of A per thread (=2)
+    constexpr int B_LD = (BN * BK / 4 + 255) / 256;                   // float4 loads of B per thread (2,1,1)
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDK];
+    float* As = lds;                      // [2][BM][LDK]
+    float* Bs = lds + 2 * BM * LDK;       // [2][BN][LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
+
+    // ---- per-thread fixed A rows ---------------------------------------------------------------------------
+    const int c4 = tid & 3;               // which float4 of the BK=16 chunk
+    int a_n[A_LD], a_oh[A_LD], a_ow[A_LD];
+    bool a_ok[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        int m = m0 + (tid >> 2) + 64 * j;
+        a_ok[j] = m < a.M;
+        int mm = a_ok[j] ? m : 0;
+        int hw = a.Hout * a.Wout;
+        a_n[j] = mm / hw;
+        int r = mm - a_n[j] * hw;
+        a_oh[j] = r / a.Wout;
+        a_ow[j] = r - a_oh[j] * a.Wout;
+    }
+    const int b_row0 = tid >> 2;          // B rows handled: b_row0 + 64*j
+
+    float4 ra[A_LD], rsc[A_LD], rsh[A_LD], rb[B_LD];
+    bool rav[A_LD];
+    const int T = a.KH * a.KW * a.kchunks;
+
+    auto load_tiles = [&](int it) {
+        const int tap = it / a.kchunks;
+        const int k0 = (it - tap * a.kchunks) * BK + c4 * 4;
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            int sh, sw;
+            bool ok = a_ok[j] && gather_src(a, a_oh[j], a_ow[j], kh, kw, sh, sw) && k0 < a.Cin;
+            rav[j] = ok;
+            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const float* p = a.x + ((size_t)(a_n[j] * a.Hin + sh) * a.Win + sw) * a.Cin + k0;
+                if (a.vec) {
+                    ra[j] = *reinterpret_cast<const float4*>(p);
+                    if (a.scale) {
+                        const size_t so = (size_t)a_n[j] * a.aff_stride + k0;
+                        rsc[j] = *reinterpret_cast<const float4*>(a.scale + so);
+                        rsh[j] = *reinterpret_cast<const float4*>(a.shift + so);
+                    }
+                } else {
+                    float t[4], s1[4], s2[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bool in = k0 + e < a.Cin;
+                        t[e] = in ? p[e] : 0.f;
+                        const size_t so = (size_t)a_n[j] * a.aff_stride + k0 + e;
+                        s1[e] = (in && a.scale) ? a.scale[so] : 0.f;
+                        s2[e] = (in && a.scale) ? a.shift[so] : 0.f;
+                    }
+                    ra[j] = make_float4(t[0], t[1], t[2], t[3]);
+                    rsc[j] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+                    rsh[j] = make_float4(s2[0], s2[1], s2[2], s2[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int row = b_row0 + 64 * j;
+            const int co = n0 + row;
+            rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < BN && co < a.Cout && k0 < a.Cin) {
+                const float* p = a.w + ((size_t)co * (a.KH * a.KW) + tap) * a.Cin + k0;
+                if (a.vec) {
+                    rb[j] = *reinterpret_cast<const float4*>(p);
+                } else {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = (k0 + e < a.Cin) ? p[e] : 0.f;
+                    rb[j] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            float4 v = ra[j];
+            if (a.scale && rav[j]) {
+                v.x = apply_act(fmaf(v.x, rsc[j].x, rsh[j].x), a.act);
+                v.y = apply_act(fmaf(v.y, rsc[j].y, rsh[j].y), a.act);
+                v.z = apply_act(fmaf(v.z, rsc[j].z, rsh[j].z), a.act);
+                v.w = apply_act(fmaf(v.w, rsc[j].w, rsh[j].w), a.act);
+            }
+            *reinterpret_cast<float4*>(&As[(buf * BM + (tid >> 2) + 64 * j) * LDK + c4 * 4]) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int row = b_row0 + 64 * j;
+            if (row < BN) *reinterpret_cast<float4*>(&Bs[(buf * BN + row) * LDK + c4 * 4]) = rb[j];
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    for (int it = 0; it < T; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < T) load_tiles(it + 1);
+        const float* Ab = As + (cur * BM + wm * WTM + frow) * LDK + fk;
+        const float* Bb = Bs + (cur * BN + wn * WTN + frow) * LDK + fk;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float4 af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (it + 1 < T) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ---------------
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + wn * WTN + j * 32 + (lane & 31);
+            if (col >= a.Cout) continue;
+            const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < a.M) {
+                    const size_t o = (size_t)row * a.Cout + col;
+                    float v = acc[i][j][r] + bv;
+                    if (a.resid) v += a.resid[o];
+                    a.y[o] = v;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight-gradient kernel: D[co][ci] (per tap) = sum over pixels
+// ---------------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    const float* scale;
+    const float* shift;
+    float* part;      // [splitk][Cout][taps][Cin]
+    int N, Hin, Win, Cin, Hout, Wout, Cout;
+    int KH, KW, stride, pad, gather, act, aff_stride;
+    int M, tiles_co, tiles_ci, splitk, chunk;   // chunk = pixels per split (multiple of 16)
+    int vec_i, vec_o;
+};
+
+template <int BCO, int BCI, int WAVES_O, int WAVES_I>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int BKP = 16;                              // pixels per step
+    constexpr int WTO = BCO / WAVES_O, WTI = BCI / WAVES_I;
+    constexpr int MI = WTO / 32, NI = WTI / 32;
+    constexpr int O_LD = (BKP * BCO / 4 + 255) / 256;    // float4 per thread for the dy tile
+    constexpr int I_LD = (BKP * BCI / 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BKP * (BCO + BCI)];
+    float* Os = lds;                       // [2][BKP][BCO]
+    float* Is = lds + 2 * BKP * BCO;       // [2][BKP][BCI]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wo = wid / WAVES_I, wi = wid % WAVES_I;
+    const int taps = a.KH * a.KW;
+    int t = blockIdx.x;
+    const int tap = t % taps; t /= taps;
+    const int ci0 = (t % a.tiles_ci) * BCI;
+    const int co0 = (t / a.tiles_ci) * BCO;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int z = blockIdx.y;
+    const int p_begin = z * a.chunk;
+    const int p_end = min(a.M, p_begin + a.chunk);
+    const int T = (p_end > p_begin) ? (p_end - p_begin + BKP - 1) / BKP : 0;
+
+    ConvArgs g;   // only the fields gather_src() reads
+    g.stride = a.stride; g.pad = a.pad; g.gather = a.gather; g.Hin = a.Hin; g.Win = a.Win;
+
+    float4 ro[O_LD], ri[I_LD], rsc[I_LD], rsh[I_LD];
+    bool riv[I_LD];
+    const int hw = a.Hout * a.Wout;
+
+    auto load_tiles = [&](int it) {
+        const int pb = p_begin + it * BKP;
+#pragma unroll
+        for (int j = 0; j < O_LD; ++j) {
+            const int i = tid + 256 * j;
+            const int p = i / (BCO / 4), c = (i % (BCO / 4)) * 4;
+            const int m = pb + p, co = co0 + c;
+            ro[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < BKP && m < p_end && co < a.Cout) {
+                const float* q = a.dy + (size_t)m * a.Cout + co;
+                if (a.vec_o) ro[j] = *reinterpret_cast<const float4*>(q);
+                else {
+                    float tt[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tt[e] = (co + e < a.Cout) ? q[e] : 0.f;
+                    ro[j] = make_float4(tt[0], tt[1], tt[2], tt[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < I_LD; ++j) {
+            const int i = tid + 256 * j;
+            const int p = i / (BCI / 4), c = (i % (BCI / 4)) * 4;
+            const int m = pb + p, ci = ci0 + c;
+            ri[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            riv[j] = false;
+            if (p < BKP && m < p_end && ci < a.Cin) {
+                const int n = m / hw;
+                const int r = m - n * hw;
+                const int oh = r / a.Wout, ow = r - oh * a.Wout;
+                int sh, sw;
+                if (gather_src(g, oh, ow, kh, kw, sh, sw)) {
+                    riv[j] = true;
+                    const float* q = a.x + ((size_t)(n * a.Hin + sh) * a.Win + sw) * a.Cin + ci;
+                    const size_t so = (size_t)n * a.aff_stride + ci;
+                    if (a.vec_i) {
+                        ri[j] = *reinterpret_cast<const float4*>(q);
+                        if (a.scale) {
+                            rsc[j] = *reinterpret_cast<const float4*>(a.scale + so);
+                            rsh[j] = *reinterpret_cast<const float4*>(a.shift + so);
+                        }
+                    } else {
+                        float tt[4], s1[4], s2[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            bool in = ci + e < a.Cin;
+                            tt[e] = in ? q[e] : 0.f;
+                            s1[e] = (in && a.scale) ? a.scale[so + e] : 0.f;
+                            s2[e] = (in && a.scale) ? a.shift[so + e] : 0.f;
+                        }
+                        ri[j] = make_float4(tt[0], tt[1], tt[2], tt[3]);
+                        rsc[j] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+                        rsh[j] = make_float4(s2[0], s2[1], s2[2], s2[3]);
+                    }
+                }
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < O_LD; ++j) {
+            const int i = tid + 256 * j;
+            const int p = i / (BCO / 4), c = (i % (BCO / 4)) * 4;
+            if (p < BKP) *reinterpret_cast<float4*>(&Os[(buf * BKP + p) * BCO + c]) = ro[j];
+        }
+#pragma unroll
+        for (int j = 0; j < I_LD; ++j) {
+            const int i = tid + 256 * j;
+            const int p = i / (BCI / 4), c = (i % (BCI / 4)) * 4;
+            float4 v = ri[j];
+            if (a.scale && riv[j]) {
+                v.x = apply_act(fmaf(v.x, rsc[j].x, rsh[j].x), a.act);
+                v.y = apply_act(fmaf(v.y, rsc[j].y, rsh[j].y), a.act);
+                v.z = apply_act(fmaf(v.z, rsc[j].z, rsh[j].z), a.act);
+                v.w = apply_act(fmaf(v.w, rsc[j].w, rsh[j].w), a.act);
+                if (!a.vec_i) {   // zero the channel tail (silu(shift) of a non-existent channel must not leak)
+                    const int ci = ci0 + c;
+                    if (ci + 1 >= a.Cin) v.y = 0.f;
+                    if (ci + 2 >= a.Cin) v.z = 0.f;
+                    if (ci + 3 >= a.Cin) v.w = 0.f;
+                }
+            }
+            if (p < BKP) *reinterpret_cast<float4*>(&Is[(buf * BKP + p) * BCI + c]) = v;
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (T > 0) {
+        load_tiles(0);
+        store_tiles(0);
+    }
+    __syncthreads();
+    const int frow = lane & 31, fk = lane >> 5;
+    for (int it = 0; it < T; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < T) load_tiles(it + 1);
+        const float* Ob = Os + (cur * BKP + fk) * BCO + wo * WTO + frow;
+        const float* Ib = Is + (cur * BKP + fk) * BCI + wi * WTI + frow;
+#pragma unroll
+        for (int kk = 0; kk < BKP / 2; ++kk) {
+            float af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = Ob[kk * 2 * BCO + i * 32];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[j] = Ib[kk * 2 * BCI + j * 32];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < T) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int ci = ci0 + wi * WTI + j * 32 + (lane & 31);
+            if (ci >= a.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wo * WTO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < a.Cout)
+                    a.part[(((size_t)z * a.Cout + co) * taps + tap) * a.Cin + ci] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ void reduce_slabs_kernel(const float* part, float* out, size_t n, int slabs) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < slabs; ++z) s += part[(size_t)z * n + i];
+    out[i] = s;
+}
+
+__global__ void weight_flip_kernel(const float* w, float* wt, int Cout, int KH, int KW, int Cin) {
+    // wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]; 32x32 LDS-tiled transpose per tap
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int kh = tap / KW, kw = tap % KW;
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        int co = co0 + r, ci = ci0 + tx;
+        tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * KH * KW + tap) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+    const int tapf = (KH - 1 - kh) * KW + (KW - 1 - kw);
+    for (int r = ty; r < 32; r += 8) {
+        int ci = ci0 + r, co = co0 + tx;
+        if (ci < Cin && co < Cout) wt[((size_t)ci * KH * KW + tapf) * Cout + co] = tile[tx][r];
+    }
+}
+
+// column sums: stage 1 = per-block partial over a row range, stage 2 = reduce_slabs_kernel
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* a, float* part, long M, int C, long rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long r = r0;
+    for (; r + 3 < r1; r += 4) {
+        s0 += a[r * C + c];
+        s1 += a[(r + 1) * C + c];
+        s2 += a[(r + 2) * C + c];
+        s3 += a[(r + 3) * C + c];
+    }
+    for (; r < r1; ++r) s0 += a[r * C + c];
+    part[(size_t)blockIdx.y * C + c] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ void upsample2x_bwd_kernel(const float* du, float* dx, int N, int H, int W, int C4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)N * H * W * C4;
+    if (i >= total) return;
+    int c = i % C4;
+    size_t p = i / C4;
+    int w = p % W; p /= W;
+    int h = p % H;
+    int n = p / H;
+    const float4* s = reinterpret_cast<const float4*>(du);
+    size_t W2 = 2 * (size_t)W;
+    size_t b = (((size_t)n * 2 * H + 2 * h) * W2 + 2 * w) * C4 + c;
+    float4 v0 = s[b], v1 = s[b + C4], v2 = s[b + W2 * C4], v3 = s[b + W2 * C4 + C4];
+    float4 o;
+    o.x = (v0.x + v1.x) + (v2.x + v3.x);
+    o.y = (v0.y + v1.y) + (v2.y + v3.y);
+    o.z = (v0.z + v1.z) + (v2.z + v3.z);
+    o.w = (v0.w + v1.w) + (v2.w + v3.w);
+    reinterpret_cast<float4*>(dx)[i] = o;
+}
+
+bool desc_ok(const favae_conv_desc* d) {
+    return d && d->N > 0 && d->Hin > 0 && d->Win > 0 && d->Cin > 0 && d->Hout > 0 && d->Wout > 0 && d->Cout > 0 &&
+           d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0 && d->gather >= 0 && d->gather <= 2 && d->act >= 0 &&
+           d->act <= 2 && (long)d->N * d->Hout * d->Wout < (1L << 31);
+}
+
+int wgrad_splitk(const favae_conv_desc* d, int tiles, int* chunk) {
+    const long M = (long)d->N * d->Hout * d->Wout;
+    long want = (1536 + tiles - 1) / tiles;                  // aim at ~6 workgroups per CU in total
+    long maxk = (M + 16 * 16 - 1) / (16 * 16);               // at least 16 steps of 16 pixels per split
+    long sk = want < 1 ? 1 : want;
+    if (sk > maxk) sk = maxk;
+    if (sk < 1) sk = 1;
+    long ch = (M + sk - 1) / sk;
+    ch = (ch + 15) / 16 * 16;
+    sk = (M + ch - 1) / ch;
+    *chunk = (int)ch;
+    return (int)sk;
+}
+
+void wgrad_tiles(const favae_conv_desc* d, int* bco, int* bci) {
+    *bco = d->Cout <= 32 ? 32 : 128;
+    *bci = (d->Cin <= 32 && *bco == 128) ? 32 : 128;
+}
+
+}  // namespace
+
+extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const float* w, const float* bias,
+                              const float* resid, const float* scale, const float* shift, float* y,
+                              favae_stream_t stream) {
+    FAVAE_REQUIRE(desc_ok(d) && x && w && y);
+    FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.resid = resid; a.scale = scale; a.shift = shift; a.y = y;
+    a.N = d->N; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->Cin; a.Hout = d->Hout; a.Wout = d->Wout; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.gather = d->gather; a.act = d->act;
+    a.aff_stride = d->affine_per_image ? d->Cin : 0;
+    a.M = d->N * d->Hout * d->Wout;
+    a.kchunks = cdiv(d->Cin, BK);
+    a.vec = (d->Cin % 4 == 0) ? 1 : 0;
+    a.tiles_m = cdiv(a.M, BM);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->Cout > 64) {
+        a.tiles_n = cdiv(d->Cout, 128);
+        hipLaunchKernelGGL((conv_fwd_kernel<128, 2, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+    } else if (d->Cout > 32) {
+        a.tiles_n = 1;
+        hipLaunchKernelGGL((conv_fwd_kernel<64, 2, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+    } else {
+        a.tiles_n = 1;
+        hipLaunchKernelGGL((conv_fwd_kernel<32, 4, 1>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+    }
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" size_t favae_conv_wgrad_workspace(const favae_conv_desc* d) {
+    if (!desc_ok(d)) return 0;
+    int bco, bci, chunk;
+    wgrad_tiles(d, &bco, &bci);
+    const int tiles = cdiv(d->Cout, bco) * cdiv(d->Cin, bci) * d->KH * d->KW;
+    const int sk = wgrad_splitk(d, tiles, &chunk);
+    return (size_t)sk * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
+}
+
+extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const float* dy, const float* scale,
+                                const float* shift, float* dw, void* ws, size_t ws_bytes, favae_stream_t stream) {
+    FAVAE_REQUIRE(desc_ok(d) && x && dy && dw && ws);
+    FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
+    if (ws_bytes < favae_conv_wgrad_workspace(d)) return FAVAE_ERR_WORKSPACE;
+    int bco, bci, chunk;
+    wgrad_tiles(d, &bco, &bci);
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.part = (float*)ws;
+    a.N = d->N; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->Cin; a.Hout = d->Hout; a.Wout = d->Wout; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.gather = d->gather; a.act = d->act;
+    a.aff_stride = d->affine_per_image ? d->Cin : 0;
+    a.M = d->N * d->Hout * d->Wout;
+    a.tiles_co = cdiv(d->Cout, bco);
+    a.tiles_ci = cdiv(d->Cin, bci);
+    const int tiles = a.tiles_co * a.tiles_ci * d->KH * d->KW;
+    a.splitk = wgrad_splitk(d, tiles, &chunk);
+    a.chunk = chunk;
+    a.vec_i = (d->Cin % 4 == 0);
+    a.vec_o = (d->Cout % 4 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(tiles, a.splitk);
+    if (bco == 128 && bci == 128)
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
+    else if (bco == 32)
+        hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, a);
+    FAVAE_CHECK_LAUNCH();
+    const size_t n = (size_t)d->Cout * d->KH * d->KW * d->Cin;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, dw, n, a.splitk);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_weight_flip(const float* w, float* wt, int Cout, int KH, int KW, int Cin, favae_stream_t stream) {
+    FAVAE_REQUIRE(w && wt && Cout > 0 && KH > 0 && KW > 0 && Cin > 0);
+    dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), KH * KW);
+    hipLaunchKernelGGL(weight_flip_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt, Cout, KH, KW, Cin);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+static int colsum_blocks(int64_t M) {
+    long b = (M + 255) / 256;
+    if (b > 512) b = 512;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" size_t favae_colsum_workspace(int64_t M, int C) { return (size_t)colsum_blocks(M) * C * sizeof(float); }
+
+extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, void* ws, size_t ws_bytes,
+                            favae_stream_t stream) {
+    FAVAE_REQUIRE(a && out && ws && M > 0 && C > 0);
+    if (ws_bytes < favae_colsum_workspace(M, C)) return FAVAE_ERR_WORKSPACE;
+    const int nb = colsum_blocks(M);
+    const long rpb = (M + nb - 1) / nb;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C, 256), nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb);
+    FAVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const float*)ws, out, (size_t)C, nb);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_upsample2x_bwd(const float* du, float* dx, int N, int H, int W, int C, favae_stream_t stream) {
+    FAVAE_REQUIRE(du && dx && N > 0 && H > 0 && W > 0 && C > 0);
+    if (C % 4) return FAVAE_ERR_UNSUPPORTED;
+    size_t total = (size_t)N * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, du, dx, N, H, W,
+                       C / 4);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}

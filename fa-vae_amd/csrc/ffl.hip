@@ -1,0 +1,219 @@
+// Focal-frequency / dynamic-spectrum loss on NHWC tensors (replaces focal_frequency_loss.FocalFrequencyLoss 0.3.0 with
+// alpha = 1, patch_factor = 1; call sites favae_scripts/train_favae.py:313,318,326, losses/vqgan_losses.py:14,25-26).
+//
+//   F = fft2_ortho(pred - target)              (linearity: ONE transform instead of the package's two)
+//   w = clamp(|F| / max_{h,w}|F|, 0, 1), NaN -> 0, detached;   loss = lambda * mean(w |F|^2)
+//   dL/dpred = (2 lambda / M) Re ifft2_ortho(w F),  dL/dtarget = -dL/dpred            
+//
+// The 2-D transform is two passes of one batched 1-D kernel over an array viewed as [outer][L][inner] (inner contiguous):
+// W-axis: outer = N*H, L = W, inner = C;  H-axis: outer = N, L = H, inner = W*C.  A block owns one `outer` index and
+// IC = 32 consecutive inner elements (256-byte contiguous complex segments -> coalesced), holds the L x IC complex tile
+// in LDS, and runs an in-LDS radix-2 DIT FFT (bit-reversed load, log2 L butterfly stages, twiddles from an LDS table).
+// HBM traffic per transform pass = one read + one write of the tile; the planes never leave LDS inside a pass.
+#include "common.h"
+
+namespace {
+
+struct FftArgs {
+    const float* in0;      // complex in, or pred (real)
+    const float* in1;      // target (real) for IN_DIFF
+    float* out;            // complex out / gpred
+    float* out2;           // gtarget (optional)
+    unsigned* planemax;    // [N][C] bit patterns of max |F|^2
+    const float* gscale;   // device scalar multiplied into the real output (bwd)
+    long outer, inner;
+    int L, logL, IC, C;
+    long plane_outer_div;  // outer index -> n : n = outer / plane_outer_div
+    float scale;           // 1/sqrt(L)
+    int inverse;
+};
+
+enum { IN_COMPLEX = 0, IN_DIFF = 1 };
+enum { OUT_COMPLEX = 0, OUT_COMPLEX_MAX = 1, OUT_REAL = 2 };
+
+template <int IN, int OUT>
+__global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float2* tw = reinterpret_cast<float2*>(sm);                 // [L/2]
+    float2* data = reinterpret_cast<float2*>(sm) + (a.L / 2 > 0 ? a.L / 2 : 1);   // [L][IC]
+    const int L = a.L, IC = a.IC, tid = threadIdx.x;
+    const long chunks = (a.inner + IC - 1) / IC;
+    const long o = blockIdx.x / chunks;
+    const long i0 = (blockIdx.x % chunks) * IC;
+
+    for (int j = tid; j < L / 2; j += 256) {
+        float s, c;
+        sincospif(2.0f * (float)j / (float)L, &s, &c);
+        tw[j] = make_float2(c, a.inverse ? s : -s);
+    }
+    // ---- load (bit-reversed along L) ------------------------------------------------------------------------
+    const int ic = tid % IC, bl = tid / IC, BL = 256 / IC;
+    const bool ic_ok = i0 + ic < a.inner;
+    const size_t base = (size_t)o * L * a.inner + i0 + ic;
+    for (int l = bl; l < L; l += BL) {
+        float2 v = make_float2(0.f, 0.f);
+        if (ic_ok) {
+            const size_t idx = base + (size_t)l * a.inner;
+            if (IN == IN_DIFF) v.x = a.in0[idx] - a.in1[idx];
+            else v = reinterpret_cast<const float2*>(a.in0)[idx];
+        }
+        const int r = (int)(__brev((unsigned)l) >> (32 - a.logL));
+        data[(a.logL ? r : 0) * IC + ic] = v;
+    }
+    __syncthreads();
+    // ---- butterflies ------------------------------------------------------------------------------------------
+    for (int s = 1; s <= a.logL; ++s) {
+        const int half = 1 << (s - 1);
+        const int tstep = L >> s;
+        for (int b = bl; b < L / 2; b += BL) {
+            const int grp = b >> (s - 1), j = b & (half - 1);
+            const int p0 = (grp << s) + j, p1 = p0 + half;
+            const float2 w = tw[j * tstep];
+            const float2 x0 = data[p0 * IC + ic], x1 = data[p1 * IC + ic];
+            const float2 t = make_float2(w.x * x1.x - w.y * x1.y, w.x * x1.y + w.y * x1.x);
+            data[p0 * IC + ic] = make_float2(x0.x + t.x, x0.y + t.y);
+            data[p1 * IC + ic] = make_float2(x0.x - t.x, x0.y - t.y);
+        }
+        __syncthreads();
+    }
+    // ---- store ------------------------------------------------------------------------------------------------
+    if (!ic_ok) return;
+    float mx = 0.f;
+    const float gs = (OUT == OUT_REAL) ? a.gscale[0] * a.scale : a.scale;
+    for (int l = bl; l < L; l += BL) {
+        float2 v = data[l * IC + ic];
+        const size_t idx = base + (size_t)l * a.inner;
+        if (OUT == OUT_REAL) {
+            const float r = v.x * gs;
+            a.out[idx] = r;
+            if (a.out2) a.out2[idx] = -r;
+        } else {
+            v.x *= gs; v.y *= gs;
+            reinterpret_cast<float2*>(a.out)[idx] = v;
+            if (OUT == OUT_COMPLEX_MAX) mx = fmaxf(mx, v.x * v.x + v.y * v.y);
+        }
+    }
+    if (OUT == OUT_COMPLEX_MAX) {
+        const long n = o / a.plane_outer_div;
+        const int c = (int)((i0 + ic) % a.C);
+        atomicMax(&a.planemax[n * a.C + c], __float_as_uint(mx));       // d >= 0: uint order == float order
+    }
+}
+
+// spec <- coef * w * F (in place), per-block partial of sum(w*d) in double
+__global__ __launch_bounds__(256) void ffl_weight_kernel(float* spec, const unsigned* planemax, double* part, long per_img,
+                                                         int C, long total, float coef) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    float2* s2 = reinterpret_cast<float2*>(spec);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / per_img;
+        const int c = (int)(i % C);
+        float2 f = s2[i];
+        const float d = f.x * f.x + f.y * f.y;
+        const float mx = sqrtf(__uint_as_float(planemax[n * C + c]));
+        float w = (mx > 0.f) ? sqrtf(d) / mx : 0.f;                   // 0/0 -> NaN -> 0 upstream
+        w = fminf(fmaxf(w, 0.f), 1.f);
+        acc += (double)(w * d);
+        const float g = coef * w;
+        s2[i] = make_float2(g * f.x, g * f.y);
+    }
+    const double tot = block_sum_d256(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void ffl_finish_kernel(const double* part, int nparts, double scale, float* loss) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+    const double tot = block_sum_d256(acc, red);
+    if (threadIdx.x == 0) loss[0] = (float)(tot * scale);
+}
+
+int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+int pick_ic(int L) { return L <= 256 ? 32 : (L <= 512 ? 16 : 8); }
+size_t fft_shm(int L, int IC) { return ((size_t)(L / 2 > 0 ? L / 2 : 1) + (size_t)L * IC) * sizeof(float2); }
+constexpr int WEIGHT_BLOCKS = 2048;
+
+template <int IN, int OUT>
+int launch_fft(FftArgs& a, hipStream_t s) {
+    a.IC = pick_ic(a.L);
+    a.logL = ilog2(a.L);
+    a.scale = 1.0f / sqrtf((float)a.L);
+    const size_t shm = fft_shm(a.L, a.IC);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)fft_lines_kernel<IN, OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    const long chunks = (a.inner + a.IC - 1) / a.IC;
+    const long blocks = a.outer * chunks;
+    if (blocks <= 0 || blocks >= (1L << 31)) return FAVAE_ERR_BAD_ARG;
+    hipLaunchKernelGGL((fft_lines_kernel<IN, OUT>), dim3((unsigned)blocks), dim3(256), shm, s, a);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+}  // namespace
+
+extern "C" size_t favae_ffl_workspace(int N, int H, int W, int C) {
+    // fwd: planemax (N*C u32) + WEIGHT_BLOCKS doubles ; bwd: complex scratch
+    const size_t fwd = (size_t)N * C * sizeof(unsigned) + 256 + WEIGHT_BLOCKS * sizeof(double);
+    const size_t bwd = (size_t)N * H * W * C * 2 * sizeof(float);
+    return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int favae_ffl_fwd(const float* pred, const float* target, int N, int H, int W, int C, float loss_weight, float* loss,
+                             float* spec, void* ws, size_t ws_bytes, favae_stream_t stream) {
+    FAVAE_REQUIRE(pred && target && loss && spec && ws && N > 0 && C > 0);
+    if (!pow2(H) || !pow2(W) || H > 1024 || W > 1024) return FAVAE_ERR_UNSUPPORTED;
+    if (ws_bytes < favae_ffl_workspace(N, H, W, C)) return FAVAE_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* planemax = (unsigned*)ws;
+    double* part = (double*)((char*)ws + (((size_t)N * C * sizeof(unsigned) + 255) / 256) * 256);
+    if (hipMemsetAsync(planemax, 0, (size_t)N * C * sizeof(unsigned), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
+    FftArgs a{};
+    a.C = C;
+    // pass 1: along W, real difference in
+    a.in0 = pred; a.in1 = target; a.out = spec; a.out2 = nullptr; a.planemax = planemax; a.gscale = nullptr;
+    a.outer = (long)N * H; a.inner = C; a.L = W; a.plane_outer_div = H; a.inverse = 0;
+    int rc = launch_fft<IN_DIFF, OUT_COMPLEX>(a, s);
+    if (rc) return rc;
+    // pass 2: along H, in place, with plane max of |F|^2
+    a.in0 = spec; a.in1 = nullptr; a.out = spec;
+    a.outer = N; a.inner = (long)W * C; a.L = H; a.plane_outer_div = 1;
+    rc = launch_fft<IN_COMPLEX, OUT_COMPLEX_MAX>(a, s);
+    if (rc) return rc;
+    const long total = (long)N * H * W * C;
+    const double M = (double)total;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > WEIGHT_BLOCKS) blocks = WEIGHT_BLOCKS;
+    hipLaunchKernelGGL(ffl_weight_kernel, dim3(blocks), dim3(256), 0, s, spec, (const unsigned*)planemax, part, (long)H * W * C,
+                       C, total, (float)(2.0 * (double)loss_weight / M));
+    FAVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ffl_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)part, blocks, (double)loss_weight / M, loss);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_ffl_bwd(const float* spec, const float* gloss, int N, int H, int W, int C, float* gpred, float* gtarget,
+                             void* ws, size_t ws_bytes, favae_stream_t stream) {
+    FAVAE_REQUIRE(spec && gloss && gpred && ws && N > 0 && C > 0);
+    if (!pow2(H) || !pow2(W) || H > 1024 || W > 1024) return FAVAE_ERR_UNSUPPORTED;
+    if (ws_bytes < favae_ffl_workspace(N, H, W, C)) return FAVAE_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    FftArgs a{};
+    a.C = C;
+    a.in0 = spec; a.in1 = nullptr; a.out = (float*)ws; a.out2 = nullptr; a.planemax = nullptr; a.gscale = nullptr;
+    a.outer = N; a.inner = (long)W * C; a.L = H; a.plane_outer_div = 1; a.inverse = 1;
+    int rc = launch_fft<IN_COMPLEX, OUT_COMPLEX>(a, s);
+    if (rc) return rc;
+    a.in0 = (const float*)ws; a.out = gpred; a.out2 = gtarget; a.gscale = gloss;
+    a.outer = (long)N * H; a.inner = C; a.L = W; a.plane_outer_div = H;
+    return launch_fft<IN_COMPLEX, OUT_REAL>(a, s);
+}

@@ -1,0 +1,237 @@
+// Batched fp32 GEMM on v_mfma_f32_32x32x2_f32 + row softmax: the single-head attention core of AttnBlock
+// (models/codec.py:87-102: nn.MultiheadAttention(C, num_heads=1)):
+//     S = (Q K^T)/sqrt(C)   -> favae_bgemm(ta=0,tb=0)      P = softmax(S)   -> favae_softmax_rows
+//     O = P V               -> favae_bgemm(ta=0,tb=1)
+//     backward: dV = P^T dO (ta=1,tb=1), dP = dO V^T (0,0), dS = P*(dP - rowsum(dP*P))/sqrt(C), dQ = dS K (0,1),
+//               dK = dS^T Q (1,1)
+// Operand convention: C[m][n] = alpha * sum_k A(m,k) * B(n,k).  t? = 0: operand stored [rows][k] (k contiguous,
+// leading dimension ld = row stride); t? = 1: stored [k][rows] (rows contiguous, ld = k stride).
+// Tile 128x128x16, 4 waves of 64x64, register-staged double-buffered LDS like the conv kernels.
+#include "common.h"
+
+namespace {
+
+constexpr int GBM = 128, GBN = 128, GBK = 16, GLDK = GBK + 4;
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    long lda, ldb, ldc, sA, sB, sC;
+    int M, N, K;
+    float alpha;
+    int accumulate, vecA, vecB;
+};
+
+// loads one 128 x 16 operand tile into registers (2 float4 per thread)
+template <int T>
+__device__ __forceinline__ void load_operand(const float* base, long ld, int rows, int K, int r0, int k0, int vec, int tid,
+                                             float4 (&r)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (T == 0) {
+            const int row = r0 + (tid >> 2) + 64 * j, k = k0 + (tid & 3) * 4;
+            if (row < rows && k < K) {
+                const float* p = base + (size_t)row * ld + k;
+                if (vec) r[j] = *reinterpret_cast<const float4*>(p);
+                else {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = (k + e < K) ? p[e] : 0.f;
+                    r[j] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+        } else {
+            const int i = tid + 256 * j;
+            const int k = k0 + (i >> 5), row = r0 + (i & 31) * 4;
+            if (k < K && row < rows) {
+                const float* p = base + (size_t)k * ld + row;
+                if (vec) r[j] = *reinterpret_cast<const float4*>(p);
+                else {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = (row + e < rows) ? p[e] : 0.f;
+                    r[j] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+        }
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void store_operand(float* lds, int tid, const float4 (&r)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (T == 0) {
+            *reinterpret_cast<float4*>(&lds[((tid >> 2) + 64 * j) * GLDK + (tid & 3) * 4]) = r[j];
+        } else {
+            const int i = tid + 256 * j;
+            *reinterpret_cast<float4*>(&lds[(i >> 5) * GBM + (i & 31) * 4]) = r[j];
+        }
+    }
+}
+
+// fragment for k-group kk (8 k values): returns the 4 values this lane feeds to the 4 MFMAs of the group
+template <int T>
+__device__ __forceinline__ float4 read_frag(const float* lds, int row, int kk, int lane) {
+    const int kb = kk * 8 + (lane >> 5) * 4;
+    if (T == 0) return *reinterpret_cast<const float4*>(&lds[row * GLDK + kb]);
+    return make_float4(lds[(kb + 0) * GBM + row], lds[(kb + 1) * GBM + row], lds[(kb + 2) * GBM + row],
+                       lds[(kb + 3) * GBM + row]);
+}
+
+constexpr int lds_elems(int T) { return T == 0 ? GBM * GLDK : GBK * GBM; }
+
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void bgemm_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * (lds_elems(TA) + lds_elems(TB))];
+    float* As = lds;
+    float* Bs = lds + 2 * lds_elems(TA);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tiles_n = (a.N + GBN - 1) / GBN;
+    const int m0 = (blockIdx.x / tiles_n) * GBM, n0 = (blockIdx.x % tiles_n) * GBN;
+    const int b = blockIdx.y;
+    const float* A = a.A + (size_t)b * a.sA;
+    const float* B = a.B + (size_t)b * a.sB;
+    float* C = a.C + (size_t)b * a.sC;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[2], rb[2];
+    const int T = (a.K + GBK - 1) / GBK;
+    load_operand<TA>(A, a.lda, a.M, a.K, m0, 0, a.vecA, tid, ra);
+    load_operand<TB>(B, a.ldb, a.N, a.K, n0, 0, a.vecB, tid, rb);
+    store_operand<TA>(As, tid, ra);
+    store_operand<TB>(Bs, tid, rb);
+    __syncthreads();
+    for (int it = 0; it < T; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < T) {
+            load_operand<TA>(A, a.lda, a.M, a.K, m0, (it + 1) * GBK, a.vecA, tid, ra);
+            load_operand<TB>(B, a.ldb, a.N, a.K, n0, (it + 1) * GBK, a.vecB, tid, rb);
+        }
+        const float* Ab = As + cur * lds_elems(TA);
+        const float* Bb = Bs + cur * lds_elems(TB);
+#pragma unroll
+        for (int kk = 0; kk < GBK / 8; ++kk) {
+            float4 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = read_frag<TA>(Ab, wm * 64 + i * 32 + (lane & 31), kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = read_frag<TB>(Bb, wn * 64 + j * 32 + (lane & 31), kk, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (it + 1 < T) {
+            store_operand<TA>(As + (cur ^ 1) * lds_elems(TA), tid, ra);
+            store_operand<TB>(Bs + (cur ^ 1) * lds_elems(TB), tid, rb);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= a.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < a.M) {
+                    float* o = C + (size_t)row * a.ldc + col;
+                    float v = a.alpha * acc[i][j][r];
+                    if (a.accumulate) v += *o;
+                    *o = v;
+                }
+            }
+        }
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, float* p, long rows, int L) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* sr = s + row * L;
+    float* pr = p + row * L;
+    float mx = -INFINITY;
+    for (int i = lane; i < L; i += 64) mx = fmaxf(mx, sr[i]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int i = lane; i < L; i += 64) {
+        const float e = expf(sr[i] - mx);
+        pr[i] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int i = lane; i < L; i += 64) pr[i] *= inv;
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* p, const float* dp, float* ds, long rows, int L,
+                                                               float alpha) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* pr = p + row * L;
+    const float* dr = dp + row * L;
+    float* o = ds + row * L;
+    float dot = 0.f;
+    for (int i = lane; i < L; i += 64) dot = fmaf(pr[i], dr[i], dot);
+    dot = wave_sum(dot);
+    for (int i = lane; i < L; i += 64) o[i] = alpha * pr[i] * (dr[i] - dot);
+}
+
+bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int favae_bgemm(int ta, int tb, int M, int N, int K, float alpha, const float* A, int64_t lda, int64_t strideA,
+                           const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC, int batch,
+                           int accumulate, favae_stream_t stream) {
+    FAVAE_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && (ta == 0 || ta == 1) && (tb == 0 || tb == 1));
+    GemmArgs a;
+    a.A = A; a.B = B; a.C = C; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.sA = strideA; a.sB = strideB; a.sC = strideC;
+    a.M = M; a.N = N; a.K = K; a.alpha = alpha; a.accumulate = accumulate;
+    a.vecA = aligned16(A) && lda % 4 == 0 && strideA % 4 == 0 && (ta == 0 ? K % 4 == 0 : M % 4 == 0);
+    a.vecB = aligned16(B) && ldb % 4 == 0 && strideB % 4 == 0 && (tb == 0 ? K % 4 == 0 : N % 4 == 0);
+    dim3 grid(cdiv(M, GBM) * cdiv(N, GBN), batch);
+    hipStream_t s = (hipStream_t)stream;
+    if (ta == 0 && tb == 0) hipLaunchKernelGGL((bgemm_kernel<0, 0>), grid, dim3(256), 0, s, a);
+    else if (ta == 0 && tb == 1) hipLaunchKernelGGL((bgemm_kernel<0, 1>), grid, dim3(256), 0, s, a);
+    else if (ta == 1 && tb == 0) hipLaunchKernelGGL((bgemm_kernel<1, 0>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((bgemm_kernel<1, 1>), grid, dim3(256), 0, s, a);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_softmax_rows(const float* s, float* p, int64_t rows, int L, favae_stream_t stream) {
+    FAVAE_REQUIRE(s && p && rows > 0 && L > 0);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, s, p, (long)rows, L);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_softmax_rows_bwd(const float* p, const float* dp, float* ds, int64_t rows, int L, float alpha,
+                                      favae_stream_t stream) {
+    FAVAE_REQUIRE(p && dp && ds && rows > 0 && L > 0);
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, p, dp, ds, (long)rows,
+                       L, alpha);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}

@@ -1,0 +1,195 @@
+// Streaming reductions and element-wise glue of the training step (all HBM-bound, 16-byte accesses, grid-stride):
+//   L1 reconstruction loss and its gradient        favae_scripts/train_favae.py:76
+//   commitment (MSE) loss + straight-through bwd   models/l2_quantize.py:554,560-561
+//   Adam(betas=(0.5,0.9)) over one flat buffer     favae_scripts/train_favae.py:297-305
+//   NCHW <-> NHWC conversion at the module boundary
+// Scalar losses are produced deterministically: per-block fp64 partials -> one finishing block.
+#include "common.h"
+
+namespace {
+
+constexpr int RED_BLOCKS = 1024;
+
+template <int SQ>
+__global__ __launch_bounds__(256) void diff_reduce_kernel(const float* a, const float* b, long n, double* part) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const long n4 = n / 4;
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    const bool vec = ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0;
+    if (vec) {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+            const float4 x = a4[i], y = b4[i];
+            const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+            if (SQ) acc += (double)(d0 * d0 + d1 * d1) + (double)(d2 * d2 + d3 * d3);
+            else acc += (double)(fabsf(d0) + fabsf(d1)) + (double)(fabsf(d2) + fabsf(d3));
+        }
+        for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+            const float d = a[i] - b[i];
+            acc += SQ ? (double)(d * d) : (double)fabsf(d);
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+            const float d = a[i] - b[i];
+            acc += SQ ? (double)(d * d) : (double)fabsf(d);
+        }
+    }
+    const double tot = block_sum_d256(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void finish_kernel(const double* part, int nparts, double scale, float* out) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+    const double tot = block_sum_d256(acc, red);
+    if (threadIdx.x == 0) out[0] = (float)(tot * scale);
+}
+
+// MODE 0: g*scale*sign(a-b) ; MODE 1: g*scale*(a-b)
+template <int MODE>
+__global__ __launch_bounds__(256) void diff_bwd_kernel(const float* a, const float* b, const float* g, float scale, long n,
+                                                       const float* add, float* out) {
+    const float gs = g[0] * scale;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = a[i] - b[i];
+        float v;
+        if (MODE == 0) v = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+        else v = gs * d;
+        if (add) v += add[i];
+        out[i] = v;
+    }
+}
+
+// straight-through estimator value exactly as the reference forms it: out = x + (q - x)   (models/l2_quantize.py:554)
+__global__ __launch_bounds__(256) void ste_kernel(const float* x, const float* q, float* out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = x[i] + (q[i] - x[i]);
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float* x, float alpha, float* y, float beta, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        y[i] = (beta == 0.f) ? alpha * x[i] : fmaf(alpha, x[i], beta * y[i]);
+}
+
+// tiled transpose between [C][HW] and [HW][C] per image
+__global__ __launch_bounds__(256) void transpose_kernel(const float* x, float* y, int rows, int cols) {
+    // x: [rows][cols] -> y: [cols][rows], batched over blockIdx.z
+    __shared__ float tile[32][33];
+    const size_t off = (size_t)blockIdx.z * rows * cols;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = x[off + (size_t)(r0 + r) * cols + c0 + tx];
+    __syncthreads();
+    for (int c = ty; c < 32; c += 8)
+        if (c0 + c < cols && r0 + tx < rows) y[off + (size_t)(c0 + c) * rows + r0 + tx] = tile[tx][c];
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1,
+                                                   float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
+int ew_blocks(long n) {
+    long b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <int SQ>
+int diff_sum(const float* a, const float* b, int64_t n, float scale, float* loss, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!(a && b && loss && ws && n > 0)) return FAVAE_ERR_BAD_ARG;
+    if (ws_bytes < RED_BLOCKS * sizeof(double)) return FAVAE_ERR_WORKSPACE;
+    long nb = (n / 4 + 255) / 256;
+    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL((diff_reduce_kernel<SQ>), dim3((int)nb), dim3(256), 0, s, a, b, (long)n, (double*)ws);
+    FAVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, (int)nb, (double)scale, loss);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+}  // namespace
+
+extern "C" int favae_abi_version(void) { return 1; }
+
+extern "C" size_t favae_reduce_workspace(int64_t n) { (void)n; return RED_BLOCKS * sizeof(double); }
+
+extern "C" int favae_absdiff_sum(const float* a, const float* b, int64_t n, float scale, float* loss, void* ws, size_t ws_bytes,
+                                 favae_stream_t stream) {
+    return diff_sum<0>(a, b, n, scale, loss, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int favae_sqdiff_sum(const float* a, const float* b, int64_t n, float scale, float* loss, void* ws, size_t ws_bytes,
+                                favae_stream_t stream) {
+    return diff_sum<1>(a, b, n, scale, loss, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int favae_absdiff_bwd(const float* a, const float* b, const float* g, float scale, int64_t n, const float* out_add,
+                                 float* out, favae_stream_t stream) {
+    FAVAE_REQUIRE(a && b && g && out && n > 0);
+    hipLaunchKernelGGL((diff_bwd_kernel<0>), dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, g, scale, (long)n,
+                       out_add, out);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+extern "C" int favae_sqdiff_bwd(const float* a, const float* b, const float* g, float scale, int64_t n, const float* out_add,
+                                float* out, favae_stream_t stream) {
+    FAVAE_REQUIRE(a && b && g && out && n > 0);
+    hipLaunchKernelGGL((diff_bwd_kernel<1>), dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, g, scale, (long)n,
+                       out_add, out);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_vq_ste(const float* x, const float* q, float* out, int64_t n, favae_stream_t stream) {
+    FAVAE_REQUIRE(x && q && out && n > 0);
+    hipLaunchKernelGGL(ste_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, q, out, (long)n);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_axpby(const float* x, float alpha, float* y, float beta, int64_t n, favae_stream_t stream) {
+    FAVAE_REQUIRE(x && y && n > 0);
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, alpha, y, beta, (long)n);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, favae_stream_t stream) {
+    FAVAE_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0);
+    const int rows = C, cols = H * W;     // [C][HW] -> [HW][C]
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32), N), dim3(256), 0, (hipStream_t)stream, x, y, rows,
+                       cols);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+extern "C" int favae_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, favae_stream_t stream) {
+    FAVAE_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0);
+    const int rows = H * W, cols = C;     // [HW][C] -> [C][HW]
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32), N), dim3(256), 0, (hipStream_t)stream, x, y, rows,
+                       cols);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                               float eps, int step, float grad_scale, favae_stream_t stream) {
+    FAVAE_REQUIRE(p && g && m && v && n > 0 && step >= 1);
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2,
+                       eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}

@@ -1,0 +1,309 @@
+// GroupNorm statistics / fused GroupNorm(+SiLU) backward for NHWC tensors (HBM-bound streaming kernels).
+//
+//   stats : per (image n, group g) mean and 1/sqrt(var+eps) over cpg = C/G channels x HW pixels, emitted both as
+//           (mean, rstd) and as the per-(n,c) affine  scale = rstd*gamma, shift = beta - mean*rstd*gamma  that the conv
+//           kernels apply while they load their input tile (the normalised tensor is never written to HBM).
+//   bwd   : da = dL/d act(GN(x))  ->  dx, dgamma, dbeta  (SURVEY Appendix C):
+//           dy = da * act'(y);  S1[n,c] = sum_hw dy, S2[n,c] = sum_hw dy*xhat  (pass 1, streaming)
+//           k1[n,g] = mean_g(gamma*S1), k2[n,g] = mean_g(gamma*S2), dgamma = sum_n S2, dbeta = sum_n S1   (tiny)
+//           dx = rstd * (dy*gamma - k1 - xhat*k2) (+ dx_add)                                                (pass 2)
+// Accumulation is in fp64 (cheap next to the HBM traffic) so E[x^2]-mean^2 does not cancel.
+// Layout of the work: a block owns a contiguous range of pixels of ONE image and all C channels; lanes run along the
+// channel dimension (16-byte loads when C % 4 == 0), so every global access is a full contiguous row segment.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float act_grad(float y, int act) {
+    if (act == FAVAE_ACT_SILU) {
+        const float s = 1.0f / (1.0f + __expf(-y));
+        return s * (1.0f + y * (1.0f - s));
+    }
+    if (act == FAVAE_ACT_LEAKY02) return y > 0.f ? 1.0f : 0.2f;
+    return 1.0f;
+}
+
+// partial[n][split][c][2] (double): sum, sumsq of x        (MODE 0)
+//                                   S1, S2 of the backward (MODE 1)
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ da,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         double* __restrict__ part, long HW, int C, int G, int act,
+                                                         long rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];     // [rl][C][2]
+    const int n = blockIdx.y, split = blockIdx.x, S = gridDim.x;
+    const int cols = C;                               // one thread per channel, rl row-lanes
+    const int rl = max(1, 256 / cols);
+    const long r0 = (long)split * rows_per_block;
+    const long r1 = min(HW, r0 + rows_per_block);
+    const int cpg = C / G;
+    for (int cb = 0; cb < C; cb += 256) {             // channel blocks (C > 256 loops)
+        const int c = cb + (threadIdx.x % min(cols, 256));
+        const int lanei = threadIdx.x / min(cols, 256);
+        double s1 = 0.0, s2 = 0.0;
+        if (c < C && lanei < rl) {
+            float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f;
+            if (MODE == 1) {
+                mu = mean[n * G + c / cpg];
+                rs = rstd[n * G + c / cpg];
+                ga = gamma[c];
+                be = beta[c];
+            }
+            const float* xp = x + ((size_t)n * HW) * C + c;
+            const float* dp = MODE == 1 ? da + ((size_t)n * HW) * C + c : nullptr;
+            for (long r = r0 + lanei; r < r1; r += rl) {
+                const float xv = xp[r * C];
+                if (MODE == 0) {
+                    s1 += (double)xv;
+                    s2 += (double)xv * (double)xv;
+                } else {
+                    const float xh = (xv - mu) * rs;
+                    const float y = fmaf(xh, ga, be);
+                    const float dy = dp[r * C] * act_grad(y, act);
+                    s1 += (double)dy;
+                    s2 += (double)dy * (double)xh;
+                }
+            }
+        }
+        // reduce the rl row-lanes through LDS
+        const int ccount = min(cols, 256);
+        if (lanei < rl && c < C) {
+            sm[(lanei * ccount + (c - cb)) * 2 + 0] = s1;
+            sm[(lanei * ccount + (c - cb)) * 2 + 1] = s2;
+        }
+        __syncthreads();
+        if (lanei == 0 && c < C) {
+            for (int l = 1; l < rl; ++l) {
+                s1 += sm[(l * ccount + (c - cb)) * 2 + 0];
+                s2 += sm[(l * ccount + (c - cb)) * 2 + 1];
+            }
+            double* o = part + (((size_t)n * S + split) * C + c) * 2;
+            o[0] = s1;
+            o[1] = s2;
+        }
+        __syncthreads();
+    }
+}
+
+// one block per (n): finalise group statistics and the per-channel affine
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, float* __restrict__ scale,
+                                                          float* __restrict__ shift, long HW, int C, int G, int S, float eps) {
+    const int n = blockIdx.x;
+    const int cpg = C / G;
+    __shared__ float s_mean[1024], s_rstd[1024];
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int s = 0; s < S; ++s)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+                const double* p = part + (((size_t)n * S + s) * C + c) * 2;
+                s1 += p[0];
+                s2 += p[1];
+            }
+        const double cnt = (double)cpg * (double)HW;
+        const double mu = s1 / cnt;
+        double var = s2 / cnt - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float rs = (float)(1.0 / sqrt(var + (double)eps));
+        mean[n * G + g] = (float)mu;
+        rstd[n * G + g] = rs;
+        if (g < 1024) { s_mean[g] = (float)mu; s_rstd[g] = rs; }
+    }
+    __syncthreads();
+    if (scale) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const int g = c / cpg;
+            const float mu = (g < 1024) ? s_mean[g] : mean[n * G + g];
+            const float rs = (g < 1024) ? s_rstd[g] : rstd[n * G + g];
+            const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+            const float sc = rs * ga;
+            scale[(size_t)n * C + c] = sc;
+            shift[(size_t)n * C + c] = be - mu * sc;
+        }
+    }
+}
+
+// one block: k1/k2 per (n,g), dgamma/dbeta per channel.  part = [N][S][C][2]
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
+                                                              float* __restrict__ k1, float* __restrict__ k2,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int N,
+                                                              long HW, int C, int G, int S) {
+    const int cpg = C / G;
+    // per-(n,g) means
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * G; i += gridDim.x * blockDim.x) {
+        const int n = i / G, g = i % G;
+        double a = 0.0, b = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int s = 0; s < S; ++s) {
+                const double* p = part + (((size_t)n * S + s) * C + c) * 2;
+                s1 += p[0];
+                s2 += p[1];
+            }
+            a += (double)gamma[c] * s1;
+            b += (double)gamma[c] * s2;
+        }
+        const double cnt = (double)cpg * (double)HW;
+        k1[i] = (float)(a / cnt);
+        k2[i] = (float)(b / cnt);
+    }
+    if (dgamma) {
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int n = 0; n < N; ++n)
+                for (int s = 0; s < S; ++s) {
+                    const double* p = part + (((size_t)n * S + s) * C + c) * 2;
+                    s1 += p[0];
+                    s2 += p[1];
+                }
+            dbeta[c] = (float)s1;
+            dgamma[c] = (float)s2;
+        }
+    }
+}
+
+// dx = rstd * (dy*gamma - k1 - xhat*k2) + dx_add ; grid-stride over float4 (VEC) or scalars
+template <bool VEC>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ x,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ k1, const float* __restrict__ k2,
+                                                           const float* __restrict__ dx_add, float* __restrict__ dx, int N,
+                                                           long HW, int C, int G, int act) {
+    const int cpg = C / G;
+    constexpr int V = VEC ? 4 : 1;
+    const size_t per_img = (size_t)HW * C / V;
+    const size_t total = (size_t)N * per_img;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / per_img);
+        const int c0 = (int)((i % (C / V)) * V);
+        float xv[4], dv[4], av[4], ov[4];
+        if (VEC) {
+            const float4 t = reinterpret_cast<const float4*>(x)[i];
+            const float4 d = reinterpret_cast<const float4*>(da)[i];
+            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
+            if (dx_add) {
+                const float4 q = reinterpret_cast<const float4*>(dx_add)[i];
+                av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w;
+            }
+        } else {
+            xv[0] = x[i]; dv[0] = da[i];
+            if (dx_add) av[0] = dx_add[i];
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int c = c0 + e;
+            const int g = c / cpg;
+            const float mu = mean[n * G + g], rs = rstd[n * G + g];
+            const float ga = gamma[c], be = beta[c];
+            const float xh = (xv[e] - mu) * rs;
+            const float y = fmaf(xh, ga, be);
+            const float dy = dv[e] * act_grad(y, act);
+            float o = rs * (dy * ga - k1[n * G + g] - xh * k2[n * G + g]);
+            if (dx_add) o += av[e];
+            ov[e] = o;
+        }
+        if (VEC) reinterpret_cast<float4*>(dx)[i] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        else dx[i] = ov[0];
+    }
+}
+
+__global__ void bn_update_running_kernel(const float* mean, const float* rstd, int C, double count, float eps, float mom,
+                                         float* rm, float* rv) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double rs = rstd[c];
+    double var = 1.0 / (rs * rs) - (double)eps;          // biased batch variance
+    if (var < 0) var = 0;
+    const double unb = count > 1 ? var * count / (count - 1.0) : var;
+    rm[c] = (1.f - mom) * rm[c] + mom * mean[c];
+    rv[c] = (1.f - mom) * rv[c] + mom * (float)unb;
+}
+
+int gn_splits(int N, long HW) {
+    long s = (HW + 255) / 256;            // >= 256 pixels per block
+    long cap = (2048 + N - 1) / N;        // ~2048 blocks in total
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+size_t part_bytes(int N, long HW, int C) { return (size_t)N * gn_splits(N, HW) * C * 2 * sizeof(double); }
+
+}  // namespace
+
+extern "C" size_t favae_gn_workspace(int N, int64_t HW, int C) {
+    // partial sums + k1/k2 (N*C floats upper bound each)
+    return part_bytes(N, HW, C) + 2 * (size_t)N * C * sizeof(float) + 256;
+}
+
+extern "C" int favae_gn_stats(const float* x, const float* gamma, const float* beta, int N, int64_t HW, int C, int G,
+                              float eps, float* mean, float* rstd, float* scale, float* shift, void* ws, size_t ws_bytes,
+                              favae_stream_t stream) {
+    FAVAE_REQUIRE(x && mean && rstd && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
+    FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
+    if (ws_bytes < favae_gn_workspace(N, HW, C)) return FAVAE_ERR_WORKSPACE;
+    const int S = gn_splits(N, HW);
+    const long rpb = (HW + S - 1) / S;
+    hipStream_t s = (hipStream_t)stream;
+    const int ccount = C < 256 ? C : 256;
+    const int rl = 256 / ccount > 0 ? 256 / ccount : 1;
+    const size_t shm = (size_t)rl * ccount * 2 * sizeof(double);
+    hipLaunchKernelGGL((gn_partial_kernel<0>), dim3(S, N), dim3(256), shm, s, x, (const float*)nullptr, gamma, beta,
+                       (const float*)nullptr, (const float*)nullptr, (double*)ws, (long)HW, C, G, 0, rpb);
+    FAVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, (const double*)ws, gamma, beta, mean, rstd, scale, shift,
+                       (long)HW, C, G, S, eps);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_gn_act_bwd(const float* da, const float* x, const float* gamma, const float* beta, const float* mean,
+                                const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
+                                float* dgamma, float* dbeta, void* ws, size_t ws_bytes, favae_stream_t stream) {
+    FAVAE_REQUIRE(da && x && gamma && beta && mean && rstd && dx && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
+    FAVAE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr));
+    if (ws_bytes < favae_gn_workspace(N, HW, C)) return FAVAE_ERR_WORKSPACE;
+    const int S = gn_splits(N, HW);
+    const long rpb = (HW + S - 1) / S;
+    hipStream_t s = (hipStream_t)stream;
+    double* part = (double*)ws;
+    float* k1 = (float*)((char*)ws + part_bytes(N, HW, C));
+    float* k2 = k1 + (size_t)N * C;
+    const int ccount = C < 256 ? C : 256;
+    const int rl = 256 / ccount > 0 ? 256 / ccount : 1;
+    const size_t shm = (size_t)rl * ccount * 2 * sizeof(double);
+    hipLaunchKernelGGL((gn_partial_kernel<1>), dim3(S, N), dim3(256), shm, s, x, da, gamma, beta, mean, rstd, part, (long)HW,
+                       C, G, act, rpb);
+    FAVAE_CHECK_LAUNCH();
+    const int work = (N * G > C ? N * G : C);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(work, 256)), dim3(256), 0, s, (const double*)part, gamma, k1, k2,
+                       dgamma, dbeta, N, (long)HW, C, G, S);
+    FAVAE_CHECK_LAUNCH();
+    const size_t total = (size_t)N * HW * C;
+    if (C % 4 == 0) {
+        int blocks = (int)((total / 4 + 255) / 256);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<true>), dim3(blocks), dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2,
+                           dx_add, dx, N, (long)HW, C, G, act);
+    } else {
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<false>), dim3(blocks), dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2,
+                           dx_add, dx, N, (long)HW, C, G, act);
+    }
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_bn_update_running(const float* mean, const float* rstd, int C, int64_t count, float eps, float momentum,
+                                       float* running_mean, float* running_var, favae_stream_t stream) {
+    FAVAE_REQUIRE(mean && rstd && running_mean && running_var && C > 0 && count > 0);
+    hipLaunchKernelGGL(bn_update_running_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, mean, rstd, C,
+                       (double)count, eps, momentum, running_mean, running_var);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}

@@ -1,0 +1,342 @@
+// Cosine-similarity vector quantiser (CosineSimCodebook.forward, models/l2_quantize.py:391-444) without ever
+// materialising the (T x C) similarity matrix or the one-hot matrix:
+//   zn = l2norm(z), en = l2norm(embed)                                  (l2_quantize.py:24-25,403,408)
+//   idx[t] = argmax_c <zn[t], en[c]>   first max wins                    (:410-411, gumbel_sample T=0 == argmax :39-41)
+//   zq[t] = embed[idx[t]]              raw EMA row, not the unit vector  (:415)
+//   bins / embed_sum / EMA                                               (:418-438)
+// The arg-max runs as a 128(codes) x 128(tokens) x d tiled fp32-MFMA product whose epilogue keeps, per token, the best and
+// second-best score of the tile in registers (codes are the MFMA row dimension, so one lane owns 16 codes of one token and
+// the per-token reduction is in-register + one shfl_xor(32) + a 2-wave LDS merge).  Tokens whose global top-2 gap is
+// below tie_eps are re-scored in fp64 so that the index does not depend on fp32 summation order ("bit-exact indices").
+// The scatter-sum for the EMA is deterministic: one wave owns one code and adds its tokens in ascending token order.
+#include "common.h"
+
+namespace {
+
+constexpr int VBM = 128, VBN = 128, VBK = 16, VLDK = VBK + 4;
+
+struct Top2 {
+    float v1;
+    int i1;
+    float v2;
+    int pad;
+};
+
+__device__ __forceinline__ void top2_push(Top2& t, float v, int i) {
+    if (v > t.v1 || (v == t.v1 && i < t.i1)) {
+        t.v2 = t.v1;
+        t.v1 = v;
+        t.i1 = i;
+    } else if (v > t.v2) {
+        t.v2 = v;
+    }
+}
+__device__ __forceinline__ void top2_merge(Top2& a, const Top2& b) {
+    if (b.v1 > a.v1 || (b.v1 == a.v1 && b.i1 < a.i1)) {
+        a.v2 = fmaxf(b.v2, a.v1);
+        a.v1 = b.v1;
+        a.i1 = b.i1;
+    } else {
+        a.v2 = fmaxf(a.v2, b.v1);
+    }
+}
+
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* x, float* out, int rows, int d) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* p = x + (size_t)row * d;
+    float s = 0.f;
+    for (int i = lane; i < d; i += 64) s = fmaf(p[i], p[i], s);
+    s = wave_sum(s);
+    const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);                 // F.normalize eps
+    float* o = out + (size_t)row * d;
+    for (int i = lane; i < d; i += 64) o[i] = p[i] * inv;
+}
+
+// part[t][tile] = top-2 of codes [tile*128, tile*128+128) for token t
+__global__ __launch_bounds__(256) void vq_dist_top2_kernel(const float* __restrict__ en, const float* __restrict__ zn,
+                                                           Top2* __restrict__ part, int C, int T, int d, int tiles_c) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * (VBM + VBN) * VLDK];
+    __shared__ Top2 mrg[2][VBN];
+    float* As = lds;
+    float* Bs = lds + 2 * VBM * VLDK;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int ct = blockIdx.x % tiles_c, tt = blockIdx.x / tiles_c;
+    const int m0 = ct * VBM, n0 = tt * VBN;
+    const bool vec = (d % 4) == 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[2], rb[2];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (tid >> 2) + 64 * j, k = k0 + (tid & 3) * 4;
+            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < d) {
+                if (m0 + row < C) {
+                    const float* p = en + (size_t)(m0 + row) * d + k;
+                    if (vec) ra[j] = *reinterpret_cast<const float4*>(p);
+                    else ra[j] = make_float4(p[0], k + 1 < d ? p[1] : 0.f, k + 2 < d ? p[2] : 0.f, k + 3 < d ? p[3] : 0.f);
+                }
+                if (n0 + row < T) {
+                    const float* p = zn + (size_t)(n0 + row) * d + k;
+                    if (vec) rb[j] = *reinterpret_cast<const float4*>(p);
+                    else rb[j] = make_float4(p[0], k + 1 < d ? p[1] : 0.f, k + 2 < d ? p[2] : 0.f, k + 3 < d ? p[3] : 0.f);
+                }
+            }
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (tid >> 2) + 64 * j;
+            *reinterpret_cast<float4*>(&As[(buf * VBM + row) * VLDK + (tid & 3) * 4]) = ra[j];
+            *reinterpret_cast<float4*>(&Bs[(buf * VBN + row) * VLDK + (tid & 3) * 4]) = rb[j];
+        }
+    };
+    const int K = (d + VBK - 1) / VBK;
+    load(0);
+    store(0);
+    __syncthreads();
+    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    for (int it = 0; it < K; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < K) load((it + 1) * VBK);
+        const float* Ab = As + (cur * VBM + wm * 64 + frow) * VLDK + fk;
+        const float* Bb = Bs + (cur * VBN + wn * 64 + frow) * VLDK + fk;
+#pragma unroll
+        for (int kk = 0; kk < VBK / 8; ++kk) {
+            float4 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * VLDK + kk * 8);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * VLDK + kk * 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (it + 1 < K) store(cur ^ 1);
+        __syncthreads();
+    }
+    // epilogue: rows = codes, cols = tokens.  lane owns column (lane&31) of each j-block, 32 codes (2 i-blocks x 16 regs)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        Top2 t;
+        t.v1 = -INFINITY; t.i1 = 0x7fffffff; t.v2 = -INFINITY; t.pad = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int code = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (code < C) top2_push(t, acc[i][j][r], code);
+            }
+        Top2 o;
+        o.v1 = __shfl_xor(t.v1, 32, 64);
+        o.i1 = __shfl_xor(t.i1, 32, 64);
+        o.v2 = __shfl_xor(t.v2, 32, 64);
+        o.pad = 0;
+        top2_merge(t, o);
+        if (lane < 32) mrg[wm][wn * 64 + j * 32 + lane] = t;
+    }
+    __syncthreads();
+    if (tid < VBN) {
+        Top2 t = mrg[0][tid];
+        top2_merge(t, mrg[1][tid]);
+        const int tok = n0 + tid;
+        if (tok < T) part[(size_t)tok * tiles_c + ct] = t;
+    }
+}
+
+// one wave per token: merge tile partials, flag near-ties
+__global__ __launch_bounds__(256) void vq_select_kernel(const Top2* part, int T, int tiles_c, float tie_eps, long long* idx,
+                                                        int* flag) {
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tok >= T) return;
+    Top2 t;
+    t.v1 = -INFINITY; t.i1 = 0x7fffffff; t.v2 = -INFINITY; t.pad = 0;
+    for (int i = lane; i < tiles_c; i += 64) top2_merge(t, part[(size_t)tok * tiles_c + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Top2 u;
+        u.v1 = __shfl_xor(t.v1, o, 64);
+        u.i1 = __shfl_xor(t.i1, o, 64);
+        u.v2 = __shfl_xor(t.v2, o, 64);
+        u.pad = 0;
+        top2_merge(t, u);
+    }
+    if (lane == 0) {
+        idx[tok] = t.i1;
+        flag[tok] = (t.v1 - t.v2 < tie_eps) ? 1 : 0;
+    }
+}
+
+// flagged tokens: full fp64 re-score (first max wins)
+__global__ __launch_bounds__(256) void vq_refine_kernel(const float* en, const float* zn, const int* flag, int C, int d,
+                                                        long long* idx) {
+    const int tok = blockIdx.x;
+    if (!flag[tok]) return;
+    __shared__ double bv[256];
+    __shared__ int bi[256];
+    extern __shared__ float zrow[];
+    for (int i = threadIdx.x; i < d; i += 256) zrow[i] = zn[(size_t)tok * d + i];
+    __syncthreads();
+    double best = -1e300;
+    int besti = 0x7fffffff;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float* e = en + (size_t)c * d;
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) s += (double)e[k] * (double)zrow[k];
+        if (s > best) { best = s; besti = c; }          // ascending c per thread: first max kept
+    }
+    bv[threadIdx.x] = best;
+    bi[threadIdx.x] = besti;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const double ov = bv[threadIdx.x + o];
+            const int oi = bi[threadIdx.x + o];
+            if (ov > bv[threadIdx.x] || (ov == bv[threadIdx.x] && oi < bi[threadIdx.x])) {
+                bv[threadIdx.x] = ov;
+                bi[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) idx[tok] = bi[0];
+}
+
+__global__ __launch_bounds__(256) void vq_gather_kernel(const float* embed, const long long* idx, float* zq, int T, int d) {
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tok >= T) return;
+    const float* e = embed + (size_t)idx[tok] * d;
+    float* o = zq + (size_t)tok * d;
+    for (int i = lane; i < d; i += 64) o[i] = e[i];
+}
+
+// one wave per code; tokens visited in ascending order -> deterministic sums
+__global__ __launch_bounds__(256) void vq_segment_sum_kernel(const float* zn, const long long* idx, int T, int d, int C,
+                                                             float* bins, float* embed_sum) {
+    const int code = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (code >= C) return;
+    constexpr int MAXV = 8;                      // d <= 64*MAXV
+    float acc[MAXV];
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) acc[v] = 0.f;
+    int count = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const bool hit = (t < T) && (idx[t] == (long long)code);
+        unsigned long long m = __ballot(hit);
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const float* row = zn + (size_t)(t0 + b) * d;
+#pragma unroll
+            for (int v = 0; v < MAXV; ++v) {
+                const int k = lane + 64 * v;
+                if (k < d) acc[v] += row[k];
+            }
+            ++count;
+        }
+    }
+    if (lane == 0) bins[code] = (float)count;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+        const int k = lane + 64 * v;
+        if (k < d) embed_sum[(size_t)code * d + k] = acc[v];
+    }
+}
+
+__global__ __launch_bounds__(256) void vq_ema_kernel(float* embed, float* cluster, const float* en, const float* bins,
+                                                     const float* esum, int C, int d, float decay) {
+    const int code = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (code >= C) return;
+    const float b = bins[code];
+    if (lane == 0) cluster[code] = cluster[code] * decay + (1.f - decay) * b;
+    float* e = embed + (size_t)code * d;
+    if (b == 0.f) {
+        for (int k = lane; k < d; k += 64) e[k] = e[k] * decay + (1.f - decay) * en[(size_t)code * d + k];
+    } else {
+        float s = 0.f;
+        for (int k = lane; k < d; k += 64) {
+            const float v = esum[(size_t)code * d + k] / b;
+            s = fmaf(v, v, s);
+        }
+        s = wave_sum(s);
+        const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+        for (int k = lane; k < d; k += 64) {
+            const float v = (esum[(size_t)code * d + k] / b) * inv;
+            e[k] = e[k] * decay + (1.f - decay) * v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t favae_vq_workspace(int T, int d, int C) {
+    const size_t tiles_c = (size_t)(C + VBM - 1) / VBM;
+    return (size_t)T * tiles_c * sizeof(Top2) + (size_t)T * sizeof(int) + 256;
+}
+
+extern "C" int favae_vq_lookup(const float* z, const float* embed, int T, int d, int C, float tie_eps, int64_t* idx, float* zq,
+                               float* zn, float* en, void* ws, size_t ws_bytes, favae_stream_t stream) {
+    FAVAE_REQUIRE(z && embed && idx && zq && zn && en && ws && T > 0 && d > 0 && C > 0);
+    if (ws_bytes < favae_vq_workspace(T, d, C)) return FAVAE_ERR_WORKSPACE;
+    if ((size_t)d * sizeof(float) > 64 * 1024) return FAVAE_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles_c = cdiv(C, VBM), tiles_t = cdiv(T, VBN);
+    Top2* part = (Top2*)ws;
+    int* flag = (int*)((char*)ws + (size_t)T * tiles_c * sizeof(Top2));
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, z, zn, T, d);
+    FAVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, embed, en, C, d);
+    FAVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vq_dist_top2_kernel, dim3(tiles_c * tiles_t), dim3(256), 0, s, (const float*)en, (const float*)zn, part, C,
+                       T, d, tiles_c);
+    FAVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vq_select_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, (const Top2*)part, T, tiles_c, tie_eps,
+                       (long long*)idx, flag);
+    FAVAE_CHECK_LAUNCH();
+    if (tie_eps > 0.f) {
+        hipLaunchKernelGGL(vq_refine_kernel, dim3(T), dim3(256), (size_t)d * sizeof(float), s, (const float*)en, (const float*)zn,
+                           (const int*)flag, C, d, (long long*)idx);
+        FAVAE_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(vq_gather_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, embed, (const long long*)idx, zq, T, d);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_vq_segment_sum(const float* zn, const int64_t* idx, int T, int d, int C, float* bins, float* embed_sum,
+                                    favae_stream_t stream) {
+    FAVAE_REQUIRE(zn && idx && bins && embed_sum && T > 0 && d > 0 && C > 0);
+    if (d > 512) return FAVAE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(vq_segment_sum_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, zn, (const long long*)idx, T,
+                       d, C, bins, embed_sum);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_vq_ema_update(float* embed, float* cluster_size, const float* en, const float* bins, const float* embed_sum,
+                                   int C, int d, float decay, favae_stream_t stream) {
+    FAVAE_REQUIRE(embed && cluster_size && en && bins && embed_sum && C > 0 && d > 0);
+    hipLaunchKernelGGL(vq_ema_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, embed, cluster_size, en, bins,
+                       embed_sum, C, d, decay);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}

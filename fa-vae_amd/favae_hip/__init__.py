@@ -1,0 +1,126 @@
+"""ctypes binding of libfavae_hip.so (C ABI declared in include/favae_hip.h).
+
+Plumbing only: PyTorch owns device memory and streams, every call below forwards raw device pointers, sizes and
+the current HIP stream to the hand-written gfx950 kernels.  There is NO fallback: if the shared library is missing
+or a call fails, a RuntimeError is raised (the product path must never silently run anything else).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, byref, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfavae_hip.so")
+ABI_VERSION = 1
+
+GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_LEAKY02 = 0, 1, 2
+
+_ERR = {1: "bad argument", 2: "kernel launch failed", 3: "unsupported shape", 4: "workspace too small"}
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int32) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "KH", "KW", "stride", "pad",
+                                       "gather", "act", "affine_per_image")]
+
+
+# name -> (restype, argtypes); mirrors include/favae_hip.h one to one (tests/test_abi.py checks the symbol list)
+_P, _S = c_void_p, c_void_p
+SIGNATURES = {
+    "favae_abi_version": (c_int, []),
+    "favae_conv_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _S]),
+    "favae_conv_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
+    "favae_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, c_size_t, _S]),
+    "favae_weight_flip": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
+    "favae_colsum_workspace": (c_size_t, [c_int64, c_int]),
+    "favae_colsum": (c_int, [_P, _P, c_int64, c_int, _P, c_size_t, _S]),
+    "favae_upsample2x_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
+    "favae_gn_workspace": (c_size_t, [c_int, c_int64, c_int]),
+    "favae_gn_stats": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_size_t, _S]),
+    "favae_gn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _S]),
+    "favae_bn_update_running": (c_int, [_P, _P, c_int, c_int64, c_float, c_float, _P, _P, _S]),
+    "favae_bgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int64, c_int64, _P, c_int64, c_int64, _P,
+                            c_int64, c_int64, c_int, c_int, _S]),
+    "favae_softmax_rows": (c_int, [_P, _P, c_int64, c_int, _S]),
+    "favae_softmax_rows_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_float, _S]),
+    "favae_blur_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _S]),
+    "favae_blur_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "favae_blur_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _S]),
+    "favae_ffl_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "favae_ffl_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_size_t, _S]),
+    "favae_ffl_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _S]),
+    "favae_vq_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "favae_vq_lookup": (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_size_t, _S]),
+    "favae_vq_segment_sum": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _S]),
+    "favae_vq_ema_update": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _S]),
+    "favae_vq_ste": (c_int, [_P, _P, _P, c_int64, _S]),
+    "favae_reduce_workspace": (c_size_t, [c_int64]),
+    "favae_absdiff_sum": (c_int, [_P, _P, c_int64, c_float, _P, _P, c_size_t, _S]),
+    "favae_sqdiff_sum": (c_int, [_P, _P, c_int64, c_float, _P, _P, c_size_t, _S]),
+    "favae_absdiff_bwd": (c_int, [_P, _P, _P, c_float, c_int64, _P, _P, _S]),
+    "favae_sqdiff_bwd": (c_int, [_P, _P, _P, c_float, c_int64, _P, _P, _S]),
+    "favae_axpby": (c_int, [_P, c_float, _P, c_float, c_int64, _S]),
+    "favae_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
+    "favae_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
+    "favae_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _S]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library (once).  Raises if it has not been built: there is no other code path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here == ABI mismatch, let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    if lib.favae_abi_version() != ABI_VERSION:
+        raise RuntimeError("libfavae_hip ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point on the current stream (stream appended automatically)."""
+    lib = load()
+    _chk(getattr(lib, name)(*args, stream()), name)
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
+    """Stream-ordered scratch from PyTorch's caching allocator (a fresh tensor per call keeps stream semantics simple)."""
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def make_conv_desc(N, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, gather=GATHER_PLAIN, act=ACT_NONE,
+                   affine_per_image=1):
+    return ConvDesc(N, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, gather, act, affine_per_image)

@@ -1,0 +1,452 @@
+"""torch.autograd.Function wrappers around libfavae_hip (the only compute path; no fallbacks).
+
+Tensors are ordinary torch CUDA tensors shaped (N, C, H, W) whose *memory* is channels-last (NHWC), so the module
+code reads like the reference's NCHW code while every kernel sees coalesced channel-fastest data.
+"""
+from __future__ import annotations
+
+import math
+from ctypes import byref
+
+import torch
+
+from . import (ACT_LEAKY02, ACT_NONE, ACT_SILU, GATHER_DILATE2, GATHER_PLAIN, GATHER_UPSAMPLE2, call, make_conv_desc,
+               ptr, query, workspace)
+
+CL = torch.channels_last
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# layout helpers
+# ---------------------------------------------------------------------------------------------------------------
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("favae_hip ops run on MI355X only (tensor is on %s); there is no CPU fallback" % t.device)
+    if t.dtype != torch.float32:
+        raise RuntimeError("favae_hip ops compute in fp32 (got %s)" % t.dtype)
+
+
+def new_cl(N, C, H, W, device):
+    return torch.empty((N, C, H, W), dtype=torch.float32, device=device, memory_format=CL)
+
+
+def _is_cl(t):
+    """True when the memory of (N,C,H,W) tensor `t` is NHWC-dense (size-1 dims have no say)."""
+    N, C, H, W = t.shape
+    want = (H * W * C, 1, W * C, C)
+    return all(sz == 1 or st == w for sz, st, w in zip(t.shape, t.stride(), want))
+
+
+def to_cl(t):
+    """Return `t` (N,C,H,W) with NHWC memory; NCHW-contiguous inputs go through the HIP transpose kernel."""
+    _require_gpu(t)
+    if _is_cl(t):
+        return t
+    N, C, H, W = t.shape
+    if not t.is_contiguous():
+        t = t.contiguous()
+    y = new_cl(N, C, H, W, t.device)
+    call("favae_nchw_to_nhwc", ptr(t), ptr(y), N, C, H, W)
+    return y
+
+
+def to_nchw(t):
+    """NCHW-contiguous copy of a channels-last tensor (module boundary only)."""
+    _require_gpu(t)
+    if t.is_contiguous():
+        return t
+    t = to_cl(t)
+    N, C, H, W = t.shape
+    y = torch.empty((N, C, H, W), dtype=torch.float32, device=t.device)
+    call("favae_nhwc_to_nchw", ptr(t), ptr(y), N, C, H, W)
+    return y
+
+
+class _ToCLFn(torch.autograd.Function):
+    """Autograd-transparent layout change (values unchanged, so the gradient passes straight through)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return to_cl(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def as_cl(t):
+    """Module-boundary version of to_cl(): safe on tensors that require grad."""
+    if _is_cl(t) and t.is_cuda:
+        return t
+    return _ToCLFn.apply(t) if t.requires_grad else to_cl(t)
+
+
+class _AddFn(torch.autograd.Function):
+    """c = a + b on the HIP axpby kernel (trunk + FCM adds of the convolutional FCM decoders, codec.py:533-548)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = to_cl(a), to_cl(b)
+        out = torch.empty_like(a)
+        call("favae_axpby", ptr(a), 1.0, ptr(out), 0.0, a.numel())
+        call("favae_axpby", ptr(b), 1.0, ptr(out), 1.0, a.numel())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _AddFn.apply(a, b)
+
+
+def weight_ohwi(w):
+    """(Cout,Cin,KH,KW) parameter -> pointer-compatible OHWI tensor (zero copy when the parameter is channels-last)."""
+    _require_gpu(w)
+    if w.dim() == 2:
+        return w if w.is_contiguous() else w.contiguous()
+    if _is_cl(w):
+        return w
+    return to_cl(w)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GroupNorm statistics (no autograd by itself; used inside FusedConv)
+# ---------------------------------------------------------------------------------------------------------------
+def gn_stats(x, gamma, beta, groups, eps=1e-5):
+    N, C, H, W = x.shape
+    dev = x.device
+    mean = torch.empty((N, groups), dtype=torch.float32, device=dev)
+    rstd = torch.empty_like(mean)
+    scale = torch.empty((N, C), dtype=torch.float32, device=dev)
+    shift = torch.empty_like(scale)
+    nb = query("favae_gn_workspace", N, H * W, C)
+    ws = workspace(nb, dev)
+    call("favae_gn_stats", ptr(x), ptr(gamma), ptr(beta), N, H * W, C, groups, eps, ptr(mean), ptr(rstd), ptr(scale),
+         ptr(shift), ptr(ws), ws.numel())
+    return mean, rstd, scale, shift
+
+
+class ConvCfg:
+    """Static description of one fused conv site."""
+    __slots__ = ("kh", "kw", "stride", "pad", "pad_br", "upsample", "act", "groups", "eps")
+
+    def __init__(self, kh, kw, stride=1, pad=0, pad_br=None, upsample=False, act=ACT_SILU, groups=32, eps=1e-5):
+        self.kh, self.kw, self.stride, self.pad = kh, kw, stride, pad
+        self.pad_br = pad if pad_br is None else pad_br
+        self.upsample, self.act, self.groups, self.eps = upsample, act, groups, eps
+
+    def out_hw(self, H, W):
+        if self.upsample:
+            H, W = 2 * H, 2 * W
+        Ho = (H + self.pad + self.pad_br - self.kh) // self.stride + 1
+        Wo = (W + self.pad + self.pad_br - self.kw) // self.stride + 1
+        return Ho, Wo
+
+
+class FusedConvFn(torch.autograd.Function):
+    """y = conv(act(GN(x)), w) + b + resid   -- GN/act optional (gn_w is None -> plain conv).
+
+    Reference sites: ResnetBlock/NonResnetBlock halves (models/codec.py:38-46), Downsample (:26-29), Upsample (:17-18),
+    conv_in/final (:140,170-175), attention in/out projections (:92)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gn_w, gn_b, resid, cfg):
+        x = to_cl(x)
+        N, Cin, Hin, Win = x.shape
+        w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
+        wk = weight_ohwi(w4)
+        Cout = w4.shape[0]
+        Ho, Wo = cfg.out_hw(Hin, Win)
+        dev = x.device
+        mean = rstd = scale = shift = None
+        if gn_w is not None:
+            mean, rstd, scale, shift = gn_stats(x, gn_w, gn_b, cfg.groups, cfg.eps)
+        if resid is not None:
+            resid = to_cl(resid)
+        y = new_cl(N, Cout, Ho, Wo, dev)
+        d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad,
+                           GATHER_UPSAMPLE2 if cfg.upsample else GATHER_PLAIN, cfg.act if gn_w is not None else ACT_NONE, 1)
+        call("favae_conv_fwd", byref(d), ptr(x), ptr(wk), ptr(b), ptr(resid), ptr(scale), ptr(shift), ptr(y))
+        ctx.cfg = cfg
+        ctx.has_b = b is not None
+        ctx.has_gn = gn_w is not None
+        ctx.has_res = resid is not None
+        ctx.w_dim = w.dim()
+        ctx.save_for_backward(x, wk, gn_w, gn_b, mean, rstd, scale, shift)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wk, gn_w, gn_b, mean, rstd, scale, shift = ctx.saved_tensors
+        cfg = ctx.cfg
+        dy = to_cl(dy)
+        N, Cin, Hin, Win = x.shape
+        _, Cout, Ho, Wo = dy.shape
+        dev = x.device
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = dw = db = dgw = dgb = None
+        gather = GATHER_UPSAMPLE2 if cfg.upsample else GATHER_PLAIN
+        act = cfg.act if ctx.has_gn else ACT_NONE
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+            M = N * Ho * Wo
+            ws = workspace(query("favae_colsum_workspace", M, Cout), dev)
+            call("favae_colsum", ptr(dy), ptr(db), M, Cout, ptr(ws), ws.numel())
+        if need_w:
+            d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad, gather, act, 1)
+            dwk = torch.empty((Cout, cfg.kh, cfg.kw, Cin), dtype=torch.float32, device=dev)
+            ws = workspace(query("favae_conv_wgrad_workspace", byref(d)), dev)
+            call("favae_conv_wgrad", byref(d), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(dwk), ptr(ws), ws.numel())
+            dw = dwk.permute(0, 3, 1, 2)                      # (Cout,Cin,KH,KW) view with channels-last strides
+            if ctx.w_dim == 2:
+                dw = dwk.view(Cout, Cin)
+        if need_x or ctx.has_gn:
+            wt = torch.empty((Cin, cfg.kh, cfg.kw, Cout), dtype=torch.float32, device=dev)
+            call("favae_weight_flip", ptr(wk), ptr(wt), Cout, cfg.kh, cfg.kw, Cin)
+            if cfg.stride == 1:
+                Hv, Wv = (2 * Hin, 2 * Win) if cfg.upsample else (Hin, Win)
+                g2, pad2 = GATHER_PLAIN, cfg.kh - 1 - cfg.pad
+            elif cfg.stride == 2 and not cfg.upsample:
+                Hv, Wv = Hin, Win
+                g2, pad2 = GATHER_DILATE2, cfg.kh - 1 - cfg.pad
+            else:
+                raise RuntimeError("unsupported conv geometry for the data gradient")
+            da = new_cl(N, Cin, Hv, Wv, dev)
+            d2 = make_conv_desc(N, Ho, Wo, Cout, Hv, Wv, Cin, cfg.kh, cfg.kw, 1, pad2, g2, ACT_NONE, 1)
+            call("favae_conv_fwd", byref(d2), ptr(dy), ptr(wt), None, None, None, None, ptr(da))
+            if cfg.upsample:
+                dlow = new_cl(N, Cin, Hin, Win, dev)
+                call("favae_upsample2x_bwd", ptr(da), ptr(dlow), N, Hin, Win, Cin)
+                da = dlow
+            if ctx.has_gn:
+                dx = new_cl(N, Cin, Hin, Win, dev)
+                dgw = torch.empty((Cin,), dtype=torch.float32, device=dev)
+                dgb = torch.empty_like(dgw)
+                ws = workspace(query("favae_gn_workspace", N, Hin * Win, Cin), dev)
+                call("favae_gn_act_bwd", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), N, Hin * Win, Cin,
+                     cfg.groups, act, None, ptr(dx), ptr(dgw), ptr(dgb), ptr(ws), ws.numel())
+            else:
+                dx = da
+        dres = dy if ctx.has_res else None
+        return dx, dw, db, dgw, dgb, dres, None
+
+
+def fused_conv(x, w, b=None, gn_w=None, gn_b=None, resid=None, cfg=None):
+    return FusedConvFn.apply(x, w, b, gn_w, gn_b, resid, cfg)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# single-head attention core (models/codec.py:92,99): qkv (N,3C,H,W) -> o (N,C,H,W)
+# ---------------------------------------------------------------------------------------------------------------
+class AttnCoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv):
+        qkv = to_cl(qkv)
+        N, C3, H, W = qkv.shape
+        C, L = C3 // 3, H * W
+        dev = qkv.device
+        alpha = 1.0 / math.sqrt(C)
+        P = torch.empty((N, L, L), dtype=torch.float32, device=dev)
+        q, k, v = qkv.data_ptr(), qkv.data_ptr() + 4 * C, qkv.data_ptr() + 8 * C
+        call("favae_bgemm", 0, 0, L, L, C, alpha, q, C3, L * C3, k, C3, L * C3, ptr(P), L, L * L, N, 0)
+        call("favae_softmax_rows", ptr(P), ptr(P), N * L, L)
+        o = new_cl(N, C, H, W, dev)
+        call("favae_bgemm", 0, 1, L, C, L, 1.0, ptr(P), L, L * L, v, C3, L * C3, ptr(o), C, L * C, N, 0)
+        ctx.save_for_backward(qkv, P)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, P = ctx.saved_tensors
+        do = to_cl(do)
+        N, C3, H, W = qkv.shape
+        C, L = C3 // 3, H * W
+        dev = qkv.device
+        alpha = 1.0 / math.sqrt(C)
+        dqkv = new_cl(N, C3, H, W, dev)
+        q, k, v = qkv.data_ptr(), qkv.data_ptr() + 4 * C, qkv.data_ptr() + 8 * C
+        dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + 4 * C, dqkv.data_ptr() + 8 * C
+        # dV[j][c] = sum_i P[i][j] dO[i][c]
+        call("favae_bgemm", 1, 1, L, C, L, 1.0, ptr(P), L, L * L, ptr(do), C, L * C, dv, C3, L * C3, N, 0)
+        # dP[i][j] = sum_c dO[i][c] V[j][c]
+        dP = torch.empty((N, L, L), dtype=torch.float32, device=dev)
+        call("favae_bgemm", 0, 0, L, L, C, 1.0, ptr(do), C, L * C, v, C3, L * C3, ptr(dP), L, L * L, N, 0)
+        call("favae_softmax_rows_bwd", ptr(P), ptr(dP), ptr(dP), N * L, L, alpha)      # dS (alpha folded in)
+        # dQ[i][c] = sum_j dS[i][j] K[j][c] ; dK[j][c] = sum_i dS[i][j] Q[i][c]
+        call("favae_bgemm", 0, 1, L, C, L, 1.0, ptr(dP), L, L * L, k, C3, L * C3, dq, C3, L * C3, N, 0)
+        call("favae_bgemm", 1, 1, L, C, L, 1.0, ptr(dP), L, L * L, q, C3, L * C3, dk, C3, L * C3, N, 0)
+        return dqkv
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# learnable-sigma Gaussian blur (models/codec.py:255-277)
+# ---------------------------------------------------------------------------------------------------------------
+class BlurFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sigmas, index, ksize):
+        x = to_cl(x)
+        _require_gpu(sigmas)
+        N, C, H, W = x.shape
+        y = new_cl(N, C, H, W, x.device)
+        sp = sigmas.data_ptr() + 4 * index
+        call("favae_blur_fwd", ptr(x), sp, ksize, N, H, W, C, ptr(y))
+        ctx.save_for_backward(x, sigmas)
+        ctx.index, ctx.ksize = index, ksize
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sigmas = ctx.saved_tensors
+        dy = to_cl(dy)
+        N, C, H, W = x.shape
+        dev = x.device
+        need_x, need_s = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = new_cl(N, C, H, W, dev) if need_x else None
+        ds = torch.zeros_like(sigmas) if need_s else None
+        ws = workspace(query("favae_blur_bwd_workspace", ctx.ksize, N, H, W, C), dev)
+        sp = sigmas.data_ptr() + 4 * ctx.index
+        dsp = (ds.data_ptr() + 4 * ctx.index) if need_s else None
+        call("favae_blur_bwd", ptr(x), ptr(dy), sp, ctx.ksize, N, H, W, C, ptr(dx), dsp, ptr(ws), ws.numel())
+        return dx, ds, None, None
+
+
+def gaussian_blur(x, sigmas, index, ksize):
+    return BlurFn.apply(x, sigmas, index, ksize)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# focal frequency loss (pip focal-frequency-loss 0.3.0 semantics, alpha = 1)
+# ---------------------------------------------------------------------------------------------------------------
+class FFLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, loss_weight):
+        pred, target = to_cl(pred), to_cl(target)
+        if pred.shape != target.shape:
+            raise RuntimeError("FFL: shape mismatch")
+        N, C, H, W = pred.shape
+        dev = pred.device
+        spec = torch.empty((N, H, W, C, 2), dtype=torch.float32, device=dev)
+        loss = torch.empty((1,), dtype=torch.float32, device=dev)
+        ws = workspace(query("favae_ffl_workspace", N, H, W, C), dev)
+        call("favae_ffl_fwd", ptr(pred), ptr(target), N, H, W, C, float(loss_weight), ptr(loss), ptr(spec), ptr(ws), ws.numel())
+        ctx.save_for_backward(spec)
+        ctx.dims = (N, C, H, W)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (spec,) = ctx.saved_tensors
+        N, C, H, W = ctx.dims
+        dev = spec.device
+        g = g.contiguous().float()
+        need_p, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gp = new_cl(N, C, H, W, dev)
+        gt = new_cl(N, C, H, W, dev) if need_t else None
+        ws = workspace(query("favae_ffl_workspace", N, H, W, C), dev)
+        call("favae_ffl_bwd", ptr(spec), ptr(g), N, H, W, C, ptr(gp), ptr(gt), ptr(ws), ws.numel())
+        return (gp if need_p else None), gt, None
+
+
+def focal_frequency_loss(pred, target, loss_weight=1.0):
+    return FFLFn.apply(pred, target, loss_weight)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# vector quantiser pieces (models/l2_quantize.py)
+# ---------------------------------------------------------------------------------------------------------------
+def vq_lookup(tokens, embed, tie_eps=4e-6):
+    """tokens (T,d) contiguous, embed (C,d) contiguous -> idx int64 (T,), zq (T,d), zn (T,d), en (C,d)."""
+    _require_gpu(tokens)
+    T, d = tokens.shape
+    C = embed.shape[0]
+    dev = tokens.device
+    idx = torch.empty((T,), dtype=torch.int64, device=dev)
+    zq = torch.empty((T, d), dtype=torch.float32, device=dev)
+    zn = torch.empty_like(zq)
+    en = torch.empty((C, d), dtype=torch.float32, device=dev)
+    ws = workspace(query("favae_vq_workspace", T, d, C), dev)
+    call("favae_vq_lookup", ptr(tokens), ptr(embed), T, d, C, float(tie_eps), ptr(idx), ptr(zq), ptr(zn), ptr(en), ptr(ws),
+         ws.numel())
+    return idx, zq, zn, en
+
+
+def vq_segment_sum(zn, idx, C):
+    T, d = zn.shape
+    bins = torch.empty((C,), dtype=torch.float32, device=zn.device)
+    esum = torch.empty((C, d), dtype=torch.float32, device=zn.device)
+    call("favae_vq_segment_sum", ptr(zn), ptr(idx), T, d, C, ptr(bins), ptr(esum))
+    return bins, esum
+
+
+def vq_ema_update(embed, cluster_size, en, bins, esum, decay):
+    C, d = en.shape
+    call("favae_vq_ema_update", ptr(embed), ptr(cluster_size), ptr(en), ptr(bins), ptr(esum), C, d, float(decay))
+
+
+class VQStraightThroughFn(torch.autograd.Function):
+    """(x, zq) -> quantize = x + (zq - x).detach(), loss = w * mse(zq, x)   (l2_quantize.py:553-561)."""
+
+    @staticmethod
+    def forward(ctx, x, zq, weight):
+        n = x.numel()
+        out = torch.empty_like(x)
+        call("favae_vq_ste", ptr(x), ptr(zq), ptr(out), n)
+        loss = torch.zeros((1,), dtype=torch.float32, device=x.device)
+        if weight > 0:
+            ws = workspace(query("favae_reduce_workspace", n), x.device)
+            call("favae_sqdiff_sum", ptr(zq), ptr(x), n, float(weight) / n, ptr(loss), ptr(ws), ws.numel())
+        ctx.save_for_backward(x, zq)
+        ctx.weight = weight
+        return out, loss
+
+    @staticmethod
+    def backward(ctx, gq, gloss):
+        x, zq = ctx.saved_tensors
+        n = x.numel()
+        gq = gq.contiguous()
+        gx = torch.empty_like(x)
+        if gloss is None:
+            gloss = torch.zeros((1,), dtype=torch.float32, device=x.device)
+        call("favae_sqdiff_bwd", ptr(x), ptr(zq), ptr(gloss.contiguous()), 2.0 * ctx.weight / n, n, ptr(gq), ptr(gx))
+        return gx, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# L1 reconstruction loss (favae_scripts/train_favae.py:76)
+# ---------------------------------------------------------------------------------------------------------------
+class L1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = to_cl(a), to_cl(b)
+        n = a.numel()
+        loss = torch.empty((1,), dtype=torch.float32, device=a.device)
+        ws = workspace(query("favae_reduce_workspace", n), a.device)
+        call("favae_absdiff_sum", ptr(a), ptr(b), n, 1.0 / n, ptr(loss), ptr(ws), ws.numel())
+        ctx.save_for_backward(a, b)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        n = a.numel()
+        g = g.contiguous().float()
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = torch.empty_like(a)
+            call("favae_absdiff_bwd", ptr(a), ptr(b), ptr(g), 1.0 / n, n, None, ptr(ga))
+        if ctx.needs_input_grad[1]:
+            gb = torch.empty_like(b)
+            call("favae_absdiff_bwd", ptr(a), ptr(b), ptr(g), -1.0 / n, n, None, ptr(gb))
+        return ga, gb
+
+
+def l1_loss(a, b):
+    return L1Fn.apply(a, b)
+
+
+def adam_step(p, g, m, v, step, lr, betas=(0.5, 0.9), eps=1e-8, grad_scale=1.0):
+    """In-place Adam over flat fp32 buffers (favae_scripts/train_favae.py:297-305)."""
+    call("favae_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
+         int(step), float(grad_scale))

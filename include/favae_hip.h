@@ -1,0 +1,194 @@
+/*
+ * libfavae_hip -- C ABI of the MI355X (gfx950) FA-VAE training-step hot path.
+ *
+ * The reference (oppo-us-research/FA-VAE) is 100 % Python and has no FFI of its own; its "kernels" are the
+ * ATen calls its modules issue.  Each entry point below replaces one such call pattern; the comment above each
+ * declaration cites the reference site (paths relative to the reference repository root).  INTEGRATION.md shows
+ * the ctypes stubs a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise; the caller owns all memory (PyTorch's
+ *     allocator in practice); the library never allocates, keeps no global state and is re-entrant per stream;
+ *   - activations are NHWC ("channels last": N, H, W, C with C fastest); conv weights are OHWI
+ *     ([Cout][KH][KW][Cin], i.e. a torch (Cout,Cin,KH,KW) tensor in channels_last memory format);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - workspaces are caller-allocated; every *_workspace() query returns the bytes needed;
+ *   - return value: FAVAE_OK (0) or an error code; nothing is printed.
+ */
+#ifndef FAVAE_HIP_H
+#define FAVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* favae_stream_t;
+
+enum {
+    FAVAE_OK = 0,
+    FAVAE_ERR_BAD_ARG = 1,
+    FAVAE_ERR_LAUNCH = 2,
+    FAVAE_ERR_UNSUPPORTED = 3,
+    FAVAE_ERR_WORKSPACE = 4
+};
+
+/* library/ABI version, bumped on any signature change */
+int favae_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Convolution family (implicit GEMM on v_mfma_f32_32x32x2_f32, exact fp32).
+ * Replaces: nn.Conv2d 3x3/1x1 inside ResnetBlock / NonResnetBlock (models/codec.py:38-46,50,65-73,77), conv_in /
+ * final (:140,170-175,447-450), Downsample = F.pad(0,1,0,1)+conv s2 (:26-29), Upsample = nearest x2 + conv (:17-18),
+ * the packed in/out projections of nn.MultiheadAttention (:92), the 4x4 convs of the Discriminator
+ * (models/discriminator.py:198-213) -- with the preceding GroupNorm(+SiLU) / BatchNorm+LeakyReLU applied on the
+ * fly to the input tile, and bias + residual add fused in the epilogue.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t N, Hin, Win, Cin;       /* input  (N,Hin,Win,Cin)  NHWC  */
+    int32_t Hout, Wout, Cout;       /* output (N,Hout,Wout,Cout) NHWC */
+    int32_t KH, KW, stride, pad;    /* pad = top/left zero padding; bottom/right padding is implied by Hout/Wout */
+    int32_t gather;                 /* 0 plain | 1 input is nearest-upsampled x2 on the fly | 2 input is zero-dilated x2
+                                       (transposed conv = data gradient of a stride-2 conv) */
+    int32_t act;                    /* activation applied after the affine input transform: 0 none | 1 SiLU | 2 LeakyReLU(0.2) */
+    int32_t affine_per_image;       /* 1: scale/shift are [N][Cin] (GroupNorm); 0: [Cin] shared by the batch (BatchNorm) */
+} favae_conv_desc;
+
+#define FAVAE_GATHER_PLAIN 0
+#define FAVAE_GATHER_UPSAMPLE2 1
+#define FAVAE_GATHER_DILATE2 2
+#define FAVAE_ACT_NONE 0
+#define FAVAE_ACT_SILU 1
+#define FAVAE_ACT_LEAKY02 2
+
+/* y = conv(T(x), w) + bias + resid, T(x) = act(x*scale+shift) (scale==NULL -> T = identity).  bias, resid, scale,
+ * shift may be NULL.  The data gradient of a stride-1 conv is this same call on dy with favae_weight_flip()'d weights. */
+int favae_conv_fwd(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
+                   const float* scale, const float* shift, float* y, favae_stream_t stream);
+
+/* dw[co][kh][kw][ci] = sum_{n,oh,ow} dy[n,oh,ow,co] * T(x)[gathered (n,oh,ow,kh,kw), ci]   (split-K, deterministic:
+ * partial slabs in `ws`, summed in a fixed order).  autograd's convolution_backward weight path. */
+size_t favae_conv_wgrad_workspace(const favae_conv_desc* d);
+int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const float* dy, const float* scale, const float* shift,
+                     float* dw, void* ws, size_t ws_bytes, favae_stream_t stream);
+
+/* wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]  (weights of the data-gradient convolution) */
+int favae_weight_flip(const float* w, float* wt, int Cout, int KH, int KW, int Cin, favae_stream_t stream);
+
+/* out[c] = sum_m a[m][c]  (bias gradient; M rows of C) ; deterministic two-stage */
+size_t favae_colsum_workspace(int64_t M, int C);
+int favae_colsum(const float* a, float* out, int64_t M, int C, void* ws, size_t ws_bytes, favae_stream_t stream);
+
+/* adjoint of nearest x2 upsampling: dx[n,h,w,c] = sum of the 2x2 children of du (N,2H,2W,C) */
+int favae_upsample2x_bwd(const float* du, float* dx, int N, int H, int W, int C, favae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GroupNorm (+SiLU) statistics and backward.  Replaces nn.GroupNorm(32,C)/nn.SiLU (models/codec.py:39-40,42-43,
+ * 66-67,69-70,90,170-171,447-448) and, with G == C and N folded into HW, the batch statistics of nn.BatchNorm2d
+ * (models/discriminator.py:207).
+ * ---------------------------------------------------------------------------------------------------------- */
+/* mean/rstd: [N][G] (biased variance, eps inside the sqrt); scale[n][c] = rstd*gamma[c], shift[n][c] = beta[c] -
+ * mean*rstd*gamma[c] -- the per-(image,channel) affine the conv kernels apply on load. */
+size_t favae_gn_workspace(int N, int64_t HW, int C);
+int favae_gn_stats(const float* x, const float* gamma, const float* beta, int N, int64_t HW, int C, int G, float eps,
+                   float* mean, float* rstd, float* scale, float* shift, void* ws, size_t ws_bytes, favae_stream_t stream);
+
+/* Given da = dL/d act(GN(x)): dx, dgamma[C], dbeta[C].  act as in favae_conv_desc.  If `dx_add` != NULL it is
+ * added to dx (fused skip-connection gradient).  dx may alias da. */
+int favae_gn_act_bwd(const float* da, const float* x, const float* gamma, const float* beta, const float* mean,
+                     const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
+                     float* dgamma, float* dbeta, void* ws, size_t ws_bytes, favae_stream_t stream);
+
+/* BatchNorm2d running-stat update (momentum m, unbiased variance), models/discriminator.py:207 in train mode */
+int favae_bn_update_running(const float* mean, const float* rstd, int C, int64_t count, float eps, float momentum,
+                            float* running_mean, float* running_var, favae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Single-head attention core.  Replaces nn.MultiheadAttention(C, 1 head) SDPA (models/codec.py:92,99).
+ * ---------------------------------------------------------------------------------------------------------- */
+/* C[b] = alpha * op(A[b]) * op(B[b]) (+ C[b] if accumulate).  ta/tb = 0: operand stored [rows][k] (k contiguous);
+ * 1: stored [k][rows].  A is M x K, B is N x K in the "0" convention (i.e. C = A * B^T). */
+int favae_bgemm(int ta, int tb, int M, int N, int K, float alpha, const float* A, int64_t lda, int64_t strideA,
+                const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC, int batch,
+                int accumulate, favae_stream_t stream);
+int favae_softmax_rows(const float* s, float* p, int64_t rows, int L, favae_stream_t stream);
+/* ds = alpha * p * (dp - rowsum(dp*p)) */
+int favae_softmax_rows_bwd(const float* p, const float* dp, float* ds, int64_t rows, int L, float alpha,
+                           favae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Learnable-sigma Gaussian blur (depthwise, reflect padding).  Replaces _get_gaussian_kernel1d/2d + F.pad(reflect)
+ * + F.conv2d(groups=C)  (models/codec.py:255-277, models/vqgan_fcm.py:20-41).  `sigma` is a device scalar.
+ * ---------------------------------------------------------------------------------------------------------- */
+int favae_blur_fwd(const float* x, const float* sigma, int ksize, int N, int H, int W, int C, float* y,
+                   favae_stream_t stream);
+size_t favae_blur_bwd_workspace(int ksize, int N, int H, int W, int C);
+/* dx = adjoint(reflect-pad o blur)(dy); dsigma (1 float, overwritten) = dL/dsigma */
+int favae_blur_bwd(const float* x, const float* dy, const float* sigma, int ksize, int N, int H, int W, int C,
+                   float* dx, float* dsigma, void* ws, size_t ws_bytes, favae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Focal-frequency / dynamic-spectrum loss.  Replaces focal_frequency_loss.FocalFrequencyLoss(loss_weight, alpha=1)
+ * (pip 0.3.0; call sites favae_scripts/train_favae.py:313,318,326, losses/vqgan_losses.py:14,25-26).
+ * H and W must be powers of two <= 1024.
+ *   loss = loss_weight * mean( w * |F|^2 ),  F = fft2_ortho(pred - target),  w = clamp(|F| / max_plane|F|, 0, 1), NaN -> 0
+ * `spec` (N*H*W*C*2 floats) receives (2*loss_weight/M) * w * F, from which favae_ffl_bwd forms
+ *   dL/dpred = gloss * Re ifft2_ortho(spec),  dL/dtarget = -dL/dpred.
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t favae_ffl_workspace(int N, int H, int W, int C);
+int favae_ffl_fwd(const float* pred, const float* target, int N, int H, int W, int C, float loss_weight, float* loss,
+                  float* spec, void* ws, size_t ws_bytes, favae_stream_t stream);
+int favae_ffl_bwd(const float* spec, const float* gloss, int N, int H, int W, int C, float* gpred, float* gtarget,
+                  void* ws, size_t ws_bytes, favae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Cosine-similarity vector quantiser.  Replaces CosineSimCodebook.forward / VectorQuantize.forward
+ * (models/l2_quantize.py:391-444, 533-596).
+ * ---------------------------------------------------------------------------------------------------------- */
+/* tokens z (T,d), codebook embed (C,d).  zn = l2norm(z), en = l2norm(embed), idx[t] = argmax_c <zn[t],en[c]> (first max;
+ * rows whose top-2 gap < tie_eps are re-evaluated in fp64), zq[t] = embed[idx[t]] (un-normalised row).  idx is int64. */
+size_t favae_vq_workspace(int T, int d, int C);
+int favae_vq_lookup(const float* z, const float* embed, int T, int d, int C, float tie_eps, int64_t* idx, float* zq,
+                    float* zn, float* en, void* ws, size_t ws_bytes, favae_stream_t stream);
+/* bins[c] = #tokens with idx==c ; embed_sum[c] = sum of zn rows with idx==c (deterministic: ascending token order) */
+int favae_vq_segment_sum(const float* zn, const int64_t* idx, int T, int d, int C, float* bins, float* embed_sum,
+                         favae_stream_t stream);
+/* EMA (l2_quantize.py:421-438): cluster_size = decay*cluster_size + (1-decay)*bins;
+ * embed = decay*embed + (1-decay)*(bins==0 ? en : l2norm(embed_sum/bins)) */
+int favae_vq_ema_update(float* embed, float* cluster_size, const float* en, const float* bins, const float* embed_sum,
+                        int C, int d, float decay, favae_stream_t stream);
+
+/* straight-through value exactly as the reference forms it: out = x + (q - x)   (models/l2_quantize.py:554) */
+int favae_vq_ste(const float* x, const float* q, float* out, int64_t n, favae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Reductions / element-wise glue.
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t favae_reduce_workspace(int64_t n);
+/* loss[0] = scale * sum |a-b|       (L1: favae_scripts/train_favae.py:76 with scale = 1/n) */
+int favae_absdiff_sum(const float* a, const float* b, int64_t n, float scale, float* loss, void* ws, size_t ws_bytes,
+                      favae_stream_t stream);
+/* loss[0] = scale * sum (a-b)^2     (commit loss: models/l2_quantize.py:560 with scale = weight/n) */
+int favae_sqdiff_sum(const float* a, const float* b, int64_t n, float scale, float* loss, void* ws, size_t ws_bytes,
+                     favae_stream_t stream);
+/* out = (out_add ? out_add : 0) + g[0]*scale*sign(a-b)   (dL1/da; pass -scale for dL1/db) */
+int favae_absdiff_bwd(const float* a, const float* b, const float* g, float scale, int64_t n, const float* out_add,
+                      float* out, favae_stream_t stream);
+/* out = (out_add ? out_add : 0) + g[0]*scale*(a-b)       (commit-loss gradient, straight-through add) */
+int favae_sqdiff_bwd(const float* a, const float* b, const float* g, float scale, int64_t n, const float* out_add,
+                     float* out, favae_stream_t stream);
+/* y = alpha*x + beta*y */
+int favae_axpby(const float* x, float alpha, float* y, float beta, int64_t n, favae_stream_t stream);
+/* layout converters: NCHW <-> NHWC */
+int favae_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, favae_stream_t stream);
+int favae_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, favae_stream_t stream);
+/* torch.optim.Adam (no weight decay / amsgrad) over one flat buffer: favae_scripts/train_favae.py:297-305 */
+int favae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    int step, float grad_scale, favae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAVAE_HIP_H */

@@ -1,0 +1,57 @@
+"""CPU: the C-ABI library loads and exports exactly the entry points include/favae_hip.h declares; the Python binding
+mirrors them one to one; the product path refuses to run without a GPU (no fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+import favae_hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "favae_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(favae_[a-z0-9_]+)\s*\(", src))
+
+
+def test_header_binding_and_library_agree():
+    syms = header_symbols()
+    assert len(syms) >= 35
+    assert syms == set(favae_hip.SIGNATURES), syms ^ set(favae_hip.SIGNATURES)
+    lib = favae_hip.load()
+    for s in syms:
+        assert hasattr(lib, s), f"libfavae_hip.so does not export {s}"
+    assert lib.favae_abi_version() == favae_hip.ABI_VERSION
+
+
+def test_no_cpu_fallback():
+    from favae_hip import ops
+    x = torch.zeros(1, 4, 8, 8)
+    with pytest.raises(RuntimeError):
+        ops.to_cl(x)
+    with pytest.raises(RuntimeError):
+        ops.focal_frequency_loss(x, x, 1.0)
+
+
+def test_dropin_surface_and_state_dict_keys():
+    """models.vqgan_fcm.VQGANFCM keeps the reference's constructor and state_dict key set/shapes."""
+    import favae_oracle as O
+    from models.vqgan_fcm import VQGANFCM
+    m = VQGANFCM(1024, 256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True, use_l2_quantizer=True,
+                 kernel_size=9, dsl_init_sigma=3.0, use_gauss_resblock=True, device="cpu")
+    shapes = O.param_shapes(O.OracleConfig(codebook_size=1024, variant="gauss_resblock"))
+    sd = m.state_dict()
+    assert set(sd) == set(shapes)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    assert hasattr(m.decoder.final[2], "weight") and hasattr(m.encoder, "sigmas") and hasattr(m.decoder, "sigmas")
+    m2 = VQGANFCM(512, 3, ch_mult=(1, 2, 4), attn_resolutions=[], use_cosine_sim=True, codebook_dim=32, use_l2_quantizer=True,
+                  kernel_size=3, dsl_init_sigma=3.0, use_same_conv_gauss=True, num_groups=3, device="cpu")
+    shapes2 = O.param_shapes(O.OracleConfig(codebook_size=512, n_embed=3, ch_mult=(1, 2, 4), attn_resolutions=(), codebook_dim=32,
+                                            kernel_size=3, variant="same_conv_gauss", num_groups=3))
+    assert {k: tuple(v.shape) for k, v in m2.state_dict().items()} == {k: tuple(v) for k, v in shapes2.items()}
+    with pytest.raises(ValueError):
+        m.forward(torch.zeros(1), stage=2)

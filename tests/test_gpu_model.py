@@ -1,0 +1,223 @@
+"""GPU parity of the whole model / training step (HIP path through the drop-in modules) against
+ (a) the golden vectors captured from the reference implementation and (b) the CPU oracle on the same seeded inputs.
+BASELINE bar: codebook indices bit-exact (near-ties with a reference top-2 gap < 1e-6 are reported separately),
+reconstruction and FFL within 1e-4 relative (fp32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import favae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+MODEL_KW = {
+    "cfg1": (dict(codebook_size=1024, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
+                  use_l2_quantizer=True, kernel_size=9, dsl_init_sigma=3.0, use_gauss_resblock=True),
+             dict(codebook_size=1024, variant="gauss_resblock", kernel_size=9)),
+    "cfg1_k3": (dict(codebook_size=1024, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
+                     use_l2_quantizer=True, kernel_size=3, dsl_init_sigma=3.0, use_gauss_resblock=True),
+                dict(codebook_size=1024, variant="gauss_resblock", kernel_size=3)),
+    "f4_same_conv": (dict(codebook_size=512, n_embed=3, ch_mult=(1, 2, 4), attn_resolutions=[], use_cosine_sim=True,
+                          codebook_dim=32, use_l2_quantizer=True, kernel_size=3, dsl_init_sigma=3.0, use_same_conv_gauss=True,
+                          num_groups=3),
+                     dict(codebook_size=512, n_embed=3, ch_mult=(1, 2, 4), attn_resolutions=(), codebook_dim=32, kernel_size=3,
+                          variant="same_conv_gauss", num_groups=3)),
+    "nonpair_conv": (dict(codebook_size=256, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
+                          use_l2_quantizer=True, kernel_size=5, dsl_init_sigma=2.0, use_non_pair_conv=True),
+                     dict(codebook_size=256, variant="non_pair_conv", kernel_size=5, dsl_init_sigma=2.0)),
+    "same_resblock": (dict(codebook_size=256, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
+                           use_l2_quantizer=True, kernel_size=3, dsl_init_sigma=3.0, use_same_gauss_resblock=True),
+                      dict(codebook_size=256, variant="same_gauss_resblock", kernel_size=3)),
+    "ffl_with_fcm": (dict(codebook_size=256, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
+                          use_l2_quantizer=True, use_ffl_with_fcm=True),
+                     dict(codebook_size=256, variant="ffl_with_fcm")),
+}
+
+
+def build(tag):
+    from models.vqgan_fcm import VQGANFCM
+    mk, ok = MODEL_KW[tag]
+    cfg = O.OracleConfig(**ok)
+    state = O.det_state(cfg, with_disc=True)
+    model = VQGANFCM(**mk, device=DEV)
+    model.load_state_dict(state, strict=True)
+    return model.to(DEV), cfg, state
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def close(a, b, tol, name):
+    e = rel(a, b)
+    assert e < tol, f"{name}: max-rel {e:.3e} >= {tol}"
+
+
+def check_indices(got, ref, gap, name="indices"):
+    got, ref, gap = np.asarray(got), np.asarray(ref), np.asarray(gap)
+    mism = got != ref
+    assert not (mism & (gap > 1e-6)).any(), f"{name}: mismatch outside flagged near-ties"
+    return int(mism.sum())
+
+
+# --------------------------------------------------------------------------------------------------------------
+# (a) golden vectors from the reference
+# --------------------------------------------------------------------------------------------------------------
+GOLDEN_FWD = [("cfg1_96", "cfg1"), ("f4_same_conv_32", "f4_same_conv"), ("nonpair_conv_80", "nonpair_conv")]
+
+
+@pytest.mark.parametrize("gtag,mtag", GOLDEN_FWD)
+def test_forward_against_reference_golden(golden_dir, gtag, mtag):
+    from favae_hip import ops as K
+    g = np.load(os.path.join(golden_dir, "models.npz"))
+    model, cfg, _ = build(mtag)
+    B, H, W, seed = [int(v) for v in g[gtag + ".shape"]]
+    x = O.det_input(B, H, W, seed).to(DEV)
+    model.train()
+    x_recon, loss_q, logits_fake, z, enc_feats, dec_feats = model(x, stage=0)
+    p = gtag + "."
+    close(loss_q, g[p + "loss_q"], 1e-4, "loss_q")
+    xr = x_recon.detach().cpu()
+    close(xr[:, :, ::max(1, H // 8), ::max(1, W // 8)], g[p + "x_recon_slice"], 1e-4, "x_recon")
+    assert abs(float(xr.double().abs().sum()) - float(g[p + "x_recon_abs"])) < 1e-4 * float(g[p + "x_recon_abs"])
+    close(K.l1_loss(x, x_recon), g[p + "loss_l1"], 1e-4, "loss_l1")
+    for i in range(4):
+        s = float(enc_feats[i].detach().double().abs().sum())
+        assert abs(s - float(g[p + f"enc_feat{i}_abs"])) < 1e-4 * float(g[p + f"enc_feat{i}_abs"]), f"enc_feat{i}"
+        s = float(dec_feats[i].detach().double().abs().sum())
+        assert abs(s - float(g[p + f"dec_feat{i}_abs"])) < 1e-4 * float(g[p + f"dec_feat{i}_abs"]), f"dec_feat{i}"
+    close(model.quantizer._codebook.cluster_size, g[p + "cluster_after"], 1e-5, "cluster (=> indices histogram)")
+    assert abs(float(model.quantizer._codebook.embed.double().abs().sum()) - float(g[p + "embed_after_abs"])) < 1e-5 * float(g[p + "embed_after_abs"])
+
+
+def test_indices_against_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "models.npz"))
+    for gtag, mtag in GOLDEN_FWD:
+        model, cfg, _ = build(mtag)
+        B, H, W, seed = [int(v) for v in g[gtag + ".shape"]]
+        model.train()
+        with torch.no_grad():
+            _, _, ind, _ = model.encode(O.det_input(B, H, W, seed).to(DEV))
+        flips = check_indices(ind.cpu().numpy(), g[gtag + ".indices"], g[gtag + ".index_gap"], gtag)
+        assert flips == 0, f"{gtag}: {flips} near-tie flips"
+
+
+def _golden_step(g, gtag, mtag, grad_tol=5e-3):
+    from favae_step import TrainStep
+    model, cfg, _ = build(mtag)
+    B, H, W, seed = [int(v) for v in g[gtag + ".shape"]]
+    x = O.det_input(B, H, W, seed).to(DEV)
+    ts = TrainStep(model, lr=4.5e-6 * 2, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01)
+    model.train()
+    ts.gflat.zero_()
+    out = ts.losses(x)
+    out["loss_g"].sum().backward()
+    p = gtag + "."
+    for k, gk in (("loss_quant", "loss_q"), ("loss_l1", "loss_l1"), ("loss_ffl", "loss_ffl"), ("loss_dsl", "loss_dsl"), ("loss_g", "loss_g")):
+        close(out[k].reshape(-1), g[p + gk], 1e-4, gk)
+    close(torch.stack([v.reshape(()) for v in out["loss_dsl_levels"]]), g[p + "loss_dsl_levels"], 1e-4, "dsl levels")
+    xr = out["x_recon"].detach().cpu()
+    close(xr[:, :, ::max(1, H // 8), ::max(1, W // 8)], g[p + "x_recon_slice"], 1e-4, "x_recon")
+    named = dict(model.named_parameters())
+    n = 0
+    for k, prm in named.items():
+        key = p + "g." + k + ".head"
+        if key in g.files:
+            gr = prm.grad.detach().cpu().contiguous()
+            tol = 2e-2 if k.endswith("sigmas") else grad_tol
+            scale = float(np.abs(g[key]).max()) + 1e-30
+            err = float(np.abs(gr.reshape(-1)[:16].numpy() - g[key]).max()) / scale
+            assert err < tol, f"grad head {k}: {err:.3e}"
+            ref_abs = float(g[p + "g." + k + ".abs"])
+            assert abs(float(gr.double().abs().sum()) - ref_abs) < tol * ref_abs, f"grad abs-sum {k}"
+            n += 1
+    assert n >= 8
+    return model, ts, out
+
+
+def test_train_step_f4_against_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "models.npz"))
+    _golden_step(g, "f4_same_conv_32", "f4_same_conv")
+
+
+def test_train_step_cfg1_256_against_reference_golden(golden_dir):
+    """BASELINE config 1 at full size: f=16, codebook 1024, 256x256, batch 2, FFL + DSL on."""
+    g = np.load(os.path.join(golden_dir, "cfg1_256.npz"))
+    model, ts, out = _golden_step(g, "cfg1_256", "cfg1")
+    with torch.no_grad():
+        m2, _, _ = build("cfg1")
+        m2.train()
+        _, _, ind, _ = m2.encode(O.det_input(2, 256, 256, 1234).to(DEV))
+    flips = check_indices(ind.cpu().numpy(), g["cfg1_256.indices"], g["cfg1_256.index_gap"])
+    assert flips == 0
+    close(model.discriminator.features[3].running_mean, g["cfg1_256.bn_running_mean"], 1e-4, "disc BN running mean")
+    # optimizer: one fused Adam step over the flat buffers vs torch.optim.Adam in the reference run
+    ts.t += 1
+    from favae_hip import ops as K
+    K.adam_step(ts.pflat, ts.gflat, ts.mflat, ts.vflat, 1, ts.lr, ts.betas, ts.eps, 1.0)
+    named = dict(model.named_parameters())
+    for k in ("encoder.conv_in.weight", "decoder.final.2.weight", "encoder.sigmas", "decoder.sigmas"):
+        got = named[k].detach().cpu().contiguous().reshape(-1)[:16]
+        close(got, g[f"cfg1_256.adam.{k}.head"], 1e-6, "adam." + k)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# (b) CPU oracle on the same seeded inputs, every decoder/DSL variant, 2 full optimizer steps
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mtag,hw", [("cfg1_k3", 64), ("f4_same_conv", 32), ("same_resblock", 64), ("ffl_with_fcm", 64),
+                                     ("nonpair_conv", 128)])
+def test_two_train_steps_vs_oracle(mtag, hw):
+    from favae_step import TrainStep
+    model, cfg, state = build(mtag)
+    dsl = 0.01
+    ts = TrainStep(model, lr=1e-4, dsl_weight=dsl)
+    orc = O.OracleTrainer(cfg, O.StepConfig(lr=1e-4, dsl_weight=dsl, with_disc_forward=True), state)
+    for step in range(2):
+        x = O.det_input(2, hw, hw, 100 + step)
+        ro = orc.step(x)
+        out = ts.step(x.to(DEV))
+        top2 = ro["out"]["dist"].topk(2, dim=-1).values
+        gap = (top2[..., 0] - top2[..., 1]).reshape(ro["out"]["indices"].shape).numpy()
+        with torch.no_grad():
+            pass
+        for k in ("loss_l1", "loss_quant", "loss_ffl", "loss_dsl", "loss_g"):
+            close(out[k].reshape(-1), ro[k].reshape(-1), 2e-4 if step else 1e-4, f"step{step}.{k}")
+        close(out["x_recon"], ro["out"]["x_recon"], 2e-4 if step else 1e-4, f"step{step}.x_recon")
+    named = dict(model.named_parameters())
+    worst = 0.0
+    for k in orc.keys:
+        if orc.P[k].grad is None:
+            continue
+        worst = max(worst, rel(named[k], orc.P[k]))
+    assert worst < 1e-4, f"parameters after 2 Adam steps: worst max-rel {worst:.3e}"
+    close(model.quantizer._codebook.embed, orc.P["quantizer._codebook.embed"], 1e-4, "EMA codebook after 2 steps")
+    close(model.quantizer._codebook.cluster_size, orc.P["quantizer._codebook.cluster_size"], 1e-5, "cluster_size")
+
+
+def test_eval_and_inference_surface():
+    """encode()/decode()/get_codebook_entry() as used by the stage-2 caller (reference models/txt_cond_transformer.py:136,165)."""
+    from models.vqgan_fcm import VQGANFCM
+    mk, ok = MODEL_KW["cfg1_k3"]
+    cfg = O.OracleConfig(**ok, inference=True)
+    state = O.det_state(cfg, with_disc=True)
+    model = VQGANFCM(**mk, device=DEV, inference=True)
+    model.load_state_dict(state, strict=True)
+    model.to(DEV).eval()
+    x = O.det_input(1, 64, 64, 9)
+    with torch.no_grad():
+        zq, lq, ind, ef = model.encode(x.to(DEV))
+        xr, df = model.decode(zq)
+        ze = model.quantizer.get_codebook_entry(ind.reshape(1, -1), (1, 4, 4, 256))
+    P = {k: v.clone() for k, v in state.items()}
+    r = O.vqganfcm_forward(P, x, cfg, training=False)
+    assert torch.equal(ind.cpu(), r["indices"])
+    assert float(lq) == 0.0 and all(d is None for d in df)
+    close(xr, r["x_recon"], 1e-4, "x_recon (eval)")
+    close(ze, r["z_q"], 1e-6, "get_codebook_entry")
+    close(ef[1], r["enc_feats"][1], 1e-4, "unblurred tap under inference")

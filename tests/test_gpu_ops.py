@@ -1,0 +1,335 @@
+"""GPU parity of every HIP op (through the C ABI) against plain PyTorch fp32 CPU references / the CPU oracle.
+Tolerances: fp32 kernels, relative to the max magnitude of the reference tensor; indices bit-exact."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import favae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    import favae_hip
+    favae_hip.load()
+    from favae_hip import ops
+    return ops
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0):
+    n = int(np.prod(shape))
+    return (scale * (2 * O._hash_uniform(n, seed).reshape(shape) - 1)).float()
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def check(a, b, tol, name):
+    e = relerr(a, b)
+    assert e < tol, f"{name}: max-rel {e:.3e} >= {tol}"
+
+
+CONV_CASES = [
+    # (N, Cin, H, W, Cout, k, stride, pad, pad_br, upsample, gn groups or None, residual)
+    (2, 32, 12, 10, 64, 3, 1, 1, 1, False, None, False),
+    (2, 32, 12, 10, 64, 3, 1, 1, 1, False, 32, True),
+    (1, 64, 9, 11, 96, 3, 1, 1, 1, False, 32, False),
+    (2, 3, 16, 16, 128, 3, 1, 1, 1, False, None, False),       # conv_in (Cin = 3, scalar path)
+    (2, 128, 16, 16, 3, 3, 1, 1, 1, False, 32, False),         # final conv (Cout = 3)
+    (2, 32, 10, 12, 32, 3, 2, 0, 1, False, None, False),       # Downsample
+    (1, 32, 9, 7, 32, 3, 2, 0, 1, False, None, False),         # Downsample, odd sizes
+    (2, 32, 5, 6, 32, 3, 1, 1, 1, True, None, False),          # Upsample fused
+    (2, 64, 6, 5, 192, 1, 1, 0, 0, False, 32, False),          # 1x1 with GN (attention in-proj shape)
+    (2, 256, 8, 8, 128, 1, 1, 0, 0, False, None, True),        # 1x1 shortcut + residual
+    (1, 8, 6, 7, 8, 3, 1, 1, 1, False, 4, False),              # tiny channels, groups=4
+    (3, 40, 17, 13, 200, 3, 1, 1, 1, False, 8, True),          # ragged tiles everywhere
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
+def test_fused_conv_fwd_bwd(K, case):
+    N, Cin, H, W, Cout, k, s, p, pbr, up, groups, use_res = case
+    x = rnd((N, Cin, H, W), 1).requires_grad_(True)
+    w = rnd((Cout, Cin, k, k), 2, math.sqrt(3.0 / (Cin * k * k))).requires_grad_(True)
+    b = rnd((Cout,), 3, 0.1).requires_grad_(True)
+    gw = (1 + rnd((Cin,), 4, 0.2)).requires_grad_(True) if groups else None
+    gb = rnd((Cin,), 5, 0.2).requires_grad_(True) if groups else None
+    # reference
+    h = x
+    if groups:
+        h = F.silu(F.group_norm(h, groups, gw, gb, eps=1e-5))
+    if up:
+        h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+    if pbr != p:
+        h = F.pad(h, (p, pbr, p, pbr))
+        y = F.conv2d(h, w, b, stride=s)
+    else:
+        y = F.conv2d(h, w, b, stride=s, padding=p)
+    res = rnd(tuple(y.shape), 6).requires_grad_(True) if use_res else None
+    if use_res:
+        y = y + res
+    gy = rnd(tuple(y.shape), 7)
+    (y * gy).sum().backward()
+    # HIP
+    d = dev()
+    xd = x.detach().to(d).requires_grad_(True)
+    wd = w.detach().to(d).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = b.detach().to(d).requires_grad_(True)
+    gwd = gw.detach().to(d).requires_grad_(True) if groups else None
+    gbd = gb.detach().to(d).requires_grad_(True) if groups else None
+    rd = res.detach().to(d).requires_grad_(True) if use_res else None
+    cfg = K.ConvCfg(k, k, s, p, pad_br=pbr, upsample=up, groups=groups or 32)
+    yd = K.fused_conv(xd, wd, bd, gwd, gbd, rd, cfg)
+    assert tuple(yd.shape) == tuple(y.shape)
+    (yd * gy.to(d)).sum().backward()
+    check(yd, y, 2e-5, "y")
+    check(xd.grad, x.grad, 5e-5, "dx")
+    check(wd.grad, w.grad, 5e-5, "dw")
+    check(bd.grad, b.grad, 5e-5, "db")
+    if groups:
+        check(gwd.grad, gw.grad, 1e-4, "dgamma")
+        check(gbd.grad, gb.grad, 1e-4, "dbeta")
+    if use_res:
+        check(rd.grad, res.grad, 1e-6, "dres")
+
+
+def test_conv_large_tile_shapes(K):
+    """one realistic layer shape: 128->128 @ 64x64, batch 2 (many full 128x128 tiles, XCD remap active)."""
+    N, C, H = 2, 128, 64
+    x = rnd((N, C, H, H), 11)
+    w = rnd((C, C, 3, 3), 12, math.sqrt(3.0 / (C * 9)))
+    b = rnd((C,), 13, 0.1)
+    gw, gb = 1 + rnd((C,), 14, 0.2), rnd((C,), 15, 0.2)
+    y = F.conv2d(F.silu(F.group_norm(x, 32, gw, gb)), w, b, padding=1)
+    d = dev()
+    yd = K.fused_conv(x.to(d), w.to(d), b.to(d), gw.to(d), gb.to(d), None, K.ConvCfg(3, 3, 1, 1))
+    check(yd, y, 2e-5, "y")
+
+
+BLOCK_DIMS = {"res_same": ("res", (64, 64)), "res_short": ("res", (32, 96)), "nonres": ("nonres", (64, 64)),
+              "nonres_g4": ("nonres4", (8, 8)), "attn": ("attn", (64,)), "down": ("down", (32,)), "down_odd": ("down", (32,)),
+              "up": ("up", (32,))}
+
+
+@pytest.mark.parametrize("name", list(BLOCK_DIMS))
+def test_blocks_against_reference_golden(K, golden_dir, name):
+    """Product modules vs the vectors captured from the reference implementation (tests/golden/blocks.npz)."""
+    from models import codec as C
+    g = np.load(os.path.join(golden_dir, "blocks.npz"))
+    kind, dims = BLOCK_DIMS[name]
+    if kind == "res":
+        mod = C.ResnetBlock(dims[0], dims[1], 0.0)
+    elif kind == "nonres":
+        mod = C.NonResnetBlock(dims[0], dims[1], 0.0)
+    elif kind == "nonres4":
+        mod = C.NonResnetBlock(dims[0], dims[1], 0.0, num_groups=4)
+    elif kind == "attn":
+        mod = C.AttnBlock(dims[0])
+    elif kind == "down":
+        mod = C.Downsample(dims[0])
+    else:
+        mod = C.Upsample(dims[0])
+    sd = {k: O.det_value("blk." + k, tuple(v.shape)) for k, v in mod.state_dict().items()}
+    mod.load_state_dict(sd, strict=True)
+    mod.to(dev())
+    x = torch.from_numpy(g[f"{name}.x"]).to(dev()).requires_grad_(True)
+    y = mod(x)
+    (y * torch.from_numpy(g[f"{name}.gy"]).to(dev())).sum().backward()
+    check(y, torch.from_numpy(g[f"{name}.y"]), 3e-5, "y")
+    check(x.grad, torch.from_numpy(g[f"{name}.gx"]), 1e-4, "gx")
+    for k, p in mod.named_parameters():
+        check(p.grad, torch.from_numpy(g[f"{name}.g.{k}"]), 2e-4, "g." + k)
+
+
+def test_attention_core(K):
+    N, C, H, W = 2, 64, 6, 5
+    qkv = rnd((N, 3 * C, H, W), 21).requires_grad_(True)
+    L = H * W
+    t = qkv.view(N, 3 * C, L).transpose(1, 2)
+    q, k, v = t.split(C, dim=-1)
+    o = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), -1) @ v
+    o = o.transpose(1, 2).reshape(N, C, H, W)
+    go = rnd((N, C, H, W), 22)
+    (o * go).sum().backward()
+    qd = qkv.detach().to(dev()).requires_grad_(True)
+    od = K.AttnCoreFn.apply(qd)
+    (od * go.to(dev())).sum().backward()
+    check(od, o, 2e-5, "o")
+    check(qd.grad, qkv.grad, 5e-5, "dqkv")
+
+
+def test_attention_core_l256_c512(K):
+    N, C, H, W = 2, 512, 16, 16
+    qkv = rnd((N, 3 * C, H, W), 23, 0.5)
+    L = H * W
+    t = qkv.view(N, 3 * C, L).transpose(1, 2)
+    q, k, v = t.split(C, dim=-1)
+    o = (torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), -1) @ v).transpose(1, 2).reshape(N, C, H, W)
+    od = K.AttnCoreFn.apply(qkv.to(dev()))
+    check(od, o, 2e-5, "o")
+
+
+def test_blur_against_reference_golden(K, golden_dir):
+    g = np.load(os.path.join(golden_dir, "blur.npz"))
+    tags = sorted({k.split(".")[0] for k in g.files})
+    for tag in tags:
+        ks = int(tag.split("_")[0][1:])
+        x = torch.from_numpy(g[f"{tag}.x"]).to(dev()).requires_grad_(True)
+        sig = torch.tensor([9.0, float(g[f"{tag}.sigma"]), 9.0, 9.0], device=dev(), requires_grad=True)
+        y = K.gaussian_blur(x, sig, 1, ks)
+        (y * torch.from_numpy(g[f"{tag}.gy"]).to(dev())).sum().backward()
+        check(y, torch.from_numpy(g[f"{tag}.y"]), 1e-5, tag + ".y")
+        check(x.grad, torch.from_numpy(g[f"{tag}.gx"]), 1e-5, tag + ".gx")
+        ref = float(g[f"{tag}.gsig"][1])
+        got = sig.grad.cpu()
+        assert abs(float(got[1]) - ref) <= 2e-4 * abs(ref) + 1e-6, (tag, float(got[1]), ref)
+        assert float(got[0]) == 0.0 and float(got[2]) == 0.0 and float(got[3]) == 0.0
+
+
+@pytest.mark.parametrize("shape,ks", [((2, 128, 32, 32), 9), ((1, 512, 16, 16), 9), ((2, 3, 64, 64), 5), ((1, 40, 20, 33), 15)])
+def test_blur_vs_oracle(K, shape, ks):
+    x = rnd(shape, 31).requires_grad_(True)
+    s = torch.tensor(2.5, requires_grad=True)
+    y = O.gaussian_blur(x, s, ks)
+    gy = rnd(shape, 32)
+    (y * gy).sum().backward()
+    xd = x.detach().to(dev()).requires_grad_(True)
+    sd = torch.tensor([2.5, 1.0, 1.0, 1.0], device=dev(), requires_grad=True)
+    yd = K.gaussian_blur(xd, sd, 0, ks)
+    (yd * gy.to(dev())).sum().backward()
+    check(yd, y, 1e-5, "y")
+    check(xd.grad, x.grad, 1e-5, "dx")
+    assert abs(float(sd.grad[0]) - float(s.grad)) <= 3e-4 * abs(float(s.grad)) + 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16), (2, 128, 32, 32), (1, 512, 16, 16), (2, 3, 256, 256), (1, 40, 8, 64), (1, 5, 64, 4)])
+def test_ffl_vs_oracle(K, shape):
+    p = rnd(shape, 41).requires_grad_(True)
+    t = rnd(shape, 42).requires_grad_(True)
+    l = O.focal_frequency_loss(p, t, 0.37)
+    l.backward()
+    pd = p.detach().to(dev()).requires_grad_(True)
+    td = t.detach().to(dev()).requires_grad_(True)
+    ld = K.focal_frequency_loss(pd, td, 0.37)
+    ld.backward()
+    assert abs(float(ld) - float(l)) <= 1e-4 * abs(float(l)), (float(ld), float(l))      # BASELINE: FFL within 1e-4 rel
+    check(pd.grad, p.grad, 1e-4, "gpred")
+    check(td.grad, t.grad, 1e-4, "gtarget")
+
+
+def test_ffl_known_answers(K):
+    d = dev()
+    x = O.det_input(2, 16, 16, 3).to(d)
+    assert float(K.focal_frequency_loss(x, x.clone(), 1.0)) == 0.0                        # identical -> 0 (NaN branch)
+    H, W, a = 16, 32, 0.75
+    t = torch.zeros(1, 1, H, W, device=d)
+    p = t.clone()
+    p[0, 0, 3, 5] = a
+    assert abs(float(K.focal_frequency_loss(p, t, 1.0)) - a * a / (H * W)) < 1e-8        # delta -> a^2/HW
+    A, k = 0.3, 5
+    xx = torch.arange(32, dtype=torch.float32)
+    p = (A * torch.cos(2 * math.pi * k * xx / 32)).view(1, 1, 1, 32).expand(1, 1, 32, 32).contiguous().to(d)
+    assert abs(float(K.focal_frequency_loss(p, torch.zeros_like(p), 1.0)) - A * A / 2) < 1e-6   # cosine -> A^2/2
+
+
+def test_ffl_rejects_non_pow2(K):
+    p = torch.zeros(1, 4, 6, 6, device=dev())
+    with pytest.raises(RuntimeError):
+        K.focal_frequency_loss(p, p, 1.0)
+
+
+VQ_CASES = [("c64", 32, None, 64, (2, 32, 4, 4), 2), ("proj", 3, 16, 48, (2, 3, 6, 6), 2), ("c1024", 256, None, 1024, (2, 256, 8, 8), 1)]
+
+
+@pytest.mark.parametrize("case", VQ_CASES, ids=[c[0] for c in VQ_CASES])
+def test_vq_against_reference_golden(K, golden_dir, case):
+    from models.l2_quantize import VectorQuantize
+    g = np.load(os.path.join(golden_dir, "vq.npz"))
+    tag, dim, cdim, C, shp, steps = case
+    vq = VectorQuantize(codebook_size=C, dim=dim, accept_image_fmap=True, use_cosine_sim=True, codebook_dim=cdim,
+                        sync_codebook=False, commitment_weight=0.7)
+    vq.load_state_dict({k: O.det_value("quantizer." + k, tuple(v.shape)) for k, v in vq.state_dict().items()}, strict=True)
+    vq.to(dev()).train()
+    n = int(np.prod(shp))
+    for s in range(steps):
+        z = (1.5 * (2 * O._hash_uniform(n, int(g[f"{tag}.s{s}.zseed"])).reshape(shp) - 1)).float().to(dev()).requires_grad_(True)
+        gq = rnd(shp, 8).to(dev())
+        q, ind, loss = vq(z)
+        ((q * gq).sum() + 3.0 * loss.sum()).backward()
+        ref_ind, gap = g[f"{tag}.s{s}.ind"], g[f"{tag}.s{s}.gap"]
+        mism = ind.cpu().numpy() != ref_ind
+        assert not (mism & (gap > 1e-6)).any(), "index mismatch outside flagged near-ties"
+        assert mism.sum() == 0, f"{mism.sum()} near-tie index flips (gaps {gap[mism]})"
+        check(loss, torch.from_numpy(g[f"{tag}.s{s}.loss"]), 1e-5, "loss")
+        check(q[:, :8, :2, :2], torch.from_numpy(g[f"{tag}.s{s}.q_slice"]), 1e-6, "q")
+        check(z.grad[:, :8, :2, :2], torch.from_numpy(g[f"{tag}.s{s}.gz_slice"]), 1e-5, "gz")
+        check(vq._codebook.embed[0, :16, :8], torch.from_numpy(g[f"{tag}.s{s}.embed_slice"]), 1e-6, "embed")
+        assert abs(float(vq._codebook.embed.double().abs().sum()) - float(g[f"{tag}.s{s}.embed_abs"])) < 1e-5 * float(g[f"{tag}.s{s}.embed_abs"])
+        check(vq._codebook.cluster_size, torch.from_numpy(g[f"{tag}.s{s}.cluster"]), 1e-6, "cluster")
+        for k, p in vq.named_parameters():
+            check(p.grad, torch.from_numpy(g[f"{tag}.s{s}.g.{k}"]), 2e-4, "g." + k)
+            p.grad = None
+    vq.eval()
+    z = rnd(shp, 999).to(dev())
+    q, ind, loss = vq(z)
+    assert np.array_equal(ind.cpu().numpy(), g[f"{tag}.eval.ind"])
+    assert float(loss) == 0.0
+    check(q[:, :8, :2, :2], torch.from_numpy(g[f"{tag}.eval.q_slice"]), 1e-6, "eval q")
+    zq = vq.get_codebook_entry(ind.reshape(shp[0], -1), (shp[0], shp[2], shp[3], cdim or dim))
+    check(zq[:, :8, :2, :2], torch.from_numpy(g[f"{tag}.entry_slice"]), 1e-6, "entry")
+
+
+def test_vq_exact_ties_pick_first_index(K):
+    """duplicate codebook rows -> exact ties -> torch.argmax semantics = lowest index."""
+    d = dev()
+    emb = F.normalize(rnd((8, 16), 51), dim=-1)
+    emb = torch.cat([emb, emb], 0).contiguous().to(d)           # rows i and i+8 identical
+    tok = rnd((40, 16), 52).to(d)
+    idx, zq, zn, en = K.vq_lookup(tok, emb)
+    assert int(idx.max()) < 8
+    ref = (F.normalize(tok.cpu(), dim=-1) @ F.normalize(emb.cpu(), dim=-1).t()).argmax(-1)
+    assert torch.equal(idx.cpu(), ref)
+
+
+def test_l1_and_adam(K):
+    d = dev()
+    a, b = rnd((2, 3, 32, 32), 61), rnd((2, 3, 32, 32), 62)
+    br = b.clone().requires_grad_(True)
+    l = (a - br).abs().mean()
+    l.backward()
+    bd = b.to(d).requires_grad_(True)
+    ld = K.l1_loss(a.to(d), bd)
+    ld.backward()
+    assert abs(float(ld) - float(l)) < 1e-6 * abs(float(l))
+    check(bd.grad, br.grad, 1e-6, "gb")
+    # Adam vs torch.optim.Adam, 3 steps
+    p = rnd((1000,), 63)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3, betas=(0.5, 0.9))
+    pd, m, v = p.to(d), torch.zeros(1000, device=d), torch.zeros(1000, device=d)
+    for t in range(1, 4):
+        gr = rnd((1000,), 70 + t)
+        pr.grad = gr.clone()
+        opt.step()
+        K.adam_step(pd, gr.to(d), m, v, t, 1e-3)
+    check(pd, pr, 1e-6, "adam")
+
+
+def test_layout_roundtrip(K):
+    x = rnd((2, 5, 7, 9), 81).to(dev())
+    y = K.to_cl(x)
+    assert torch.equal(y.cpu(), x.cpu()) and y.is_contiguous(memory_format=torch.channels_last)
+    z = K.to_nchw(y)
+    assert z.is_contiguous() and torch.equal(z.cpu(), x.cpu())
