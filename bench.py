@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""FA-VAE training-step benchmark on MI355X (driver contract: `python bench.py --gpus N --steps K --warmup W`).
+
+Workload (BASELINE.json configs[1]): FA-VAE f=16 CelebA-HQ config -- codebook 16384, embed_dim 256, residual FCM +
+non pair-wise DSL (gaussian_kernel 9, sigma0 3), FFL 1.0 + DSL 0.01, LPIPS / discriminator training off -- on
+synthetic 256x256x3 batches of 32 images per GPU, fp32, random-init weights.  A "step" is one full stage-0 training
+step (forward incl. the always-executed discriminator forward, all losses, backward, [RCCL gradient all-reduce],
+fused Adam) with the batch already resident in HBM.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement"):
+  value      whole-job images/s  (sum over ranks / max-over-ranks time, barrier + synchronize on both sides)
+  roofline   dominant kernel = conv_fwd_kernel<128,2,2> (forward + data-gradient implicit GEMM, exact-fp32 MFMA):
+             algorithmic FLOPs (2*M*Cout*KH*KW*Cin per launch) / launch durations measured with HIP events on the launch
+             stream inside the timed region; peak = 157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md)
+  cpu_baseline  the CPU oracle (kind "port": pure-PyTorch restatement of the reference step, oracle/) timed on this
+             host's cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "fa-vae_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE config: 32)")
+    ap.add_argument("--codebook", type=int, default=16384)
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=1, help="images in the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+class ConvEventHook:
+    """Brackets every launch of the dominant kernel with HIP events (torch.cuda.Event records on the current stream,
+    which is the stream favae_hip launches on)."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.recs = []          # (start, end, flops)
+        self.enabled = False
+
+    def __call__(self, name, args, launch):
+        if not self.enabled or name != "favae_conv_fwd":
+            return launch()
+        d = args[0]._obj
+        if d.Cout <= 64:        # dispatches to the narrow-tile variants, not the dominant kernel
+            return launch()
+        flops = 2.0 * d.N * d.Hout * d.Wout * d.Cout * d.KH * d.KW * d.Cin
+        s = self.torch.cuda.Event(enable_timing=True)
+        e = self.torch.cuda.Event(enable_timing=True)
+        s.record()
+        launch()
+        e.record()
+        self.recs.append((s, e, flops))
+
+    def summary(self):
+        if not self.recs:
+            return None
+        ms = [s.elapsed_time(e) for s, e, _ in self.recs]
+        fl = [f for _, _, f in self.recs]
+        tot_ms, tot_fl = sum(ms), sum(fl)
+        return {"launches": len(ms), "avg_us": 1e3 * tot_ms / len(ms), "avg_gflop": 1e-9 * tot_fl / len(ms),
+                "tflops": 1e-12 * tot_fl / (1e-3 * tot_ms), "total_ms": tot_ms}
+
+
+def cpu_baseline(args, torch):
+    import favae_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    cfg = O.OracleConfig(codebook_size=args.codebook, variant="gauss_resblock", kernel_size=9)
+    sc = O.StepConfig(lr=4.5e-6 * args.batch, with_disc_forward=True)
+    tr = O.OracleTrainer(cfg, sc)
+    B = args.cpu_batch
+    x = O.det_input(B, args.res, args.res, 1234)
+    tr.step(x)                                   # untimed: thread-pool / allocator warm-up
+    t0 = time.perf_counter()
+    tr.step(O.det_input(B, args.res, args.res, 1235))
+    dt = time.perf_counter() - t0
+    return {"value": B / dt, "unit": "images/s", "cores": ncores, "kind": "port",
+            "sample": f"1 timed training step (after 1 warm-up step) of the same f=16 config at batch {B}, "
+                      f"oracle/favae_oracle.py on torch {torch.__version__} CPU, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")           # RCCL on ROCm
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import favae_hip
+    import favae_oracle as O                       # deterministic synthetic data only (det_input); checker otherwise
+    from favae_step import TrainStep
+    from models.vqgan_fcm import VQGANFCM
+
+    favae_hip.load()
+    torch.manual_seed(0)                           # favae_scripts/train_favae.py:235
+    model = VQGANFCM(args.codebook, 256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
+                     use_l2_quantizer=True, sync_codebook=world > 1, commitment_weight=1.0, kernel_size=9, dsl_init_sigma=3.0,
+                     device=dev, use_gauss_resblock=True).to(dev)
+    lr = 4.5e-6 * args.batch * world               # train_favae.py:250-251
+    ts = TrainStep(model, lr=lr, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, distributed=world > 1)
+    xs = [O.det_input(args.batch, args.res, args.res, 1234 + 17 * rank + i).to(dev) for i in range(2)]
+
+    hook = ConvEventHook(torch)
+    favae_hip.set_call_hook(hook)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        ts.step(xs[i % 2])
+    sync()
+    hook.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = ts.step(xs[i % 2])
+    sync()
+    dt = time.perf_counter() - t0
+    hook.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out["loss_g"].reshape(-1)[0])
+
+    if rank == 0:
+        conv = hook.summary()
+        res = {
+            "metric": "images/sec (256x256, f=16 FA-VAE train step)",
+            "value": args.batch * world * args.steps / dt,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: FA-VAE f=16 CelebA-HQ config, codebook %d, embed_dim 256, residual FCM + "
+                                   "non-pairwise DSL (k=9, sigma0=3), FFL 1.0 + DSL 0.01, %dx%d, batch %d per GPU, stage-0 step "
+                                   "(LPIPS/disc training off, disc forward on)" % (args.codebook, args.res, args.res, args.batch),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss_g_last": loss},
+        }
+        if conv:
+            res["roofline"] = {"bound": "mfma", "achieved": conv["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": conv["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "kernel": "conv_fwd_kernel<128,2,2> (fwd + dgrad implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                               "launches": conv["launches"], "avg_launch_us": conv["avg_us"],
+                               "avg_algorithmic_gflop_per_launch": conv["avg_gflop"],
+                               "share_of_step_time": conv["total_ms"] / (1e3 * dt)}
+        if world == 1 and not args.no_cpu_baseline:
+            favae_hip.set_call_hook(None)
+            res["cpu_baseline"] = cpu_baseline(args, torch)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

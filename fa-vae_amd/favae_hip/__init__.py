@@ -103,10 +103,23 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_hook = None
+
+
+def set_call_hook(fn):
+    """fn(name, args, launch) or None.  Used by bench.py to bracket selected launches with HIP events on the launch
+    stream; `launch()` performs the real call.  Never used to reroute compute."""
+    global _hook
+    _hook = fn
+
+
 def call(name, *args):
     """Invoke an int-returning entry point on the current stream (stream appended automatically)."""
     lib = load()
-    _chk(getattr(lib, name)(*args, stream()), name)
+    if _hook is None:
+        _chk(getattr(lib, name)(*args, stream()), name)
+    else:
+        _hook(name, args, lambda: _chk(getattr(lib, name)(*args, stream()), name))
 
 
 def query(name, *args):
