@@ -77,7 +77,11 @@ class ConvEventHook:
 
 def cpu_baseline(args, torch):
     import favae_oracle as O
-    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))        # cores this process may actually use (cgroup/affinity aware)
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, torch.get_num_threads()))
     torch.set_num_threads(ncores)
     cfg = O.OracleConfig(codebook_size=args.codebook, variant="gauss_resblock", kernel_size=9)
     sc = O.StepConfig(lr=4.5e-6 * args.batch, with_disc_forward=True)
@@ -175,6 +179,7 @@ def main():
                                "share_of_step_time": conv["total_ms"] / (1e3 * dt)}
         if world == 1 and not args.no_cpu_baseline:
             favae_hip.set_call_hook(None)
+            print("[bench] GPU part done: %.2f images/s; timing the CPU baseline sample..." % res["value"], file=sys.stderr, flush=True)
             res["cpu_baseline"] = cpu_baseline(args, torch)
         print(json.dumps(res), flush=True)
     if world > 1:

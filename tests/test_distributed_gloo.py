@@ -1,0 +1,104 @@
+"""CPU, world_size 2, gloo: the data-parallel scheme of favae_step.TrainStep is correct by construction.
+
+TrainStep exchanges exactly three things per step: SUM all-reduce of the flat gradient buffer
+(scaled by 1/world inside the Adam kernel) and the two SUM all-reduces of the codebook statistics inside the quantizer
+forward (reference models/l2_quantize.py:419,427).  Here the same exchanges are driven through the CPU oracle on 2 gloo
+ranks and compared with ONE process stepping on the concatenated global batch: identical codebooks on all ranks, equal to
+the global-batch EMA, and rank-averaged gradients equal to the global-batch gradients (every loss term is a per-sample
+mean).  The HIP kernels themselves cannot run here (no GPU, no fallback); the host-side flat-buffer plumbing is
+checked in test_trainstep_flat_views."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import favae_oracle as O
+
+TINY = dict(codebook_size=64, n_embed=32, ch=32, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(16,), resolution=32,
+            kernel_size=3, variant="gauss_resblock")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = O.OracleConfig(**TINY)
+    sc = O.StepConfig(lr=1e-3, dsl_weight=0.01)
+    tr = O.OracleTrainer(cfg, sc, dtype=torch.float64)
+    xg = O.det_input(4, 32, 32, 5, torch.float64)
+    x = xg[2 * rank:2 * rank + 2]
+
+    def grad_avg(g):
+        dist.all_reduce(g)
+        g.div_(world)
+
+    for _ in range(2):
+        res = tr.step(x, all_reduce=dist.all_reduce, grad_all_reduce=grad_avg)
+    out = {"embed": tr.P["quantizer._codebook.embed"].clone(), "cluster": tr.P["quantizer._codebook.cluster_size"].clone(),
+           "w": tr.P["encoder.conv_in.weight"].detach().clone(), "sig": tr.P["decoder.sigmas"].detach().clone(),
+           "g": res["grads"]["decoder.final.2.weight"].clone()}
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_global_batch_step():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process, global batch
+    cfg = O.OracleConfig(**TINY)
+    tr = O.OracleTrainer(cfg, O.StepConfig(lr=1e-3, dsl_weight=0.01), dtype=torch.float64)
+    xg = O.det_input(4, 32, 32, 5, torch.float64)
+    for _ in range(2):
+        res = tr.step(xg)
+    ref = {"embed": tr.P["quantizer._codebook.embed"], "cluster": tr.P["quantizer._codebook.cluster_size"],
+           "w": tr.P["encoder.conv_in.weight"].detach(), "sig": tr.P["decoder.sigmas"].detach(),
+           "g": res["grads"]["decoder.final.2.weight"]}
+    for k in ref:
+        assert torch.equal(got[0][k], got[1][k]) or float((got[0][k] - got[1][k]).abs().max()) < 1e-12, f"ranks diverged: {k}"
+        err = float((got[0][k] - ref[k]).abs().max() / (ref[k].abs().max() + 1e-30))
+        assert err < 1e-9, f"{k}: 2-rank result differs from the global-batch step by {err:.2e}"
+
+
+def test_trainstep_flat_views():
+    """Host plumbing of TrainStep: parameters/gradients are views of the flat buffers (one Adam launch, one all-reduce),
+    channels-last conv weights keep their OHWI memory, pair-wise sigmas sit in their own tail segment."""
+    from favae_step import TrainStep
+    from models.vqgan_fcm import VQGANFCM
+    m = VQGANFCM(64, 3, ch_mult=(1, 2, 4), attn_resolutions=[], use_cosine_sim=True, codebook_dim=8, use_l2_quantizer=True,
+                 kernel_size=3, dsl_init_sigma=3.0, use_same_conv_gauss=True, num_groups=3, device="cpu")
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    ts = TrainStep(m, lr=1e-4)
+    n_train = sum(p.numel() for k, p in m.named_parameters() if not k.startswith("discriminator."))
+    assert ts.pflat.numel() == n_train and ts.pflat.numel() - ts.n_main == 4
+    lo, hi = ts.pflat.data_ptr(), ts.pflat.data_ptr() + 4 * ts.pflat.numel()
+    for k, p in m.named_parameters():
+        if k.startswith("discriminator."):
+            continue
+        assert lo <= p.data_ptr() < hi and torch.equal(p.detach(), before[k]), k
+        assert p.grad is not None and p.grad.stride() == p.stride()
+        if p.dim() == 4 and p.shape[2] > 1:
+            assert p.is_contiguous(memory_format=torch.channels_last), k
+    assert m.sigmas.data_ptr() == ts.pflat.data_ptr() + 4 * ts.n_main
+    ts.gflat.fill_(1.0)
+    assert float(m.encoder.conv_in.weight.grad.sum()) == m.encoder.conv_in.weight.numel()
