@@ -9,7 +9,7 @@ fused Adam) with the batch already resident in HBM.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement"):
   value      whole-job images/s  (sum over ranks / max-over-ranks time, barrier + synchronize on both sides)
-  roofline   dominant kernel = conv_fwd_kernel<128,2,2> (forward + data-gradient implicit GEMM, exact-fp32 MFMA):
+  roofline   dominant kernel = conv_fwd_fast_kernel<128,2,2,PLAIN> (forward + data-gradient implicit GEMM, exact-fp32 MFMA):
              algorithmic FLOPs (2*M*Cout*KH*KW*Cin per launch) / launch durations measured with HIP events on the launch
              stream inside the timed region; peak = 157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md)
   cpu_baseline  the CPU oracle (kind "port": pure-PyTorch restatement of the reference step, oracle/) timed on this
@@ -55,7 +55,7 @@ class ConvEventHook:
         if not self.enabled or name != "favae_conv_fwd":
             return launch()
         d = args[0]._obj
-        if d.Cout <= 64:        # dispatches to the narrow-tile variants, not the dominant kernel
+        if d.Cout <= 64 or d.Cin % 4 or d.gather != 0:      # other instantiations, not the dominant kernel
             return launch()
         flops = 2.0 * d.N * d.Hout * d.Wout * d.Cout * d.KH * d.KW * d.Cin
         s = self.torch.cuda.Event(enable_timing=True)
@@ -173,7 +173,7 @@ def main():
         if conv:
             res["roofline"] = {"bound": "mfma", "achieved": conv["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": conv["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                               "kernel": "conv_fwd_kernel<128,2,2> (fwd + dgrad implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                               "kernel": "conv_fwd_fast_kernel<128,2,2,PLAIN> (fwd + dgrad implicit GEMM, v_mfma_f32_32x32x2_f32)",
                                "launches": conv["launches"], "avg_launch_us": conv["avg_us"],
                                "avg_algorithmic_gflop_per_launch": conv["avg_gflop"],
                                "share_of_step_time": conv["total_ms"] / (1e3 * dt)}

@@ -1,12 +1,15 @@
 // Learnable-sigma Gaussian blur of the Frequency Complement Module taps (models/codec.py:255-277, models/vqgan_fcm.py:20-41):
 //   g = exp(-0.5 (t/sigma)^2) / sum,  t = linspace(-(k-1)/2, (k-1)/2, k);   K = g g^T;   y = K (*) reflectpad(x), depthwise.
-// NHWC, HBM-bound.  A block owns a TH x TW pixel tile x CC channels of one image; the (TH+k-1) x (TW+k-1) x CC halo tile is
-// staged once in LDS with the reflect indexing applied while loading (forward, dK) or zero-extended (dx adjoint), lanes run
-// along channels (contiguous, conflict-free LDS reads), each thread produces 16 pixels of one channel.
-//   dx     = adjoint(reflect-pad o correlation): every padded position j that reflects onto i contributes
-//            Z[j] = sum_ab K[a][b] dy0[j+p-a]  (dy0 = dy zero-extended)  -> dx[i] = sum_{j in pre(i)} Z[j]
-//   dsigma : dK[a][b] = sum dy * xpad[.+a,.+b]  (k^2 block-reduced partials -> deterministic column sum) then
-//            dg_a = sum_b (dK[a][b]+dK[b][a]) g_b ; dp = (dg - <dg,g>)/sum(p) ; dsigma = sum_j dp_j p_j t_j^2 / sigma^3
+// NHWC, HBM-bound.  K is an outer product and reflect padding acts per axis, so the blur is run as two 1-D passes
+// (F_h F_w) inside one kernel: a block owns a TH x TW pixel tile x CC channels, stages the (TH+k-1) x (TW+k-1) halo tile
+// in LDS once (reflect indexing applied while loading), blurs rows into a second LDS tile, then columns into the output --
+// 2k LDS taps per output instead of k^2 and exactly one HBM read + one write per element (plus the halo overlap).
+// Backward, one fused kernel (D = dy zero-extended, X = x reflect-extended, both staged in LDS):
+//   V  = F_h^T D   (vertical adjoint incl. the reflect fold: every padded row j that reflects onto y contributes)
+//   dx = F_w^T V
+//   U  = F_w X ;  dg_a = sum D[y,x] U[y+a,x]  +  sum V[y,x] X[y,x+a]      (2k block partials, reduced deterministically)
+//   dsigma = sum_j dp_j p_j t_j^2 / sigma^3,  dp = (dg - <dg,g>) / sum(p)
+// Lanes run along channels: all global accesses are contiguous channel segments, all LDS accesses conflict-free.
 #include "common.h"
 
 extern "C" size_t favae_colsum_workspace(int64_t M, int C);
@@ -20,7 +23,9 @@ struct BlurArgs {
     const float* x;
     const float* dy;
     const float* sigma;
-    float* out;       // y / dx / dK partials
+    float* y;         // forward output
+    float* dx;        // backward: may be null
+    float* part;      // backward: [blocks][2k] partials of dg, may be null
     int N, H, W, C, k, TH, TW, CC, tiles_h, tiles_w, cchunks;
 };
 
@@ -46,180 +51,188 @@ __device__ __forceinline__ void make_kernel1d(const float* sigma, int k, float* 
     }
 }
 
-// MODE 0: forward; MODE 1: dx adjoint; MODE 2: dK partials
-template <int MODE>
-__global__ __launch_bounds__(256) void blur_kernel(BlurArgs a) {
+// padded-domain positions that reflect onto image index i (1-D): i itself, -i, 2(n-1)-i
+__device__ __forceinline__ int preimages(int i, int n, int p, int (&j)[3]) {
+    int c = 0;
+    j[c++] = i;
+    if (i >= 1 && i <= p) j[c++] = -i;
+    if (i <= n - 2 && i >= n - 1 - p) j[c++] = 2 * (n - 1) - i;
+    return c;
+}
+
+template <int MODE>   // 0 forward, 1 backward
+__global__ __launch_bounds__(256) void blur_sep_kernel(BlurArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* g = sm;                         // [32]
-    float* red = sm + 32;                  // [4] cross-wave scratch (MODE 2)
-    float* halo = sm + 64;                 // [(TH+k-1)][(TW+k-1)][CC]
-    const int k = a.k, p = k / 2;
+    const int k = a.k, p = k / 2, CC = a.CC;
     const int HH = a.TH + k - 1, HW = a.TW + k - 1;
+    float* g = sm;                                   // [32]
+    float* red = sm + 32;                            // [2*MAXK][4] cross-wave partials (backward)
+    float* Xh = sm + 32 + 8 * MAXK;                  // [HH][HW][CC]  reflect-extended x
+    float* U = Xh + HH * HW * CC;                    // [HH][TW][CC]  row-blurred x
+    float* Dh = U + HH * a.TW * CC;                  // [HH][HW][CC]  zero-extended dy      (backward only)
+    float* V = Dh + HH * HW * CC;                    // [TH][HW][CC]  F_h^T dy              (backward only)
     int b = blockIdx.x;
     const int cchunk = b % a.cchunks; b /= a.cchunks;
     const int tw = b % a.tiles_w; b /= a.tiles_w;
     const int th = b % a.tiles_h;
     const int n = b / a.tiles_h;
-    const int y0 = th * a.TH, x0 = tw * a.TW, c0 = cchunk * a.CC;
-    const int CC = a.CC;
+    const int y0 = th * a.TH, x0 = tw * a.TW, c0 = cchunk * CC;
     const int tid = threadIdx.x;
+    const int c = tid % CC, pl = tid / CC, PL = 256 / CC;
+    const bool c_ok = c0 + c < a.C;
 
     make_kernel1d(a.sigma, k, g);
-    // ---- stage the halo tile ------------------------------------------------------------------------------------
-    const float* src = (MODE == 1) ? a.dy : a.x;
-    const float* img = src + (size_t)n * a.H * a.W * a.C;
-    const int total = HH * HW * CC;
-    for (int i = tid; i < total; i += 256) {
-        const int c = i % CC;
-        const int hx = (i / CC) % HW;
-        const int hy = i / (CC * HW);
-        int sy = y0 + hy - p, sx = x0 + hx - p;
-        float v = 0.f;
-        if (c0 + c < a.C) {
-            if (MODE == 1) {
-                if (sy >= 0 && sy < a.H && sx >= 0 && sx < a.W) v = img[((size_t)sy * a.W + sx) * a.C + c0 + c];
-            } else {
-                sy = reflect_idx(sy, a.H);
-                sx = reflect_idx(sx, a.W);
-                v = img[((size_t)sy * a.W + sx) * a.C + c0 + c];
+    // ---- stage halo tiles ---------------------------------------------------------------------------------------
+    {
+        const float* ximg = a.x + (size_t)n * a.H * a.W * a.C;
+        const float* dimg = MODE == 1 ? a.dy + (size_t)n * a.H * a.W * a.C : nullptr;
+        for (int q = pl; q < HH * HW; q += PL) {
+            const int hy = q / HW, hx = q - hy * HW;
+            const int sy = y0 + hy - p, sx = x0 + hx - p;
+            float xv = 0.f, dv = 0.f;
+            if (c_ok) {
+                xv = ximg[((size_t)reflect_idx(sy, a.H) * a.W + reflect_idx(sx, a.W)) * a.C + c0 + c];
+                if (MODE == 1 && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W) dv = dimg[((size_t)sy * a.W + sx) * a.C + c0 + c];
             }
+            Xh[q * CC + c] = xv;
+            if (MODE == 1) Dh[q * CC + c] = dv;
         }
-        halo[i] = v;
     }
     __syncthreads();
-
-    const int c = tid % CC, pl = tid / CC, PL = 256 / CC;
-    const bool c_ok = (c0 + c < a.C) && pl < PL;
+    // ---- pass 1: U = F_w X on every halo row; V = F_h^T D on every halo column ------------------------------------
+    if (MODE == 0 || a.part) {
+        for (int q = pl; q < HH * a.TW; q += PL) {
+            const int hy = q / a.TW, x = q - hy * a.TW;
+            const float* row = Xh + (hy * HW + x) * CC + c;
+            float acc = 0.f;
+            for (int v = 0; v < k; ++v) acc = fmaf(g[v], row[v * CC], acc);
+            U[q * CC + c] = acc;
+        }
+    }
+    if (MODE == 1) {
+        for (int q = pl; q < a.TH * HW; q += PL) {
+            const int yy = q / HW, hx = q - yy * HW;
+            const int y = y0 + yy;
+            float acc = 0.f;
+            if (y < a.H) {
+                int jy[3];
+                const int ny = preimages(y, a.H, p, jy);
+                for (int i = 0; i < ny; ++i)
+                    for (int u = 0; u < k; ++u) {
+                        const int ry = jy[i] + p - u;                     // dy row in image coordinates
+                        const int hy = ry - (y0 - p);
+                        if (ry < 0 || ry >= a.H || hy < 0 || hy >= HH) continue;
+                        acc = fmaf(g[u], Dh[(hy * HW + hx) * CC + c], acc);
+                    }
+            }
+            V[q * CC + c] = acc;
+        }
+    }
+    __syncthreads();
+    // ---- pass 2 ---------------------------------------------------------------------------------------------------
     const int npix = a.TH * a.TW;
-
     if (MODE == 0) {
         if (!c_ok) return;
-        float* out = a.out + (size_t)n * a.H * a.W * a.C;
+        float* out = a.y + (size_t)n * a.H * a.W * a.C;
         for (int q = pl; q < npix; q += PL) {
-            const int py = q / a.TW, px = q % a.TW;
+            const int py = q / a.TW, px = q - py * a.TW;
             if (y0 + py >= a.H || x0 + px >= a.W) continue;
+            const float* col = U + (py * a.TW + px) * CC + c;
             float acc = 0.f;
-            for (int u = 0; u < k; ++u) {
-                const float gu = g[u];
-                const float* row = halo + ((py + u) * HW + px) * CC + c;
-                for (int v = 0; v < k; ++v) acc = fmaf(gu * g[v], row[v * CC], acc);
-            }
+            for (int u = 0; u < k; ++u) acc = fmaf(g[u], col[u * a.TW * CC], acc);
             out[((size_t)(y0 + py) * a.W + x0 + px) * a.C + c0 + c] = acc;
         }
-    } else if (MODE == 1) {
-        if (!c_ok) return;
-        float* out = a.out + (size_t)n * a.H * a.W * a.C;
+        return;
+    }
+    if (a.dx && c_ok) {
+        float* out = a.dx + (size_t)n * a.H * a.W * a.C;
         for (int q = pl; q < npix; q += PL) {
-            const int py = q / a.TW, px = q % a.TW;
+            const int py = q / a.TW, px = q - py * a.TW;
             const int y = y0 + py, x = x0 + px;
             if (y >= a.H || x >= a.W) continue;
-            // padded-domain positions that reflect onto (y, x)
-            int jy[3], jx[3], ny = 0, nx = 0;
-            jy[ny++] = y;
-            if (y >= 1 && y <= p) jy[ny++] = -y;
-            if (y <= a.H - 2 && y >= a.H - 1 - p) jy[ny++] = 2 * (a.H - 1) - y;
-            jx[nx++] = x;
-            if (x >= 1 && x <= p) jx[nx++] = -x;
-            if (x <= a.W - 2 && x >= a.W - 1 - p) jx[nx++] = 2 * (a.W - 1) - x;
+            int jx[3];
+            const int nx = preimages(x, a.W, p, jx);
             float acc = 0.f;
-            for (int iy = 0; iy < ny; ++iy)
-                for (int ix = 0; ix < nx; ++ix) {
-                    for (int u = 0; u < k; ++u) {
-                        const int ry = jy[iy] + p - u;                   // dy row (image coords)
-                        if (ry < 0 || ry >= a.H) continue;
-                        const int hy = ry - (y0 - p);
-                        if (hy < 0 || hy >= HH) continue;
-                        const float gu = g[u];
-                        for (int v = 0; v < k; ++v) {
-                            const int rx = jx[ix] + p - v;
-                            if (rx < 0 || rx >= a.W) continue;
-                            const int hx = rx - (x0 - p);
-                            if (hx < 0 || hx >= HW) continue;
-                            acc = fmaf(gu * g[v], halo[(hy * HW + hx) * CC + c], acc);
-                        }
-                    }
+            for (int i = 0; i < nx; ++i)
+                for (int v = 0; v < k; ++v) {
+                    const int rx = jx[i] + p - v;
+                    const int hx = rx - (x0 - p);
+                    if (rx < 0 || rx >= a.W || hx < 0 || hx >= HW) continue;
+                    acc = fmaf(g[v], V[(py * HW + hx) * CC + c], acc);
                 }
             out[((size_t)y * a.W + x) * a.C + c0 + c] = acc;
         }
-    } else {
-        // dK[u][v] partial of this block: sum over its pixels/channels of dy * xpad
-        constexpr int MAXPIX = 16;
-        float dyv[MAXPIX];
-        const float* dimg = a.dy + (size_t)n * a.H * a.W * a.C;
-        int cnt = 0;
-        for (int q = pl; q < npix && cnt < MAXPIX; q += PL, ++cnt) {
-            const int py = q / a.TW, px = q % a.TW;
-            const bool ok = c_ok && (y0 + py < a.H) && (x0 + px < a.W);
-            dyv[cnt] = ok ? dimg[((size_t)(y0 + py) * a.W + x0 + px) * a.C + c0 + c] : 0.f;
-        }
-        float* out = a.out + (size_t)blockIdx.x * (k * k);
+    }
+    if (a.part) {
         const int lane = tid & 63, wid = tid >> 6;
-        for (int u = 0; u < k; ++u)
-            for (int v = 0; v < k; ++v) {
-                float acc = 0.f;
-                if (c_ok) {
-                    int i = 0;
-                    for (int q = pl; q < npix && i < MAXPIX; q += PL, ++i) {
-                        const int py = q / a.TW, px = q % a.TW;
-                        acc = fmaf(dyv[i], halo[((py + u) * HW + px + v) * CC + c], acc);
-                    }
+        for (int t = 0; t < k; ++t) {
+            float ah = 0.f, aw = 0.f;
+            if (c_ok) {
+                for (int q = pl; q < npix; q += PL) {
+                    const int py = q / a.TW, px = q - py * a.TW;
+                    if (y0 + py >= a.H || x0 + px >= a.W) continue;
+                    ah = fmaf(Dh[((py + p) * HW + px + p) * CC + c], U[((py + t) * a.TW + px) * CC + c], ah);
+                    aw = fmaf(V[(py * HW + px + p) * CC + c], Xh[((py + p) * HW + px + t) * CC + c], aw);
                 }
-                acc = wave_sum(acc);
-                __syncthreads();
-                if (lane == 0) red[wid] = acc;
-                __syncthreads();
-                if (tid == 0) out[u * k + v] = (red[0] + red[1]) + (red[2] + red[3]);
             }
+            ah = wave_sum(ah);
+            aw = wave_sum(aw);
+            if (lane == 0) red[t * 4 + wid] = ah + aw;
+        }
+        __syncthreads();
+        if (tid < k) a.part[(size_t)blockIdx.x * k + tid] = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
     }
 }
 
-// dK (k*k floats, already summed over blocks) -> dsigma
-__global__ void blur_dsigma_kernel(const float* dK, const float* sigma, int k, float* dsigma) {
+// dg (k floats, summed over blocks) -> dsigma
+__global__ void blur_dsigma_kernel(const float* dgv, const float* sigma, int k, float* dsigma) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double s = sigma[0];
     const double half = (k - 1) * 0.5;
-    double pz[MAXK], g[MAXK], dg[MAXK];
-    double S = 0.0;
+    double S = 0.0, dot = 0.0;
     for (int j = 0; j < k; ++j) {
         const double t = j - half;
-        pz[j] = exp(-0.5 * (t / s) * (t / s));
-        S += pz[j];
+        S += exp(-0.5 * (t / s) * (t / s));
     }
-    for (int j = 0; j < k; ++j) g[j] = pz[j] / S;
-    double dot = 0.0;
-    for (int u = 0; u < k; ++u) {
-        double acc = 0.0;
-        for (int v = 0; v < k; ++v) acc += ((double)dK[u * k + v] + (double)dK[v * k + u]) * g[v];
-        dg[u] = acc;
-        dot += acc * g[u];
+    for (int j = 0; j < k; ++j) {
+        const double t = j - half;
+        dot += (double)dgv[j] * exp(-0.5 * (t / s) * (t / s)) / S;
     }
     double ds = 0.0;
     for (int j = 0; j < k; ++j) {
         const double t = j - half;
-        const double dp = (dg[j] - dot) / S;
-        ds += dp * pz[j] * t * t / (s * s * s);
+        const double pj = exp(-0.5 * (t / s) * (t / s));
+        ds += ((double)dgv[j] - dot) / S * pj * t * t / (s * s * s);
     }
     dsigma[0] = (float)ds;
 }
 
-void plan(int ksize, int N, int H, int W, int C, BlurArgs& a) {
-    a.N = N; a.H = H; a.W = W; a.C = C; a.k = ksize;
-    a.CC = C >= 32 ? 32 : (C >= 16 ? 16 : (C >= 8 ? 8 : 4));
-    const int PL = 256 / a.CC;                 // pixel lanes
-    // 16 pixels per thread
-    int npix = 16 * PL;                        // 128 @CC=32, 256 @16, 512 @8, 1024 @4
-    a.TW = 16;
-    a.TH = npix / a.TW;
-    if (ksize > 9 && a.TH > 8) a.TH = 8;
-    while (a.TH > 8 && a.TH / 2 >= H) a.TH /= 2;
-    if (a.TH > 32) a.TH = 32;
-    a.tiles_h = (H + a.TH - 1) / a.TH;
-    a.tiles_w = (W + a.TW - 1) / a.TW;
-    a.cchunks = (C + a.CC - 1) / a.CC;
+size_t shm_floats(const BlurArgs& a, bool bwd) {
+    const size_t HH = a.TH + a.k - 1, HW = a.TW + a.k - 1;
+    size_t f = 32 + 8 * MAXK + HH * HW * a.CC + HH * a.TW * a.CC;
+    if (bwd) f += HH * HW * a.CC + (size_t)a.TH * HW * a.CC;
+    return f;
 }
 
-size_t shm_bytes(const BlurArgs& a) {
-    return (size_t)(64 + (a.TH + a.k - 1) * (a.TW + a.k - 1) * a.CC) * sizeof(float);
+bool plan(int ksize, int N, int H, int W, int C, bool bwd, BlurArgs& a) {
+    a.N = N; a.H = H; a.W = W; a.C = C; a.k = ksize;
+    const int ccs[3] = {16, 8, 4};
+    const int tiles[4][2] = {{16, 16}, {8, 16}, {8, 8}, {4, 8}};
+    const size_t budget = (bwd ? 80 : 64) * 1024 / 4;          // floats: keeps >= 2 blocks per CU
+    for (int relax = 0; relax < 2; ++relax)
+        for (int ci = 0; ci < 3; ++ci)                          // prefer wide channel chunks (coalescing), then big tiles
+            for (int ti = 0; ti < 4; ++ti) {
+                a.CC = ccs[ci];
+                if (a.CC > 4 && a.CC / 2 >= C) continue;          // do not waste lanes on tiny channel counts
+                a.TH = tiles[ti][0]; a.TW = tiles[ti][1];
+                if (shm_floats(a, bwd) <= (relax ? (size_t)38000 : budget)) {
+                    a.tiles_h = (H + a.TH - 1) / a.TH;
+                    a.tiles_w = (W + a.TW - 1) / a.TW;
+                    a.cchunks = (C + a.CC - 1) / a.CC;
+                    return true;
+                }
+            }
+    return false;
 }
 
 bool blur_ok(int ksize, int N, int H, int W, int C) {
@@ -231,63 +244,52 @@ bool blur_ok(int ksize, int N, int H, int W, int C) {
 extern "C" int favae_blur_fwd(const float* x, const float* sigma, int ksize, int N, int H, int W, int C, float* y,
                               favae_stream_t stream) {
     FAVAE_REQUIRE(x && sigma && y && blur_ok(ksize, N, H, W, C));
-    BlurArgs a;
-    plan(ksize, N, H, W, C, a);
-    a.x = x; a.dy = nullptr; a.sigma = sigma; a.out = y;
-    const size_t shm = shm_bytes(a);
-    if (shm > 160 * 1024) return FAVAE_ERR_UNSUPPORTED;
+    BlurArgs a{};
+    if (!plan(ksize, N, H, W, C, false, a)) return FAVAE_ERR_UNSUPPORTED;
+    a.x = x; a.sigma = sigma; a.y = y;
+    const size_t shm = shm_floats(a, false) * sizeof(float);
     static bool attr0 = false;
-    if (!attr0) { (void)hipFuncSetAttribute((const void*)blur_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr0 = true; }
-    const int grid = N * a.tiles_h * a.tiles_w * a.cchunks;
-    hipLaunchKernelGGL((blur_kernel<0>), dim3(grid), dim3(256), shm, (hipStream_t)stream, a);
+    if (!attr0) { (void)hipFuncSetAttribute((const void*)blur_sep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr0 = true; }
+    const long grid = (long)N * a.tiles_h * a.tiles_w * a.cchunks;
+    if (grid >= (1L << 31)) return FAVAE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((blur_sep_kernel<0>), dim3((unsigned)grid), dim3(256), shm, (hipStream_t)stream, a);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
 
 extern "C" size_t favae_blur_bwd_workspace(int ksize, int N, int H, int W, int C) {
     if (!blur_ok(ksize, N, H, W, C)) return 0;
-    BlurArgs a;
-    plan(ksize, N, H, W, C, a);
+    BlurArgs a{};
+    if (!plan(ksize, N, H, W, C, true, a)) return 0;
     const size_t blocks = (size_t)N * a.tiles_h * a.tiles_w * a.cchunks;
-    const size_t kk = (size_t)ksize * ksize;
-    return blocks * kk * sizeof(float) + favae_colsum_workspace((int64_t)blocks, (int)kk) + kk * sizeof(float) + 256;
+    return blocks * ksize * sizeof(float) + favae_colsum_workspace((int64_t)blocks, ksize) + MAXK * sizeof(float) + 512;
 }
 
 extern "C" int favae_blur_bwd(const float* x, const float* dy, const float* sigma, int ksize, int N, int H, int W, int C,
                               float* dx, float* dsigma, void* ws, size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(x && dy && sigma && ws && blur_ok(ksize, N, H, W, C));
     FAVAE_REQUIRE(dx || dsigma);
+    BlurArgs a{};
+    if (!plan(ksize, N, H, W, C, true, a)) return FAVAE_ERR_UNSUPPORTED;
     if (ws_bytes < favae_blur_bwd_workspace(ksize, N, H, W, C)) return FAVAE_ERR_WORKSPACE;
-    BlurArgs a;
-    plan(ksize, N, H, W, C, a);
-    a.x = x; a.dy = dy; a.sigma = sigma;
-    const size_t shm = shm_bytes(a);
-    if (shm > 160 * 1024) return FAVAE_ERR_UNSUPPORTED;
+    const long grid = (long)N * a.tiles_h * a.tiles_w * a.cchunks;
+    if (grid >= (1L << 31)) return FAVAE_ERR_UNSUPPORTED;
+    float* part = (float*)ws;
+    char* p2 = (char*)ws + (((size_t)grid * ksize * sizeof(float) + 255) / 256) * 256;
+    const size_t cws = favae_colsum_workspace(grid, ksize);
+    float* dgv = (float*)(p2 + ((cws + 255) / 256) * 256);
+    if ((char*)(dgv + ksize) > (char*)ws + ws_bytes) return FAVAE_ERR_WORKSPACE;
+    a.x = x; a.dy = dy; a.sigma = sigma; a.dx = dx; a.part = dsigma ? part : nullptr;
+    const size_t shm = shm_floats(a, true) * sizeof(float);
     static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)blur_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)blur_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)blur_sep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     hipStream_t s = (hipStream_t)stream;
-    const int grid = N * a.tiles_h * a.tiles_w * a.cchunks;
-    if (dx) {
-        a.out = dx;
-        hipLaunchKernelGGL((blur_kernel<1>), dim3(grid), dim3(256), shm, s, a);
-        FAVAE_CHECK_LAUNCH();
-    }
+    hipLaunchKernelGGL((blur_sep_kernel<1>), dim3((unsigned)grid), dim3(256), shm, s, a);
+    FAVAE_CHECK_LAUNCH();
     if (dsigma) {
-        const int kk = ksize * ksize;
-        float* part = (float*)ws;
-        char* p2 = (char*)ws + (size_t)grid * kk * sizeof(float);
-        const size_t cws = favae_colsum_workspace(grid, kk);
-        float* dK = (float*)(p2 + cws);
-        a.out = part;
-        hipLaunchKernelGGL((blur_kernel<2>), dim3(grid), dim3(256), shm, s, a);
-        FAVAE_CHECK_LAUNCH();
-        int rc = favae_colsum(part, dK, grid, kk, p2, cws, stream);
+        int rc = favae_colsum(part, dgv, grid, ksize, p2, cws, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(blur_dsigma_kernel, dim3(1), dim3(64), 0, s, (const float*)dK, sigma, ksize, dsigma);
+        hipLaunchKernelGGL(blur_dsigma_kernel, dim3(1), dim3(64), 0, s, (const float*)dgv, sigma, ksize, dsigma);
         FAVAE_CHECK_LAUNCH();
     }
     return FAVAE_OK;

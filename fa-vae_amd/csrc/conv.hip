@@ -17,8 +17,17 @@
 //   double-buffered through LDS so that the loads of step i+1 are in flight during the MFMAs of step i.
 //   blockIdx is remapped XCD-aware: tiles that share input rows / halos land on the same XCD's L2.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
+
+// debugging / A-B switch: FAVAE_CONV_GENERIC=1 forces the generic (runtime-predicated) kernels
+bool force_generic() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FAVAE_CONV_GENERIC"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 
 constexpr int BM = 128;
 constexpr int BK = 16;
@@ -416,6 +425,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
 }
 
+#include "conv_fast.h"
+
 __global__ void reduce_slabs_kernel(const float* part, float* out, size_t n, int slabs) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -524,16 +535,27 @@ extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const fl
     a.vec = (d->Cin % 4 == 0) ? 1 : 0;
     a.tiles_m = cdiv(a.M, BM);
     hipStream_t s = (hipStream_t)stream;
-    if (d->Cout > 64) {
-        a.tiles_n = cdiv(d->Cout, 128);
-        hipLaunchKernelGGL((conv_fwd_kernel<128, 2, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
-    } else if (d->Cout > 32) {
-        a.tiles_n = 1;
-        hipLaunchKernelGGL((conv_fwd_kernel<64, 2, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+    const int bn = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
+    a.tiles_n = cdiv(d->Cout, bn);
+    const dim3 grid(a.tiles_m * a.tiles_n), blk(256);
+#define FAVAE_LAUNCH_FWD(G)                                                                                        \
+    do {                                                                                                           \
+        if (bn == 128) hipLaunchKernelGGL((conv_fwd_fast_kernel<128, 2, 2, G>), grid, blk, 0, s, a);               \
+        else if (bn == 64) hipLaunchKernelGGL((conv_fwd_fast_kernel<64, 2, 2, G>), grid, blk, 0, s, a);            \
+        else hipLaunchKernelGGL((conv_fwd_fast_kernel<32, 4, 1, G>), grid, blk, 0, s, a);                          \
+    } while (0)
+    if (a.vec && !force_generic()) {
+        if (d->gather == FAVAE_GATHER_PLAIN) FAVAE_LAUNCH_FWD(FAVAE_GATHER_PLAIN);
+        else if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_FWD(FAVAE_GATHER_UPSAMPLE2);
+        else FAVAE_LAUNCH_FWD(FAVAE_GATHER_DILATE2);
+    } else if (bn == 128) {
+        hipLaunchKernelGGL((conv_fwd_kernel<128, 2, 2>), grid, blk, 0, s, a);
+    } else if (bn == 64) {
+        hipLaunchKernelGGL((conv_fwd_kernel<64, 2, 2>), grid, blk, 0, s, a);
     } else {
-        a.tiles_n = 1;
-        hipLaunchKernelGGL((conv_fwd_kernel<32, 4, 1>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_fwd_kernel<32, 4, 1>), grid, blk, 0, s, a);
     }
+#undef FAVAE_LAUNCH_FWD
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -569,12 +591,23 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     a.vec_o = (d->Cout % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(tiles, a.splitk);
-    if (bco == 128 && bci == 128)
+#define FAVAE_LAUNCH_WGRAD(G)                                                                                      \
+    do {                                                                                                           \
+        if (bco == 128 && bci == 128) hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 128, 2, 2, G>), grid, dim3(256), 0, s, a); \
+        else if (bco == 32) hipLaunchKernelGGL((conv_wgrad_fast_kernel<32, 128, 1, 4, G>), grid, dim3(256), 0, s, a);            \
+        else hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 32, 4, 1, G>), grid, dim3(256), 0, s, a);                           \
+    } while (0)
+    if (a.vec_i && a.vec_o && !force_generic()) {
+        if (d->gather == FAVAE_GATHER_PLAIN) FAVAE_LAUNCH_WGRAD(FAVAE_GATHER_PLAIN);
+        else if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_WGRAD(FAVAE_GATHER_UPSAMPLE2);
+        else FAVAE_LAUNCH_WGRAD(FAVAE_GATHER_DILATE2);
+    } else if (bco == 128 && bci == 128)
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
     else if (bco == 32)
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, a);
+#undef FAVAE_LAUNCH_WGRAD
     FAVAE_CHECK_LAUNCH();
     const size_t n = (size_t)d->Cout * d->KH * d->KW * d->Cin;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, dw, n, a.splitk);

@@ -9,114 +9,137 @@
 //           dx = rstd * (dy*gamma - k1 - xhat*k2) (+ dx_add)                                                (pass 2)
 // Accumulation is in fp64 (cheap next to the HBM traffic) so E[x^2]-mean^2 does not cancel.
 // Layout of the work: a block owns a contiguous range of pixels of ONE image and all C channels; lanes run along the
-// channel dimension (16-byte loads when C % 4 == 0), so every global access is a full contiguous row segment.
+// channel dimension with 16-byte loads (C % 4 == 0), so every global access is a full contiguous row segment.
 #include "common.h"
 
 namespace {
 
 __device__ __forceinline__ float act_grad(float y, int act) {
     if (act == FAVAE_ACT_SILU) {
-        const float s = 1.0f / (1.0f + __expf(-y));
+        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
         return s * (1.0f + y * (1.0f - s));
     }
     if (act == FAVAE_ACT_LEAKY02) return y > 0.f ? 1.0f : 0.2f;
     return 1.0f;
 }
 
-// partial[n][split][c][2] (double): sum, sumsq of x        (MODE 0)
-//                                   S1, S2 of the backward (MODE 1)
-template <int MODE>
+// part[n][split][c][2] (double): MODE 0: sum x, sum x^2 ; MODE 1: S1, S2 of the backward.
+// VEC: thread = (channel quad, row lane); otherwise thread = (channel, row lane); C > 256*V loops over channel blocks.
+template <int MODE, int V>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ da,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          double* __restrict__ part, long HW, int C, int G, int act,
                                                          long rows_per_block) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];     // [rl][C][2]
+    extern __shared__ __attribute__((aligned(16))) double sm[];     // [RL][Q][2*V]
     const int n = blockIdx.y, split = blockIdx.x, S = gridDim.x;
-    const int cols = C;                               // one thread per channel, rl row-lanes
-    const int rl = max(1, 256 / cols);
+    const int QT = C / V;                                           // column items in total
+    const int Q = QT < 256 ? QT : 256;                              // column items per pass
+    const int RL = 256 / Q;
+    const int qi = threadIdx.x % Q, li = threadIdx.x / Q;
     const long r0 = (long)split * rows_per_block;
     const long r1 = min(HW, r0 + rows_per_block);
     const int cpg = C / G;
-    for (int cb = 0; cb < C; cb += 256) {             // channel blocks (C > 256 loops)
-        const int c = cb + (threadIdx.x % min(cols, 256));
-        const int lanei = threadIdx.x / min(cols, 256);
-        double s1 = 0.0, s2 = 0.0;
-        if (c < C && lanei < rl) {
-            float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f;
+    for (int qb = 0; qb < QT; qb += Q) {
+        const int c = (qb + qi) * V;
+        const bool on = (qb + qi) < QT && li < RL;
+        double s1[V], s2[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { s1[e] = 0.0; s2[e] = 0.0; }
+        if (on) {
+            float mu[V], rs[V], ga[V], be[V];
             if (MODE == 1) {
-                mu = mean[n * G + c / cpg];
-                rs = rstd[n * G + c / cpg];
-                ga = gamma[c];
-                be = beta[c];
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    mu[e] = mean[n * G + (c + e) / cpg];
+                    rs[e] = rstd[n * G + (c + e) / cpg];
+                    ga[e] = gamma[c + e];
+                    be[e] = beta[c + e];
+                }
             }
             const float* xp = x + ((size_t)n * HW) * C + c;
             const float* dp = MODE == 1 ? da + ((size_t)n * HW) * C + c : nullptr;
-            for (long r = r0 + lanei; r < r1; r += rl) {
-                const float xv = xp[r * C];
-                if (MODE == 0) {
-                    s1 += (double)xv;
-                    s2 += (double)xv * (double)xv;
+            for (long r = r0 + li; r < r1; r += RL) {
+                float xv[V], dv[V];
+                if (V == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(xp + r * C);
+                    xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                    if (MODE == 1) {
+                        const float4 d = *reinterpret_cast<const float4*>(dp + r * C);
+                        dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
+                    }
                 } else {
-                    const float xh = (xv - mu) * rs;
-                    const float y = fmaf(xh, ga, be);
-                    const float dy = dp[r * C] * act_grad(y, act);
-                    s1 += (double)dy;
-                    s2 += (double)dy * (double)xh;
+                    xv[0] = xp[r * C];
+                    if (MODE == 1) dv[0] = dp[r * C];
+                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    if (MODE == 0) {
+                        s1[e] += (double)xv[e];
+                        s2[e] += (double)xv[e] * (double)xv[e];
+                    } else {
+                        const float xh = (xv[e] - mu[e]) * rs[e];
+                        const float y = fmaf(xh, ga[e], be[e]);
+                        const float dy = dv[e] * act_grad(y, act);
+                        s1[e] += (double)dy;
+                        s2[e] += (double)dy * (double)xh;
+                    }
                 }
             }
-        }
-        // reduce the rl row-lanes through LDS
-        const int ccount = min(cols, 256);
-        if (lanei < rl && c < C) {
-            sm[(lanei * ccount + (c - cb)) * 2 + 0] = s1;
-            sm[(lanei * ccount + (c - cb)) * 2 + 1] = s2;
+            double* o = sm + ((size_t)li * Q + qi) * 2 * V;
+#pragma unroll
+            for (int e = 0; e < V; ++e) { o[2 * e] = s1[e]; o[2 * e + 1] = s2[e]; }
         }
         __syncthreads();
-        if (lanei == 0 && c < C) {
-            for (int l = 1; l < rl; ++l) {
-                s1 += sm[(l * ccount + (c - cb)) * 2 + 0];
-                s2 += sm[(l * ccount + (c - cb)) * 2 + 1];
+        if (on && li == 0) {
+            for (int l = 1; l < RL; ++l) {
+                const double* o = sm + ((size_t)l * Q + qi) * 2 * V;
+#pragma unroll
+                for (int e = 0; e < V; ++e) { s1[e] += o[2 * e]; s2[e] += o[2 * e + 1]; }
             }
-            double* o = part + (((size_t)n * S + split) * C + c) * 2;
-            o[0] = s1;
-            o[1] = s2;
+            double* out = part + (((size_t)n * S + split) * C + c) * 2;
+#pragma unroll
+            for (int e = 0; e < V; ++e) { out[2 * e] = s1[e]; out[2 * e + 1] = s2[e]; }
         }
         __syncthreads();
     }
 }
 
-// one block per (n): finalise group statistics and the per-channel affine
+// one block per image: sum the splits per channel -> acc[n][c][2] (double), then group statistics + per-channel affine
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ mean,
                                                           float* __restrict__ rstd, float* __restrict__ scale,
-                                                          float* __restrict__ shift, long HW, int C, int G, int S, float eps) {
+                                                          float* __restrict__ shift, double* __restrict__ acc, long HW, int C,
+                                                          int G, int S, float eps) {
     const int n = blockIdx.x;
     const int cpg = C / G;
-    __shared__ float s_mean[1024], s_rstd[1024];
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    double* a = acc + (size_t)n * C * 2;
+    for (int c = threadIdx.x; c < C; c += 256) {
         double s1 = 0.0, s2 = 0.0;
-        for (int s = 0; s < S; ++s)
-            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-                const double* p = part + (((size_t)n * S + s) * C + c) * 2;
-                s1 += p[0];
-                s2 += p[1];
-            }
+        for (int s = 0; s < S; ++s) {
+            const double* p = part + (((size_t)n * S + s) * C + c) * 2;
+            s1 += p[0];
+            s2 += p[1];
+        }
+        a[2 * c] = s1;
+        a[2 * c + 1] = s2;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s1 += a[2 * c]; s2 += a[2 * c + 1]; }
         const double cnt = (double)cpg * (double)HW;
         const double mu = s1 / cnt;
         double var = s2 / cnt - mu * mu;
         if (var < 0.0) var = 0.0;
-        const float rs = (float)(1.0 / sqrt(var + (double)eps));
         mean[n * G + g] = (float)mu;
-        rstd[n * G + g] = rs;
-        if (g < 1024) { s_mean[g] = (float)mu; s_rstd[g] = rs; }
+        rstd[n * G + g] = (float)(1.0 / sqrt(var + (double)eps));
     }
     __syncthreads();
     if (scale) {
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        for (int c = threadIdx.x; c < C; c += 256) {
             const int g = c / cpg;
-            const float mu = (g < 1024) ? s_mean[g] : mean[n * G + g];
-            const float rs = (g < 1024) ? s_rstd[g] : rstd[n * G + g];
+            const float mu = mean[n * G + g], rs = rstd[n * G + g];
             const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
             const float sc = rs * ga;
             scale[(size_t)n * C + c] = sc;
@@ -125,43 +148,48 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     }
 }
 
-// one block: k1/k2 per (n,g), dgamma/dbeta per channel.  part = [N][S][C][2]
+// backward, one block per image: acc[n][c] = sum over splits of (S1,S2); k1/k2 per group
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
                                                               float* __restrict__ k1, float* __restrict__ k2,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int N,
-                                                              long HW, int C, int G, int S) {
+                                                              double* __restrict__ acc, long HW, int C, int G, int S) {
+    const int n = blockIdx.x;
     const int cpg = C / G;
-    // per-(n,g) means
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * G; i += gridDim.x * blockDim.x) {
-        const int n = i / G, g = i % G;
-        double a = 0.0, b = 0.0;
+    double* a = acc + (size_t)n * C * 2;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int s = 0; s < S; ++s) {
+            const double* p = part + (((size_t)n * S + s) * C + c) * 2;
+            s1 += p[0];
+            s2 += p[1];
+        }
+        a[2 * c] = s1;
+        a[2 * c + 1] = s2;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += 256) {
+        double u = 0.0, v = 0.0;
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int s = 0; s < S; ++s) {
-                const double* p = part + (((size_t)n * S + s) * C + c) * 2;
-                s1 += p[0];
-                s2 += p[1];
-            }
-            a += (double)gamma[c] * s1;
-            b += (double)gamma[c] * s2;
+            u += (double)gamma[c] * a[2 * c];
+            v += (double)gamma[c] * a[2 * c + 1];
         }
         const double cnt = (double)cpg * (double)HW;
-        k1[i] = (float)(a / cnt);
-        k2[i] = (float)(b / cnt);
+        k1[n * G + g] = (float)(u / cnt);
+        k2[n * G + g] = (float)(v / cnt);
     }
-    if (dgamma) {
-        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int n = 0; n < N; ++n)
-                for (int s = 0; s < S; ++s) {
-                    const double* p = part + (((size_t)n * S + s) * C + c) * 2;
-                    s1 += p[0];
-                    s2 += p[1];
-                }
-            dbeta[c] = (float)s1;
-            dgamma[c] = (float)s2;
-        }
+}
+
+// dgamma[c] = sum_n S2[n][c], dbeta[c] = sum_n S1[n][c]
+__global__ __launch_bounds__(256) void gn_param_grad_kernel(const double* __restrict__ acc, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int N, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < N; ++n) {
+        s1 += acc[((size_t)n * C + c) * 2];
+        s2 += acc[((size_t)n * C + c) * 2 + 1];
     }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
 }
 
 // dx = rstd * (dy*gamma - k1 - xhat*k2) + dx_add ; grid-stride over float4 (VEC) or scalars
@@ -224,20 +252,40 @@ __global__ void bn_update_running_kernel(const float* mean, const float* rstd, i
 }
 
 int gn_splits(int N, long HW) {
-    long s = (HW + 255) / 256;            // >= 256 pixels per block
-    long cap = (2048 + N - 1) / N;        // ~2048 blocks in total
+    long s = (HW + 1023) / 1024;          // >= 1024 pixels per block
+    long cap = (1024 + N - 1) / N;        // ~1024 blocks in total
     if (s > cap) s = cap;
     if (s < 1) s = 1;
     return (int)s;
 }
 
 size_t part_bytes(int N, long HW, int C) { return (size_t)N * gn_splits(N, HW) * C * 2 * sizeof(double); }
+size_t acc_bytes(int N, int C) { return (size_t)N * C * 2 * sizeof(double); }
+
+template <int MODE>
+void launch_partial(const float* x, const float* da, const float* gamma, const float* beta, const float* mean,
+                    const float* rstd, double* part, int N, long HW, int C, int G, int act, hipStream_t s) {
+    const int S = gn_splits(N, HW);
+    const long rpb = (HW + S - 1) / S;
+    const bool vec = (C % 4 == 0) && ((((uintptr_t)x) & 15) == 0) && (MODE == 0 || (((uintptr_t)da) & 15) == 0);
+    if (vec) {
+        const int QT = C / 4, Q = QT < 256 ? QT : 256, RL = 256 / Q;
+        const size_t shm = (size_t)RL * Q * 8 * sizeof(double);
+        hipLaunchKernelGGL((gn_partial_kernel<MODE, 4>), dim3(S, N), dim3(256), shm, s, x, da, gamma, beta, mean, rstd, part, HW, C,
+                           G, act, rpb);
+    } else {
+        const int Q = C < 256 ? C : 256, RL = 256 / Q;
+        const size_t shm = (size_t)RL * Q * 2 * sizeof(double);
+        hipLaunchKernelGGL((gn_partial_kernel<MODE, 1>), dim3(S, N), dim3(256), shm, s, x, da, gamma, beta, mean, rstd, part, HW, C,
+                           G, act, rpb);
+    }
+}
 
 }  // namespace
 
 extern "C" size_t favae_gn_workspace(int N, int64_t HW, int C) {
-    // partial sums + k1/k2 (N*C floats upper bound each)
-    return part_bytes(N, HW, C) + 2 * (size_t)N * C * sizeof(float) + 256;
+    // split partials + per-(n,c) accumulators + k1/k2 (N*C floats upper bound each)
+    return part_bytes(N, HW, C) + acc_bytes(N, C) + 2 * (size_t)N * C * sizeof(float) + 512;
 }
 
 extern "C" int favae_gn_stats(const float* x, const float* gamma, const float* beta, int N, int64_t HW, int C, int G,
@@ -246,17 +294,13 @@ extern "C" int favae_gn_stats(const float* x, const float* gamma, const float* b
     FAVAE_REQUIRE(x && mean && rstd && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     if (ws_bytes < favae_gn_workspace(N, HW, C)) return FAVAE_ERR_WORKSPACE;
-    const int S = gn_splits(N, HW);
-    const long rpb = (HW + S - 1) / S;
     hipStream_t s = (hipStream_t)stream;
-    const int ccount = C < 256 ? C : 256;
-    const int rl = 256 / ccount > 0 ? 256 / ccount : 1;
-    const size_t shm = (size_t)rl * ccount * 2 * sizeof(double);
-    hipLaunchKernelGGL((gn_partial_kernel<0>), dim3(S, N), dim3(256), shm, s, x, (const float*)nullptr, gamma, beta,
-                       (const float*)nullptr, (const float*)nullptr, (double*)ws, (long)HW, C, G, 0, rpb);
+    double* part = (double*)ws;
+    double* acc = (double*)((char*)ws + part_bytes(N, HW, C));
+    launch_partial<0>(x, nullptr, gamma, beta, nullptr, nullptr, part, N, (long)HW, C, G, 0, s);
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, (const double*)ws, gamma, beta, mean, rstd, scale, shift,
-                       (long)HW, C, G, S, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
+                       acc, (long)HW, C, G, gn_splits(N, HW), eps);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -267,24 +311,23 @@ extern "C" int favae_gn_act_bwd(const float* da, const float* x, const float* ga
     FAVAE_REQUIRE(da && x && gamma && beta && mean && rstd && dx && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
     FAVAE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr));
     if (ws_bytes < favae_gn_workspace(N, HW, C)) return FAVAE_ERR_WORKSPACE;
-    const int S = gn_splits(N, HW);
-    const long rpb = (HW + S - 1) / S;
     hipStream_t s = (hipStream_t)stream;
     double* part = (double*)ws;
-    float* k1 = (float*)((char*)ws + part_bytes(N, HW, C));
+    double* acc = (double*)((char*)ws + part_bytes(N, HW, C));
+    float* k1 = (float*)((char*)acc + acc_bytes(N, C));
     float* k2 = k1 + (size_t)N * C;
-    const int ccount = C < 256 ? C : 256;
-    const int rl = 256 / ccount > 0 ? 256 / ccount : 1;
-    const size_t shm = (size_t)rl * ccount * 2 * sizeof(double);
-    hipLaunchKernelGGL((gn_partial_kernel<1>), dim3(S, N), dim3(256), shm, s, x, da, gamma, beta, mean, rstd, part, (long)HW,
-                       C, G, act, rpb);
+    launch_partial<1>(x, da, gamma, beta, mean, rstd, part, N, (long)HW, C, G, act, s);
     FAVAE_CHECK_LAUNCH();
-    const int work = (N * G > C ? N * G : C);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(work, 256)), dim3(256), 0, s, (const double*)part, gamma, k1, k2,
-                       dgamma, dbeta, N, (long)HW, C, G, S);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, s, (const double*)part, gamma, k1, k2, acc, (long)HW, C, G,
+                       gn_splits(N, HW));
     FAVAE_CHECK_LAUNCH();
+    if (dgamma) {
+        hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)acc, dgamma, dbeta, N, C);
+        FAVAE_CHECK_LAUNCH();
+    }
     const size_t total = (size_t)N * HW * C;
-    if (C % 4 == 0) {
+    const bool vec = (C % 4 == 0) && (((((uintptr_t)da) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)dx_add)) & 15) == 0);
+    if (vec) {
         int blocks = (int)((total / 4 + 255) / 256);
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL((gn_bwd_apply_kernel<true>), dim3(blocks), dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2,
