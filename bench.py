@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--codebook", type=int, default=16384)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=1, help="images in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-batch", type=int, default=8, help="images in the bounded CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -75,20 +75,30 @@ class ConvEventHook:
                 "tflops": 1e-12 * tot_fl / (1e-3 * tot_ms), "total_ms": tot_ms}
 
 
+def usable_cores(torch):
+    """CPU cores this process may really use: min(affinity, cgroup cpu.max quota, torch's default pool size)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, torch.get_num_threads()))
+
+
 def cpu_baseline(args, torch):
     import favae_oracle as O
-    try:
-        ncores = len(os.sched_getaffinity(0))        # cores this process may actually use (cgroup/affinity aware)
-    except AttributeError:
-        ncores = os.cpu_count() or 1
-    ncores = max(1, min(ncores, torch.get_num_threads()))
+    ncores = usable_cores(torch)
     torch.set_num_threads(ncores)
     cfg = O.OracleConfig(codebook_size=args.codebook, variant="gauss_resblock", kernel_size=9)
     sc = O.StepConfig(lr=4.5e-6 * args.batch, with_disc_forward=True)
     tr = O.OracleTrainer(cfg, sc)
     B = args.cpu_batch
-    x = O.det_input(B, args.res, args.res, 1234)
-    tr.step(x)                                   # untimed: thread-pool / allocator warm-up
+    tr.step(O.det_input(1, args.res, args.res, 1234))      # untimed batch-1 step: thread-pool / allocator warm-up
     t0 = time.perf_counter()
     tr.step(O.det_input(B, args.res, args.res, 1235))
     dt = time.perf_counter() - t0
