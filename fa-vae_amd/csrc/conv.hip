@@ -27,6 +27,12 @@ bool force_generic() {
     if (v < 0) { const char* e = getenv("FAVAE_CONV_GENERIC"); v = (e && e[0] == '1') ? 1 : 0; }
     return v == 1;
 }
+// FAVAE_CONV_NOBUF=1 disables the buffer-addressed kernels (A/B against the flat-addressed fast kernels)
+bool force_nobuf() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FAVAE_CONV_NOBUF"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
 
 
 constexpr int BM = 128;
@@ -47,6 +53,7 @@ struct ConvArgs {
     int tiles_m, tiles_n;
     int kchunks;      // ceil(Cin/BK)
     int vec;          // Cin % 4 == 0 (16-byte channel loads legal)
+    unsigned x_bytes, w_bytes, aff_bytes;   // operand sizes for the buffer-addressed kernels
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -256,6 +263,7 @@ struct WgradArgs {
     int KH, KW, stride, pad, gather, act, aff_stride;
     int M, tiles_co, tiles_ci, splitk, chunk;   // chunk = pixels per split (multiple of 16)
     int vec_i, vec_o;
+    unsigned x_bytes, aff_bytes;
 };
 
 template <int BCO, int BCI, int WAVES_O, int WAVES_I>
@@ -426,6 +434,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 #include "conv_fast.h"
+#include "conv_buf.h"
 
 __global__ void reduce_slabs_kernel(const float* part, float* out, size_t n, int slabs) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -544,7 +553,26 @@ extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const fl
         else if (bn == 64) hipLaunchKernelGGL((conv_fwd_fast_kernel<64, 2, 2, G>), grid, blk, 0, s, a);            \
         else hipLaunchKernelGGL((conv_fwd_fast_kernel<32, 4, 1, G>), grid, blk, 0, s, a);                          \
     } while (0)
-    if (a.vec && !force_generic()) {
+    const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, wb = (size_t)d->Cout * d->KH * d->KW * d->Cin * 4;
+    const size_t ab = (size_t)(d->affine_per_image ? d->N : 1) * d->Cin * 4;
+    const int xf = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_LEAKY02 ? 3 : 1)) : 0;
+    const bool buf_ok = !force_generic() && !force_nobuf() && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) &&
+                        (d->gather == FAVAE_GATHER_PLAIN || xf == 0);
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.aff_bytes = (unsigned)ab;
+#define FAVAE_LAUNCH_BUF(G, X)                                                                                     \
+    do {                                                                                                           \
+        if (bn == 128) hipLaunchKernelGGL((conv_fwd_buf_kernel<128, 2, 2, G, X>), grid, blk, 0, s, a);             \
+        else if (bn == 64) hipLaunchKernelGGL((conv_fwd_buf_kernel<64, 2, 2, G, X>), grid, blk, 0, s, a);          \
+        else hipLaunchKernelGGL((conv_fwd_buf_kernel<32, 4, 1, G, X>), grid, blk, 0, s, a);                        \
+    } while (0)
+    if (buf_ok) {
+        if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_BUF(FAVAE_GATHER_UPSAMPLE2, 0);
+        else if (d->gather == FAVAE_GATHER_DILATE2) FAVAE_LAUNCH_BUF(FAVAE_GATHER_DILATE2, 0);
+        else if (xf == 0) FAVAE_LAUNCH_BUF(FAVAE_GATHER_PLAIN, 0);
+        else if (xf == 1) FAVAE_LAUNCH_BUF(FAVAE_GATHER_PLAIN, 1);
+        else if (xf == 2) FAVAE_LAUNCH_BUF(FAVAE_GATHER_PLAIN, 2);
+        else FAVAE_LAUNCH_BUF(FAVAE_GATHER_PLAIN, 3);
+    } else if (a.vec && !force_generic()) {
         if (d->gather == FAVAE_GATHER_PLAIN) FAVAE_LAUNCH_FWD(FAVAE_GATHER_PLAIN);
         else if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_FWD(FAVAE_GATHER_UPSAMPLE2);
         else FAVAE_LAUNCH_FWD(FAVAE_GATHER_DILATE2);
@@ -556,6 +584,7 @@ extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const fl
         hipLaunchKernelGGL((conv_fwd_kernel<32, 4, 1>), grid, blk, 0, s, a);
     }
 #undef FAVAE_LAUNCH_FWD
+#undef FAVAE_LAUNCH_BUF
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -597,7 +626,23 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
         else if (bco == 32) hipLaunchKernelGGL((conv_wgrad_fast_kernel<32, 128, 1, 4, G>), grid, dim3(256), 0, s, a);            \
         else hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 32, 4, 1, G>), grid, dim3(256), 0, s, a);                           \
     } while (0)
-    if (a.vec_i && a.vec_o && !force_generic()) {
+    const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, yb = (size_t)d->N * d->Hout * d->Wout * d->Cout * 4;
+    const size_t ab = (size_t)(d->affine_per_image ? d->N : 1) * d->Cin * 4;
+    const int xf = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_LEAKY02 ? 3 : 1)) : 0;
+    const bool buf_ok = !force_generic() && !force_nobuf() && a.vec_i && a.vec_o && d->gather == FAVAE_GATHER_PLAIN &&
+                        d->stride == 1 && d->Wout % 16 == 0 && xb < (1u << 31) && yb < (1u << 31) && xf != 3;
+    a.x_bytes = (unsigned)xb; a.aff_bytes = (unsigned)ab;
+#define FAVAE_LAUNCH_WBUF(X)                                                                                       \
+    do {                                                                                                           \
+        if (bco == 128 && bci == 128) hipLaunchKernelGGL((conv_wgrad_buf_kernel<128, 128, 2, 2, X>), grid, dim3(256), 0, s, a); \
+        else if (bco == 32) hipLaunchKernelGGL((conv_wgrad_buf_kernel<32, 128, 1, 4, X>), grid, dim3(256), 0, s, a);            \
+        else hipLaunchKernelGGL((conv_wgrad_buf_kernel<128, 32, 4, 1, X>), grid, dim3(256), 0, s, a);                           \
+    } while (0)
+    if (buf_ok) {
+        if (xf == 0) FAVAE_LAUNCH_WBUF(0);
+        else if (xf == 1) FAVAE_LAUNCH_WBUF(1);
+        else FAVAE_LAUNCH_WBUF(2);
+    } else if (a.vec_i && a.vec_o && !force_generic()) {
         if (d->gather == FAVAE_GATHER_PLAIN) FAVAE_LAUNCH_WGRAD(FAVAE_GATHER_PLAIN);
         else if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_WGRAD(FAVAE_GATHER_UPSAMPLE2);
         else FAVAE_LAUNCH_WGRAD(FAVAE_GATHER_DILATE2);
@@ -608,6 +653,7 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, a);
 #undef FAVAE_LAUNCH_WGRAD
+#undef FAVAE_LAUNCH_WBUF
     FAVAE_CHECK_LAUNCH();
     const size_t n = (size_t)d->Cout * d->KH * d->KW * d->Cin;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, dw, n, a.splitk);
