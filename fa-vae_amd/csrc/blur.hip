@@ -13,7 +13,8 @@
 #include "common.h"
 
 extern "C" size_t favae_colsum_workspace(int64_t M, int C);
-extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, void* ws, size_t ws_bytes, favae_stream_t stream);
+extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, int accumulate, void* ws, size_t ws_bytes,
+                            favae_stream_t stream);
 
 namespace {
 
@@ -80,6 +81,9 @@ __global__ __launch_bounds__(256) void blur_sep_kernel(BlurArgs a) {
     const int tid = threadIdx.x;
     const int c = tid % CC, pl = tid / CC, PL = 256 / CC;
     const bool c_ok = c0 + c < a.C;
+    // interior tiles (no reflect fold, no image border inside the halo) take branch-free k-tap loops
+    const bool int_y = y0 >= p + 1 && y0 + a.TH - 1 < a.H - 1 - p;
+    const bool int_x = x0 >= p + 1 && x0 + a.TW - 1 < a.W - 1 - p;
 
     make_kernel1d(a.sigma, k, g);
     // ---- stage halo tiles ---------------------------------------------------------------------------------------
@@ -114,7 +118,10 @@ __global__ __launch_bounds__(256) void blur_sep_kernel(BlurArgs a) {
             const int yy = q / HW, hx = q - yy * HW;
             const int y = y0 + yy;
             float acc = 0.f;
-            if (y < a.H) {
+            if (int_y) {                                  // interior tile: no fold, no bounds -> k taps straight down the column
+                const float* col = Dh + ((yy + 2 * p) * HW + hx) * CC + c;
+                for (int u = 0; u < k; ++u) acc = fmaf(g[u], col[-u * HW * CC], acc);
+            } else if (y < a.H) {
                 int jy[3];
                 const int ny = preimages(y, a.H, p, jy);
                 for (int i = 0; i < ny; ++i)
@@ -150,9 +157,15 @@ __global__ __launch_bounds__(256) void blur_sep_kernel(BlurArgs a) {
             const int py = q / a.TW, px = q - py * a.TW;
             const int y = y0 + py, x = x0 + px;
             if (y >= a.H || x >= a.W) continue;
+            float acc = 0.f;
+            if (int_x) {
+                const float* row = V + (py * HW + px + 2 * p) * CC + c;
+                for (int v = 0; v < k; ++v) acc = fmaf(g[v], row[-v * CC], acc);
+                out[((size_t)y * a.W + x) * a.C + c0 + c] = acc;
+                continue;
+            }
             int jx[3];
             const int nx = preimages(x, a.W, p, jx);
-            float acc = 0.f;
             for (int i = 0; i < nx; ++i)
                 for (int v = 0; v < k; ++v) {
                     const int rx = jx[i] + p - v;
@@ -165,15 +178,25 @@ __global__ __launch_bounds__(256) void blur_sep_kernel(BlurArgs a) {
     }
     if (a.part) {
         const int lane = tid & 63, wid = tid >> 6;
+        constexpr int MAXP = 16;                              // pixels per thread (plan() keeps TH*TW/PL <= 16)
+        float dc[MAXP], vc[MAXP];
+        int offU[MAXP], offX[MAXP];
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int q = pl + i * PL;
+            const int py = q / a.TW, px = q - py * a.TW;
+            const bool ok = c_ok && q < npix && y0 + py < a.H && x0 + px < a.W;
+            dc[i] = ok ? Dh[((py + p) * HW + px + p) * CC + c] : 0.f;
+            vc[i] = ok ? V[(py * HW + px + p) * CC + c] : 0.f;
+            offU[i] = ok ? (py * a.TW + px) * CC + c : 0;
+            offX[i] = ok ? ((py + p) * HW + px) * CC + c : 0;
+        }
         for (int t = 0; t < k; ++t) {
             float ah = 0.f, aw = 0.f;
-            if (c_ok) {
-                for (int q = pl; q < npix; q += PL) {
-                    const int py = q / a.TW, px = q - py * a.TW;
-                    if (y0 + py >= a.H || x0 + px >= a.W) continue;
-                    ah = fmaf(Dh[((py + p) * HW + px + p) * CC + c], U[((py + t) * a.TW + px) * CC + c], ah);
-                    aw = fmaf(V[(py * HW + px + p) * CC + c], Xh[((py + p) * HW + px + t) * CC + c], aw);
-                }
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                ah = fmaf(dc[i], U[offU[i] + t * a.TW * CC], ah);
+                aw = fmaf(vc[i], Xh[offX[i] + t * CC], aw);
             }
             ah = wave_sum(ah);
             aw = wave_sum(aw);
@@ -287,7 +310,7 @@ extern "C" int favae_blur_bwd(const float* x, const float* dy, const float* sigm
     hipLaunchKernelGGL((blur_sep_kernel<1>), dim3((unsigned)grid), dim3(256), shm, s, a);
     FAVAE_CHECK_LAUNCH();
     if (dsigma) {
-        int rc = favae_colsum(part, dgv, grid, ksize, p2, cws, stream);
+        int rc = favae_colsum(part, dgv, grid, ksize, 0, p2, cws, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(blur_dsigma_kernel, dim3(1), dim3(64), 0, s, (const float*)dgv, sigma, ksize, dsigma);
         FAVAE_CHECK_LAUNCH();

@@ -436,12 +436,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #include "conv_fast.h"
 #include "conv_buf.h"
 
-__global__ void reduce_slabs_kernel(const float* part, float* out, size_t n, int slabs) {
+// out[i] (+)= sum_z part[z][i] in a fixed order (4 interleaved partial sums -> 4 loads in flight per thread)
+__global__ void reduce_slabs_kernel(const float* part, float* out, size_t n, int slabs, int accumulate) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float s = 0.f;
-    for (int z = 0; z < slabs; ++z) s += part[(size_t)z * n + i];
-    out[i] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 3 < slabs; z += 4) {
+        s0 += part[(size_t)z * n + i];
+        s1 += part[(size_t)(z + 1) * n + i];
+        s2 += part[(size_t)(z + 2) * n + i];
+        s3 += part[(size_t)(z + 3) * n + i];
+    }
+    for (; z < slabs; ++z) s0 += part[(size_t)z * n + i];
+    const float s = (s0 + s1) + (s2 + s3);
+    out[i] = accumulate ? out[i] + s : s;
 }
 
 __global__ void weight_flip_kernel(const float* w, float* wt, int Cout, int KH, int KW, int Cin) {
@@ -479,6 +488,45 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* a, flo
     }
     for (; r < r1; ++r) s0 += a[r * C + c];
     part[(size_t)blockIdx.y * C + c] = (s0 + s1) + (s2 + s3);
+}
+
+// vector version (C % 4 == 0): thread = (channel quad, row lane), 16-byte loads, LDS reduce over the row lanes
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float* a, float* part, long M, int C, long rows_per_block) {
+    __shared__ float4 sm[256];
+    const int QT = C / 4;
+    const int Q = QT < 256 ? QT : 256, RL = 256 / Q;
+    const int qi = threadIdx.x % Q, li = threadIdx.x / Q;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    for (int qb = 0; qb < QT; qb += Q) {
+        const int q = qb + qi;
+        const bool on = q < QT && li < RL;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+        if (on) {
+            const float4* p = reinterpret_cast<const float4*>(a) + q;
+            long r = r0 + li;
+            for (; r + RL < r1; r += 2 * RL) {
+                const float4 u = p[r * QT], v = p[(r + RL) * QT];
+                s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            }
+            if (r < r1) {
+                const float4 u = p[r * QT];
+                s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+            }
+            s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w;
+        }
+        __syncthreads();
+        sm[threadIdx.x] = s0;
+        __syncthreads();
+        if (on && li == 0) {
+            for (int l = 1; l < RL; ++l) {
+                const float4 v = sm[l * Q + qi];
+                s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+            }
+            reinterpret_cast<float4*>(part + (size_t)blockIdx.y * C)[q] = s0;
+        }
+    }
 }
 
 __global__ void upsample2x_bwd_kernel(const float* du, float* dx, int N, int H, int W, int C4) {
@@ -599,7 +647,8 @@ extern "C" size_t favae_conv_wgrad_workspace(const favae_conv_desc* d) {
 }
 
 extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const float* dy, const float* scale,
-                                const float* shift, float* dw, void* ws, size_t ws_bytes, favae_stream_t stream) {
+                                const float* shift, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                                favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && x && dy && dw && ws);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     if (ws_bytes < favae_conv_wgrad_workspace(d)) return FAVAE_ERR_WORKSPACE;
@@ -656,7 +705,7 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
 #undef FAVAE_LAUNCH_WBUF
     FAVAE_CHECK_LAUNCH();
     const size_t n = (size_t)d->Cout * d->KH * d->KW * d->Cin;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, dw, n, a.splitk);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, dw, n, a.splitk, accumulate);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -678,16 +727,19 @@ static int colsum_blocks(int64_t M) {
 
 extern "C" size_t favae_colsum_workspace(int64_t M, int C) { return (size_t)colsum_blocks(M) * C * sizeof(float); }
 
-extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, void* ws, size_t ws_bytes,
+extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, int accumulate, void* ws, size_t ws_bytes,
                             favae_stream_t stream) {
     FAVAE_REQUIRE(a && out && ws && M > 0 && C > 0);
     if (ws_bytes < favae_colsum_workspace(M, C)) return FAVAE_ERR_WORKSPACE;
     const int nb = colsum_blocks(M);
     const long rpb = (M + nb - 1) / nb;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C, 256), nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb);
+    if (C % 4 == 0 && ((((uintptr_t)a) & 15) == 0))
+        hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3(1, nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C, 256), nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb);
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const float*)ws, out, (size_t)C, nb);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const float*)ws, out, (size_t)C, nb, accumulate);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }

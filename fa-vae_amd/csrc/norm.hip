@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
 
 // dgamma[c] = sum_n S2[n][c], dbeta[c] = sum_n S1[n][c]
 __global__ __launch_bounds__(256) void gn_param_grad_kernel(const double* __restrict__ acc, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int N, int C) {
+                                                            float* __restrict__ dbeta, int N, int C, int accumulate) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(const double* __rest
         s1 += acc[((size_t)n * C + c) * 2];
         s2 += acc[((size_t)n * C + c) * 2 + 1];
     }
-    dbeta[c] = (float)s1;
-    dgamma[c] = (float)s2;
+    dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+    dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
 }
 
 // dx = rstd * (dy*gamma - k1 - xhat*k2) + dx_add ; grid-stride over float4 (VEC) or scalars
@@ -307,7 +307,8 @@ extern "C" int favae_gn_stats(const float* x, const float* gamma, const float* b
 
 extern "C" int favae_gn_act_bwd(const float* da, const float* x, const float* gamma, const float* beta, const float* mean,
                                 const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
-                                float* dgamma, float* dbeta, void* ws, size_t ws_bytes, favae_stream_t stream) {
+                                float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes,
+                                favae_stream_t stream) {
     FAVAE_REQUIRE(da && x && gamma && beta && mean && rstd && dx && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
     FAVAE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr));
     if (ws_bytes < favae_gn_workspace(N, HW, C)) return FAVAE_ERR_WORKSPACE;
@@ -322,7 +323,7 @@ extern "C" int favae_gn_act_bwd(const float* da, const float* x, const float* ga
                        gn_splits(N, HW));
     FAVAE_CHECK_LAUNCH();
     if (dgamma) {
-        hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)acc, dgamma, dbeta, N, C);
+        hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)acc, dgamma, dbeta, N, C, accumulate);
         FAVAE_CHECK_LAUNCH();
     }
     const size_t total = (size_t)N * HW * C;

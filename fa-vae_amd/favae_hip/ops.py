@@ -128,6 +128,18 @@ def gn_stats(x, gamma, beta, groups, eps=1e-5):
     return mean, rstd, scale, shift
 
 
+def _direct_grad(p):
+    """Gradient target for parameter `p` when its .grad is a pre-zeroed view of a flat gradient buffer owned by
+    favae_step.TrainStep (marked `_favae_flat`): the reduction kernels then ACCUMULATE into it and autograd is handed
+    None, which removes one AccumulateGrad add kernel per parameter.  None -> ordinary autograd path."""
+    if p is None or not getattr(p, "_favae_flat", False) or p.grad is None:
+        return None
+    g = p.grad
+    if g.dim() == 4:
+        return g if _is_cl(g) else None
+    return g if g.is_contiguous() else None
+
+
 class ConvCfg:
     """Static description of one fused conv site."""
     __slots__ = ("kh", "kw", "stride", "pad", "pad_br", "upsample", "act", "groups", "eps")
@@ -174,6 +186,7 @@ class FusedConvFn(torch.autograd.Function):
         ctx.has_gn = gn_w is not None
         ctx.has_res = resid is not None
         ctx.w_dim = w.dim()
+        ctx.params = (w, b, gn_w, gn_b)           # to reach pre-assigned flat-buffer gradients (see _direct_grad)
         ctx.save_for_backward(x, wk, gn_w, gn_b, mean, rstd, scale, shift)
         return y
 
@@ -189,19 +202,26 @@ class FusedConvFn(torch.autograd.Function):
         dx = dw = db = dgw = dgb = None
         gather = GATHER_UPSAMPLE2 if cfg.upsample else GATHER_PLAIN
         act = cfg.act if ctx.has_gn else ACT_NONE
+        p_w, p_b, p_gw, p_gb = ctx.params
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = torch.empty((Cout,), dtype=torch.float32, device=dev)
             M = N * Ho * Wo
             ws = workspace(query("favae_colsum_workspace", M, Cout), dev)
-            call("favae_colsum", ptr(dy), ptr(db), M, Cout, ptr(ws), ws.numel())
+            tgt = _direct_grad(p_b)
+            if tgt is None:
+                db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+            call("favae_colsum", ptr(dy), ptr(db if tgt is None else tgt), M, Cout, 0 if tgt is None else 1, ptr(ws), ws.numel())
         if need_w:
             d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad, gather, act, 1)
-            dwk = torch.empty((Cout, cfg.kh, cfg.kw, Cin), dtype=torch.float32, device=dev)
             ws = workspace(query("favae_conv_wgrad_workspace", byref(d)), dev)
-            call("favae_conv_wgrad", byref(d), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(dwk), ptr(ws), ws.numel())
-            dw = dwk.permute(0, 3, 1, 2)                      # (Cout,Cin,KH,KW) view with channels-last strides
-            if ctx.w_dim == 2:
-                dw = dwk.view(Cout, Cin)
+            tgt = _direct_grad(p_w)
+            if tgt is None:
+                dwk = torch.empty((Cout, cfg.kh, cfg.kw, Cin), dtype=torch.float32, device=dev)
+                call("favae_conv_wgrad", byref(d), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(dwk), 0, ptr(ws), ws.numel())
+                dw = dwk.permute(0, 3, 1, 2)                  # (Cout,Cin,KH,KW) view with channels-last strides
+                if ctx.w_dim == 2:
+                    dw = dwk.view(Cout, Cin)
+            else:                                             # accumulate straight into the flat gradient buffer
+                call("favae_conv_wgrad", byref(d), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(tgt), 1, ptr(ws), ws.numel())
         if need_x or ctx.has_gn:
             wt = torch.empty((Cin, cfg.kh, cfg.kw, Cout), dtype=torch.float32, device=dev)
             call("favae_weight_flip", ptr(wk), ptr(wt), Cout, cfg.kh, cfg.kw, Cin)
@@ -222,11 +242,15 @@ class FusedConvFn(torch.autograd.Function):
                 da = dlow
             if ctx.has_gn:
                 dx = new_cl(N, Cin, Hin, Win, dev)
-                dgw = torch.empty((Cin,), dtype=torch.float32, device=dev)
-                dgb = torch.empty_like(dgw)
+                tg, tb = _direct_grad(p_gw), _direct_grad(p_gb)
+                direct = tg is not None and tb is not None
+                if not direct:
+                    dgw = torch.empty((Cin,), dtype=torch.float32, device=dev)
+                    dgb = torch.empty_like(dgw)
                 ws = workspace(query("favae_gn_workspace", N, Hin * Win, Cin), dev)
                 call("favae_gn_act_bwd", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), N, Hin * Win, Cin,
-                     cfg.groups, act, None, ptr(dx), ptr(dgw), ptr(dgb), ptr(ws), ws.numel())
+                     cfg.groups, act, None, ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,
+                     ptr(ws), ws.numel())
             else:
                 dx = da
         dres = dy if ctx.has_res else None

@@ -47,6 +47,7 @@ class TrainStep:
             view.copy_(p.data)
             p.data = view
             p.grad = self.gflat[off:off + n].as_strided(p.shape, p.stride())
+            p._favae_flat = True          # ops._direct_grad: reductions accumulate straight into this (zeroed) view
             off += n
 
     def losses(self, x):

@@ -72,14 +72,16 @@ int favae_conv_fwd(const favae_conv_desc* d, const float* x, const float* w, con
  * partial slabs in `ws`, summed in a fixed order).  autograd's convolution_backward weight path. */
 size_t favae_conv_wgrad_workspace(const favae_conv_desc* d);
 int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const float* dy, const float* scale, const float* shift,
-                     float* dw, void* ws, size_t ws_bytes, favae_stream_t stream);
+                     float* dw, int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream);
 
 /* wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]  (weights of the data-gradient convolution) */
 int favae_weight_flip(const float* w, float* wt, int Cout, int KH, int KW, int Cin, favae_stream_t stream);
 
-/* out[c] = sum_m a[m][c]  (bias gradient; M rows of C) ; deterministic two-stage */
+/* out[c] (+)= sum_m a[m][c]  (bias gradient; M rows of C) ; deterministic two-stage.  `accumulate` != 0 adds to `out`
+ * (gradients written straight into a pre-zeroed flat gradient buffer, as favae_conv_wgrad / favae_gn_act_bwd do). */
 size_t favae_colsum_workspace(int64_t M, int C);
-int favae_colsum(const float* a, float* out, int64_t M, int C, void* ws, size_t ws_bytes, favae_stream_t stream);
+int favae_colsum(const float* a, float* out, int64_t M, int C, int accumulate, void* ws, size_t ws_bytes,
+                 favae_stream_t stream);
 
 /* adjoint of nearest x2 upsampling: dx[n,h,w,c] = sum of the 2x2 children of du (N,2H,2W,C) */
 int favae_upsample2x_bwd(const float* du, float* dx, int N, int H, int W, int C, favae_stream_t stream);
@@ -99,7 +101,7 @@ int favae_gn_stats(const float* x, const float* gamma, const float* beta, int N,
  * added to dx (fused skip-connection gradient).  dx may alias da. */
 int favae_gn_act_bwd(const float* da, const float* x, const float* gamma, const float* beta, const float* mean,
                      const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
-                     float* dgamma, float* dbeta, void* ws, size_t ws_bytes, favae_stream_t stream);
+                     float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream);
 
 /* BatchNorm2d running-stat update (momentum m, unbiased variance), models/discriminator.py:207 in train mode */
 int favae_bn_update_running(const float* mean, const float* rstd, int C, int64_t count, float eps, float momentum,

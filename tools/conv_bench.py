@@ -42,5 +42,5 @@ for cin, cout, hw, k in SHAPES:
     t_d = timeit(lambda: H.call("favae_conv_fwd", byref(d2), H.ptr(y), H.ptr(wt), None, None, None, None, H.ptr(dx)))
     dw = torch.empty(cout, k, k, cin, device=dev)
     ws = H.workspace(H.query("favae_conv_wgrad_workspace", byref(d)), dev)
-    t_w = timeit(lambda: H.call("favae_conv_wgrad", byref(d), H.ptr(x), H.ptr(y), H.ptr(scale), H.ptr(shift), H.ptr(dw), H.ptr(ws), ws.numel()))
+    t_w = timeit(lambda: H.call("favae_conv_wgrad", byref(d), H.ptr(x), H.ptr(y), H.ptr(scale), H.ptr(shift), H.ptr(dw), 0, H.ptr(ws), ws.numel()))
     print(f"{cin:4d}->{cout:4d} @{hw:3d} k{k}: fwd {flops/t_f*1e-12:6.1f}  dgrad {flops/t_d*1e-12:6.1f}  wgrad {flops/t_w*1e-12:6.1f} TFLOP/s   ({t_f*1e3:.2f} / {t_d*1e3:.2f} / {t_w*1e3:.2f} ms)", flush=True)

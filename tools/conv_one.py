@@ -25,5 +25,5 @@ ws = H.workspace(H.query("favae_conv_wgrad_workspace", byref(d)), dev)
 for _ in range(3):
     H.call("favae_conv_fwd", byref(d), H.ptr(x), H.ptr(w), H.ptr(b), None, H.ptr(scale), H.ptr(shift), H.ptr(y))
     H.call("favae_conv_fwd", byref(d2), H.ptr(y), H.ptr(wt), None, None, None, None, H.ptr(dx))
-    H.call("favae_conv_wgrad", byref(d), H.ptr(x), H.ptr(y), H.ptr(scale), H.ptr(shift), H.ptr(dw), H.ptr(ws), ws.numel())
+    H.call("favae_conv_wgrad", byref(d), H.ptr(x), H.ptr(y), H.ptr(scale), H.ptr(shift), H.ptr(dw), 0, H.ptr(ws), ws.numel())
 torch.cuda.synchronize()
