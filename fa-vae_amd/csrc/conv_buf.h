@@ -143,37 +143,55 @@ __global__ __launch_bounds__(256) void conv_fwd_buf_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Schedule (2 LDS buffers, ONE barrier per K step, placed in the MIDDLE of the step's MFMA stream):
+    //   top   : ds_write tile i+1 (its global loads were issued a whole step earlier) ; issue global loads of tile i+2
+    //   first : fragment reads of k-group 1 (tile i) -> 16 MFMAs of k-group 0
+    //   middle: lgkmcnt(0) + s_barrier  (tile i+1 is now complete in LDS, tile i-1's buffer is free)
+    //   second: fragment reads of k-group 0 of tile i+1 -> 16 MFMAs of k-group 1
+    // so the LDS write -> barrier -> read latency of the classic end-of-step barrier is covered by the second MFMA group
+    // (PMC: with VALU work already minimal the pipe was still idle ~17 % of the time, profiles/r01_pmc_conv.md).
     const int T = taps * a.kchunks;
-    load_tiles();
-    store_tiles(0);
-    __syncthreads();
     const int frow = lane & 31, fk = (lane >> 5) * 4;
     const float* Ab0 = As + (wm * WTM + frow) * LDK + fk;
     const float* Bb0 = Bs + (wn * WTN + frow) * LDK + fk;
+    float4 af0[MI], bf0[NI], af1[MI], bf1[NI];
+    auto read_frags = [&](int buf, int kk, float4 (&af)[MI], float4 (&bf)[NI]) {
+        const float* Ab = Ab0 + buf * BM * LDK + kk * 8;
+        const float* Bb = Bb0 + buf * BN * LDK + kk * 8;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK);
+    };
+    auto mfma_group = [&](const float4 (&af)[MI], const float4 (&bf)[NI]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+            }
+    };
+    load_tiles();
+    store_tiles(0);
+    if (T > 1) load_tiles();                               // tile 1 in flight
+    __syncthreads();
+    read_frags(0, 0, af0, bf0);
     for (int it = 0; it < T; ++it) {
         const int cur = it & 1;
-        if (it + 1 < T) load_tiles();
-        const float* Ab = Ab0 + cur * BM * LDK;
-        const float* Bb = Bb0 + cur * BN * LDK;
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            float4 af[MI], bf[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + kk * 8);
-#pragma unroll
-            for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + kk * 8);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (it + 1 < T) store_tiles(cur ^ 1);
+        if (it + 1 < T) store_tiles(cur ^ 1);              // tile it+1: registers -> LDS (other buffer)
+        if (it + 2 < T) load_tiles();                      // tile it+2: global -> registers
+        read_frags(cur, 1, af1, bf1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        if (it + 1 < T) read_frags(cur ^ 1, 0, af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(af1, bf1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
 #pragma unroll
@@ -308,32 +326,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_buf_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (T > 0) {
-        load_tiles();
-        store_tiles(0);
-    }
-    __syncthreads();
+    // same mid-step barrier schedule as conv_fwd_buf_kernel: k-pairs 0..3 | barrier | k-pairs 4..7
     const int frow = lane & 31, fk = lane >> 5;
-    for (int it = 0; it < T; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < T) load_tiles();
-        const float* Ob = Os + (cur * BKP + fk) * BCO + wo * WTO + frow;
-        const float* Ib = Is + (cur * BKP + fk) * BCI + wi * WTI + frow;
+    constexpr int HALF = BKP / 4;                          // k-pairs per half step
+    float af0[HALF][MI], bf0[HALF][NI], af1[HALF][MI], bf1[HALF][NI];
+    auto read_frags = [&](int buf, int half, float (&af)[HALF][MI], float (&bf)[HALF][NI]) {
+        const float* Ob = Os + (buf * BKP + fk + 2 * HALF * half) * BCO + wo * WTO + frow;
+        const float* Ib = Is + (buf * BKP + fk + 2 * HALF * half) * BCI + wi * WTI + frow;
 #pragma unroll
-        for (int kk = 0; kk < BKP / 2; ++kk) {
-            float af[MI], bf[NI];
+        for (int kk = 0; kk < HALF; ++kk) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = Ob[kk * 2 * BCO + i * 32];
+            for (int i = 0; i < MI; ++i) af[kk][i] = Ob[kk * 2 * BCO + i * 32];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bf[j] = Ib[kk * 2 * BCI + j * 32];
+            for (int j = 0; j < NI; ++j) bf[kk][j] = Ib[kk * 2 * BCI + j * 32];
+        }
+    };
+    auto mfma_group = [&](const float (&af)[HALF][MI], const float (&bf)[HALF][NI]) {
+#pragma unroll
+        for (int kk = 0; kk < HALF; ++kk)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
+    };
+    if (T > 0) {
+        load_tiles();
+        store_tiles(0);
+        if (T > 1) load_tiles();
+    }
+    __syncthreads();
+    if (T > 0) read_frags(0, 0, af0, bf0);
+    for (int it = 0; it < T; ++it) {
+        const int cur = it & 1;
         if (it + 1 < T) store_tiles(cur ^ 1);
+        if (it + 2 < T) load_tiles();
+        read_frags(cur, 1, af1, bf1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        if (it + 1 < T) read_frags(cur ^ 1, 0, af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(af1, bf1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
