@@ -9,7 +9,7 @@ fused Adam) with the batch already resident in HBM.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement"):
   value      whole-job images/s  (sum over ranks / max-over-ranks time, barrier + synchronize on both sides)
-  roofline   dominant kernel = conv_fwd_fast_kernel<128,2,2,PLAIN> (forward + data-gradient implicit GEMM, exact-fp32 MFMA):
+  roofline   dominant kernel = the conv_fwd_buf_kernel<128,2,2,gather,xform> instantiation with the largest time share (forward + data-gradient implicit GEMM, exact-fp32 MFMA):
              algorithmic FLOPs (2*M*Cout*KH*KW*Cin per launch) / launch durations measured with HIP events on the launch
              stream inside the timed region; peak = 157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md)
   cpu_baseline  the CPU oracle (kind "port": pure-PyTorch restatement of the reference step, oracle/) timed on this
@@ -43,19 +43,30 @@ def parse():
 
 
 class ConvEventHook:
-    """Brackets every launch of the dominant kernel with HIP events (torch.cuda.Event records on the current stream,
-    which is the stream favae_hip launches on)."""
+    """Brackets every launch of the implicit-GEMM forward/data-gradient kernel family with HIP events (torch.cuda.Event
+    records on the current stream, which is the stream favae_hip launches on).  Launches are keyed by the template
+    instantiation they dispatch to, so each key corresponds to exactly one kernel name in a rocprofv3 trace."""
 
     def __init__(self, torch):
         self.torch = torch
-        self.recs = []          # (start, end, flops)
+        self.recs = {}          # kernel name -> list of (start, end, flops)
         self.enabled = False
+
+    @staticmethod
+    def kernel_name(d, has_affine):
+        if d.Cin % 16 or d.Cout <= 64:
+            return None                                    # other tile shapes / non-buffer paths: not the dominant family
+        xf = 0 if not has_affine else {0: 1, 1: 2, 2: 3}[d.act]
+        if d.gather != 0 and xf != 0:
+            return None
+        return "conv_fwd_buf_kernel<128, 2, 2, %d, %d>" % (d.gather, xf)
 
     def __call__(self, name, args, launch):
         if not self.enabled or name != "favae_conv_fwd":
             return launch()
         d = args[0]._obj
-        if d.Cout <= 64 or d.Cin % 4 or d.gather != 0:      # other instantiations, not the dominant kernel
+        kn = self.kernel_name(d, args[5] is not None)
+        if kn is None:
             return launch()
         flops = 2.0 * d.N * d.Hout * d.Wout * d.Cout * d.KH * d.KW * d.Cin
         s = self.torch.cuda.Event(enable_timing=True)
@@ -63,16 +74,17 @@ class ConvEventHook:
         s.record()
         launch()
         e.record()
-        self.recs.append((s, e, flops))
+        self.recs.setdefault(kn, []).append((s, e, flops))
 
     def summary(self):
-        if not self.recs:
-            return None
-        ms = [s.elapsed_time(e) for s, e, _ in self.recs]
-        fl = [f for _, _, f in self.recs]
-        tot_ms, tot_fl = sum(ms), sum(fl)
-        return {"launches": len(ms), "avg_us": 1e3 * tot_ms / len(ms), "avg_gflop": 1e-9 * tot_fl / len(ms),
-                "tflops": 1e-12 * tot_fl / (1e-3 * tot_ms), "total_ms": tot_ms}
+        out = {}
+        for kn, recs in self.recs.items():
+            ms = [s.elapsed_time(e) for s, e, _ in recs]
+            fl = [f for _, _, f in recs]
+            tot_ms, tot_fl = sum(ms), sum(fl)
+            out[kn] = {"launches": len(ms), "avg_us": 1e3 * tot_ms / len(ms), "avg_gflop": 1e-9 * tot_fl / len(ms),
+                       "tflops": 1e-12 * tot_fl / (1e-3 * tot_ms), "total_ms": tot_ms}
+        return out
 
 
 def usable_cores(torch):
@@ -181,12 +193,25 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss_g_last": loss},
         }
         if conv:
-            res["roofline"] = {"bound": "mfma", "achieved": conv["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": conv["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                               "kernel": "conv_fwd_fast_kernel<128,2,2,PLAIN> (fwd + dgrad implicit GEMM, v_mfma_f32_32x32x2_f32)",
-                               "launches": conv["launches"], "avg_launch_us": conv["avg_us"],
-                               "avg_algorithmic_gflop_per_launch": conv["avg_gflop"],
-                               "share_of_step_time": conv["total_ms"] / (1e3 * dt)}
+            def entry(kn, c):
+                return {"bound": "mfma", "achieved": c["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": c["tflops"] / PEAK_F32_MFMA_TFLOPS,
+                        "traffic": (traffic.get(kn) or {}).get("hbm_bytes_per_launch_corrected"), "kernel": kn,
+                        "launches": c["launches"], "avg_launch_us": c["avg_us"],
+                        "avg_algorithmic_gflop_per_launch": c["avg_gflop"], "share_of_step_time": c["total_ms"] / (1e3 * dt)}
+            traffic = {}
+            try:                                            # per-launch HBM bytes from the committed PMC passes (profiles/)
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            except Exception:
+                pass
+            ranked = sorted(conv.items(), key=lambda kv: -kv[1]["total_ms"])
+            res["roofline"] = entry(*ranked[0])            # dominant instantiation (largest share of the timed region)
+            res["roofline"]["note"] = ("implicit-GEMM conv on v_mfma_f32_32x32x2_f32; template args <BN, wavesM, wavesN, gather, "
+                                       "xform>: xform 0 = plain (data gradient / un-normalised convs), 2 = GroupNorm+SiLU fused")
+            res["roofline"]["traffic_note"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the launches of one "
+                                               "step, separate rocprofv3 --pmc passes (gfx950 FETCH_SIZE x2 correction of "
+                                               "MI355X_MICROARCH.md; fabric-side counter, includes Infinity-Cache hits)")
+            res["roofline_others"] = [entry(kn, c) for kn, c in ranked[1:]]
         if world == 1 and not args.no_cpu_baseline:
             favae_hip.set_call_hook(None)
             print("[bench] GPU part done: %.2f images/s; timing the CPU baseline sample..." % res["value"], file=sys.stderr, flush=True)
