@@ -127,8 +127,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # FAVAE_FORCE_DIST=1 exercises the multi-GPU code path (RCCL process group, codebook + gradient all-reduce) at any
+    # world size, including 1 (used by tests/test_gpu_dist.py on the single-GPU box)
+    use_dist = world > 1 or os.environ.get("FAVAE_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl")           # RCCL on ROCm
     torch.cuda.set_device(local)
@@ -142,17 +148,17 @@ def main():
     favae_hip.load()
     torch.manual_seed(0)                           # favae_scripts/train_favae.py:235
     model = VQGANFCM(args.codebook, 256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
-                     use_l2_quantizer=True, sync_codebook=world > 1, commitment_weight=1.0, kernel_size=9, dsl_init_sigma=3.0,
+                     use_l2_quantizer=True, sync_codebook=use_dist, commitment_weight=1.0, kernel_size=9, dsl_init_sigma=3.0,
                      device=dev, use_gauss_resblock=True).to(dev)
     lr = 4.5e-6 * args.batch * world               # train_favae.py:250-251
-    ts = TrainStep(model, lr=lr, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, distributed=world > 1)
+    ts = TrainStep(model, lr=lr, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, distributed=use_dist)
     xs = [O.det_input(args.batch, args.res, args.res, 1234 + 17 * rank + i).to(dev) for i in range(2)]
 
     hook = ConvEventHook(torch)
     favae_hip.set_call_hook(hook)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -166,7 +172,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     hook.enabled = False
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -217,7 +223,7 @@ def main():
             print("[bench] GPU part done: %.2f images/s; timing the CPU baseline sample..." % res["value"], file=sys.stderr, flush=True)
             res["cpu_baseline"] = cpu_baseline(args, torch)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
