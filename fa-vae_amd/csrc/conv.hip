@@ -27,6 +27,13 @@ bool force_generic() {
     if (v < 0) { const char* e = getenv("FAVAE_CONV_GENERIC"); v = (e && e[0] == '1') ? 1 : 0; }
     return v == 1;
 }
+// 128-wide forward/data-gradient convs run on the exact-split bf16x6 matrix path (conv_b6.h); FAVAE_CONV_B6=0 falls back to
+// the fp32-MFMA kernels (A/B measurements, debugging)
+bool use_b6() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FAVAE_CONV_B6"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
 // FAVAE_CONV_NOBUF=1 disables the buffer-addressed kernels (A/B against the flat-addressed fast kernels)
 bool force_nobuf() {
     static int v = -1;
@@ -435,6 +442,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
 #include "conv_fast.h"
 #include "conv_buf.h"
+#include "conv_b6.h"
 
 // out[i] (+)= sum_z part[z][i] in a fixed order (4 interleaved partial sums -> 4 loads in flight per thread)
 __global__ void reduce_slabs_kernel(const float* part, float* out, size_t n, int slabs, int accumulate) {
@@ -613,7 +621,16 @@ extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const fl
         else if (bn == 64) hipLaunchKernelGGL((conv_fwd_buf_kernel<64, 2, 2, G, X>), grid, blk, 0, s, a);          \
         else hipLaunchKernelGGL((conv_fwd_buf_kernel<32, 4, 1, G, X>), grid, blk, 0, s, a);                        \
     } while (0)
-    if (buf_ok) {
+    if (buf_ok && use_b6() && bn == 128) {
+#define FAVAE_LAUNCH_B6(G, X) hipLaunchKernelGGL((conv_fwd_b6_kernel<G, X>), grid, blk, 0, s, a)
+        if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_B6(FAVAE_GATHER_UPSAMPLE2, 0);
+        else if (d->gather == FAVAE_GATHER_DILATE2) FAVAE_LAUNCH_B6(FAVAE_GATHER_DILATE2, 0);
+        else if (xf == 0) FAVAE_LAUNCH_B6(FAVAE_GATHER_PLAIN, 0);
+        else if (xf == 1) FAVAE_LAUNCH_B6(FAVAE_GATHER_PLAIN, 1);
+        else if (xf == 2) FAVAE_LAUNCH_B6(FAVAE_GATHER_PLAIN, 2);
+        else FAVAE_LAUNCH_B6(FAVAE_GATHER_PLAIN, 3);
+#undef FAVAE_LAUNCH_B6
+    } else if (buf_ok) {
         if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_BUF(FAVAE_GATHER_UPSAMPLE2, 0);
         else if (d->gather == FAVAE_GATHER_DILATE2) FAVAE_LAUNCH_BUF(FAVAE_GATHER_DILATE2, 0);
         else if (xf == 0) FAVAE_LAUNCH_BUF(FAVAE_GATHER_PLAIN, 0);
