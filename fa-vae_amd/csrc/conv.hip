@@ -704,7 +704,11 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
         else if (bco == 32) hipLaunchKernelGGL((conv_wgrad_buf_kernel<32, 128, 1, 4, X>), grid, dim3(256), 0, s, a);            \
         else hipLaunchKernelGGL((conv_wgrad_buf_kernel<128, 32, 4, 1, X>), grid, dim3(256), 0, s, a);                           \
     } while (0)
-    if (buf_ok) {
+    if (buf_ok && use_b6() && bco == 128 && bci == 128) {
+        if (xf == 0) hipLaunchKernelGGL((conv_wgrad_b6_kernel<0>), grid, dim3(256), 0, s, a);
+        else if (xf == 1) hipLaunchKernelGGL((conv_wgrad_b6_kernel<1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_wgrad_b6_kernel<2>), grid, dim3(256), 0, s, a);
+    } else if (buf_ok) {
         if (xf == 0) FAVAE_LAUNCH_WBUF(0);
         else if (xf == 1) FAVAE_LAUNCH_WBUF(1);
         else FAVAE_LAUNCH_WBUF(2);

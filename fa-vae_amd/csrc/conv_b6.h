@@ -185,3 +185,182 @@ __global__ __launch_bounds__(256) void conv_fwd_b6_kernel(ConvArgs a) {
             }
         }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient on the bf16x6 path.  K = pixels, but NHWC tiles are pixel-major: the three bf16 planes are stored
+// [plane][pixel][channel] exactly as they arrive (one ds_write_b64 per plane per float4) and the MFMA fragments
+// (8 consecutive pixels of one channel per lane) are fetched with gfx950's transposing LDS read ds_read_b64_tr_b16:
+// in every 16-lane group lane s supplies the address of 4 consecutive channels of pixel row (s>>2), and lane c receives
+// element (c&3) of the chunks of lanes {c>>2, 4+(c>>2), 8+(c>>2), 12+(c>>2)}  (probed on hardware, tools/experiments/tr_b16.hip).
+// Pixel rows are padded to 320 B so that the 4 rows x 2 channel blocks a 32-lane half touches fall on different banks.
+// Preconditions as conv_wgrad_buf_kernel (plain gather, stride 1, Wout % 16 == 0, channels % 4 == 0), 128x128 tiles.
+// ---------------------------------------------------------------------------------------------------------------
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+namespace b6 {
+constexpr int RSB = 320;                   // bytes per pixel row of a plane (128 ch x 2 B + 64 B pad: conflict-free tr reads)
+constexpr int PLB = 16 * RSB;              // bytes per plane (16 pixels)
+constexpr int OPB = 3 * PLB;               // bytes per operand buffer
+
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* p) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + 4 * RSB));
+    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+}  // namespace b6
+
+template <int XFORM>
+__global__ __launch_bounds__(256) void conv_wgrad_b6_kernel(WgradArgs a) {
+    constexpr int BCO = 128, BCI = 128, BKP = 16, MI = 2, NI = 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * b6::OPB];
+    unsigned char* Os = lds;                   // [2][3 planes][16 px][288 B]
+    unsigned char* Is = lds + 2 * b6::OPB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wo = wid >> 1, wi = wid & 1;
+    const int taps = a.KH * a.KW;
+    int t = blockIdx.x;
+    const int tap = t % taps; t /= taps;
+    const int ci0 = (t % a.tiles_ci) * BCI;
+    const int co0 = (t / a.tiles_ci) * BCO;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int z = blockIdx.y;
+    const int p_begin = z * a.chunk;
+    const int p_end = min(a.M, p_begin + a.chunk);
+    const int T = (p_end > p_begin) ? (p_end - p_begin + BKP - 1) / BKP : 0;
+
+    const auto rx = make_rsrc(a.x, a.x_bytes);
+    const auto rdy = make_rsrc(a.dy, (unsigned)p_end * (unsigned)a.Cout * 4u);
+    const auto rsc_d = make_rsrc(XFORM ? a.scale : a.x, XFORM ? a.aff_bytes : 0u);
+    const auto rsh_d = make_rsrc(XFORM ? a.shift : a.x, XFORM ? a.aff_bytes : 0u);
+
+    // staging slots: float4 index i = tid + 256 j  ->  pixel i/32, channel quad i%32
+    unsigned voo[2], vos[2];
+    int s_p[2], s_c[2];
+    bool o_ok[2], i_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + 256 * j;
+        s_p[j] = i >> 5;
+        s_c[j] = (i & 31) * 4;
+        o_ok[j] = co0 + s_c[j] < a.Cout;
+        i_ok[j] = ci0 + s_c[j] < a.Cin;
+        voo[j] = o_ok[j] ? (unsigned)((s_p[j] * a.Cout + co0 + s_c[j]) * 4) : FAVAE_OOB;
+        vos[j] = (unsigned)((ci0 + s_c[j]) * 4);
+    }
+    int s_n, s_oh, s_ow;
+    {
+        const int hw = a.Hout * a.Wout;
+        const int mb = min(p_begin, a.M - 1);
+        s_n = mb / hw;
+        const int r = mb - s_n * hw;
+        s_oh = r / a.Wout;
+        s_ow = r - s_oh * a.Wout;
+    }
+    int ld_pb = p_begin;
+
+    float4 ro[2], ri[2], rsc[2], rsh[2];
+    auto load_tiles = [&]() {
+        const unsigned so = (unsigned)ld_pb * (unsigned)a.Cout * 4u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ro[j] = bload(rdy, voo[j], so);
+        const int ih = s_oh + kh - a.pad;
+        const bool row_ok = (unsigned)ih < (unsigned)a.Hin;
+        const unsigned sx = row_ok ? (unsigned)(((s_n * a.Hin + ih) * a.Win) * a.Cin) * 4u : 0u;
+        const unsigned ss = (unsigned)(s_n * a.aff_stride) * 4u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int iw = s_ow + s_p[j] + kw - a.pad;
+            const bool ok = row_ok && i_ok[j] && (unsigned)iw < (unsigned)a.Win && ld_pb + s_p[j] < p_end;
+            const unsigned vx = ok ? (unsigned)((iw * a.Cin + ci0 + s_c[j]) * 4) : FAVAE_OOB;
+            ri[j] = bload(rx, vx, sx);
+            if (XFORM) {
+                const unsigned vs = ok ? vos[j] : FAVAE_OOB;
+                rsc[j] = bload(rsc_d, vs, ss);
+                rsh[j] = bload(rsh_d, vs, ss);
+            }
+        }
+        ld_pb += BKP;
+        s_ow += BKP;
+        if (s_ow >= a.Wout) {
+            s_ow = 0;
+            if (++s_oh >= a.Hout) { s_oh = 0; ++s_n; }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint2 p0, p1, p2;
+            const int off = buf * b6::OPB + s_p[j] * b6::RSB + s_c[j] * 2;
+            b6::split4(ro[j], p0, p1, p2);
+            *reinterpret_cast<uint2*>(Os + off) = p0;
+            *reinterpret_cast<uint2*>(Os + off + b6::PLB) = p1;
+            *reinterpret_cast<uint2*>(Os + off + 2 * b6::PLB) = p2;
+            b6::split4(xform4_t<XFORM>(ri[j], rsc[j], rsh[j]), p0, p1, p2);
+            *reinterpret_cast<uint2*>(Is + off) = p0;
+            *reinterpret_cast<uint2*>(Is + off + b6::PLB) = p1;
+            *reinterpret_cast<uint2*>(Is + off + 2 * b6::PLB) = p2;
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposing fragment reads: lane = 16 g + s ; pixel row 8 (g>>1) + (s>>2) (+4 for the second read), channels 16 (g&1) + 4 (s&3)
+    const int s16 = lane & 15, g = lane >> 4;
+    const int frag_off = (8 * (g >> 1) + (s16 >> 2)) * b6::RSB + (16 * (g & 1) + 4 * (s16 & 3)) * 2;
+    const unsigned char* Ofr = Os + frag_off + wo * 64 * 2;
+    const unsigned char* Ifr = Is + frag_off + wi * 64 * 2;
+
+    if (T > 0) {
+        load_tiles();
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < T; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < T) load_tiles();
+        bf16x8_t af[MI][3], bf[NI][3];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[i][p] = b6::tr_frag(Ofr + cur * b6::OPB + p * b6::PLB + i * 64);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[j][p] = b6::tr_frag(Ifr + cur * b6::OPB + p * b6::PLB + j * 64);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            }
+        if (it + 1 < T) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int ci = ci0 + wi * 64 + j * 32 + (lane & 31);
+            if (ci >= a.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wo * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < a.Cout) a.part[(((size_t)z * a.Cout + co) * taps + tap) * a.Cin + ci] = acc[i][j][r];
+            }
+        }
+}
