@@ -62,7 +62,7 @@ class ConvEventHook:
         return "conv_fwd_buf_kernel<128, 2, 2, %d, %d>" % (d.gather, xf)
 
     def __call__(self, name, args, launch):
-        if not self.enabled or name != "favae_conv_fwd":
+        if not self.enabled or name not in ("favae_conv_fwd", "favae_conv_fwd_w6"):
             return launch()
         d = args[0]._obj
         kn = self.kernel_name(d, args[5] is not None)

@@ -34,6 +34,18 @@ bool use_b6() {
     if (v < 0) { const char* e = getenv("FAVAE_CONV_B6"); v = (e && e[0] == '0') ? 0 : 1; }
     return v == 1;
 }
+// FAVAE_CONV_HALO=0 disables the LDS-halo 3x3 kernel (A/B switch)
+bool use_halo() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FAVAE_CONV_HALO"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+// FAVAE_B6_WAVES=4|8: waves per workgroup of the bf16x6 forward kernel (A/B switch)
+int b6_waves() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FAVAE_B6_WAVES"); v = (e && e[0] == '4') ? 4 : 8; }
+    return v;
+}
 // FAVAE_CONV_NOBUF=1 disables the buffer-addressed kernels (A/B against the flat-addressed fast kernels)
 bool force_nobuf() {
     static int v = -1;
@@ -61,6 +73,7 @@ struct ConvArgs {
     int kchunks;      // ceil(Cin/BK)
     int vec;          // Cin % 4 == 0 (16-byte channel loads legal)
     unsigned x_bytes, w_bytes, aff_bytes;   // operand sizes for the buffer-addressed kernels
+    int dbg;          // FAVAE_B6_ABLATE: timing ablations (results invalid): 1 no global loads, 2 no split, 3 no LDS stores
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -585,9 +598,44 @@ void wgrad_tiles(const favae_conv_desc* d, int* bco, int* bci) {
 
 }  // namespace
 
+static bool b6_fwd_eligible(const favae_conv_desc* d, bool has_affine) {
+    if (!desc_ok(d) || force_generic() || force_nobuf() || !use_b6()) return false;
+    const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, wb = (size_t)d->Cout * d->KH * d->KW * d->Cin * 6;
+    return d->Cout > 64 && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) && (d->gather == FAVAE_GATHER_PLAIN || !has_affine);
+}
+
+extern "C" int favae_conv_wants_split_weights(const favae_conv_desc* d, int has_affine) {
+    return b6_fwd_eligible(d, has_affine != 0) ? 1 : 0;
+}
+
+extern "C" int favae_split3(const float* in, void* out, int64_t n, favae_stream_t stream) {
+    FAVAE_REQUIRE(in && out && n > 0 && n % 4 == 0);
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)in, (unsigned*)out,
+                       (size_t)(n / 4));
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
+                         const float* scale, const float* shift, float* y, bool w6, favae_stream_t stream);
+
 extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const float* w, const float* bias,
                               const float* resid, const float* scale, const float* shift, float* y,
                               favae_stream_t stream) {
+    return conv_fwd_impl(d, x, w, bias, resid, scale, shift, y, false, stream);
+}
+
+extern "C" int favae_conv_fwd_w6(const favae_conv_desc* d, const float* x, const void* w6, const float* bias,
+                                 const float* resid, const float* scale, const float* shift, float* y,
+                                 favae_stream_t stream) {
+    if (!b6_fwd_eligible(d, scale != nullptr)) return FAVAE_ERR_UNSUPPORTED;
+    return conv_fwd_impl(d, x, (const float*)w6, bias, resid, scale, shift, y, true, stream);
+}
+
+static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
+                         const float* scale, const float* shift, float* y, bool w6, favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && x && w && y);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     ConvArgs a;
@@ -614,15 +662,35 @@ extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const fl
     const int xf = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_LEAKY02 ? 3 : 1)) : 0;
     const bool buf_ok = !force_generic() && !force_nobuf() && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) &&
                         (d->gather == FAVAE_GATHER_PLAIN || xf == 0);
-    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.aff_bytes = (unsigned)ab;
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)(w6 ? wb / 4 * 6 : wb); a.aff_bytes = (unsigned)ab;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("FAVAE_B6_ABLATE"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
 #define FAVAE_LAUNCH_BUF(G, X)                                                                                     \
     do {                                                                                                           \
         if (bn == 128) hipLaunchKernelGGL((conv_fwd_buf_kernel<128, 2, 2, G, X>), grid, blk, 0, s, a);             \
         else if (bn == 64) hipLaunchKernelGGL((conv_fwd_buf_kernel<64, 2, 2, G, X>), grid, blk, 0, s, a);          \
         else hipLaunchKernelGGL((conv_fwd_buf_kernel<32, 4, 1, G, X>), grid, blk, 0, s, a);                        \
     } while (0)
-    if (buf_ok && use_b6() && bn == 128) {
-#define FAVAE_LAUNCH_B6(G, X) hipLaunchKernelGGL((conv_fwd_b6_kernel<G, X>), grid, blk, 0, s, a)
+    const bool halo_ok = buf_ok && use_b6() && w6 && use_halo() && bn == 128 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
+                         d->pad == 1 && d->gather == FAVAE_GATHER_PLAIN && d->Hout == d->Hin && d->Wout == d->Win &&
+                         d->Hin % 8 == 0 && d->Win % 16 == 0;
+    if (halo_ok) {
+        a.tiles_n = cdiv(d->Cout, 128);
+        const dim3 hgrid((unsigned)(d->N * (d->Hin / 8) * (d->Win / 16) * a.tiles_n));
+        if (xf == 0) hipLaunchKernelGGL((conv3x3_halo_b6_kernel<0>), hgrid, dim3(512), 0, s, a);
+        else if (xf == 1) hipLaunchKernelGGL((conv3x3_halo_b6_kernel<1>), hgrid, dim3(512), 0, s, a);
+        else if (xf == 2) hipLaunchKernelGGL((conv3x3_halo_b6_kernel<2>), hgrid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_halo_b6_kernel<3>), hgrid, dim3(512), 0, s, a);
+    } else if (buf_ok && use_b6() && bn == 128) {
+#define FAVAE_LAUNCH_B6(G, X)                                                                     \
+    do {                                                                                          \
+        if (b6_waves() == 8) {                                                                    \
+            if (w6) hipLaunchKernelGGL((conv_fwd_b6_kernel<G, X, true, 8>), grid, dim3(512), 0, s, a);   \
+            else hipLaunchKernelGGL((conv_fwd_b6_kernel<G, X, false, 8>), grid, dim3(512), 0, s, a);     \
+        } else {                                                                                  \
+            if (w6) hipLaunchKernelGGL((conv_fwd_b6_kernel<G, X, true, 4>), grid, blk, 0, s, a);  \
+            else hipLaunchKernelGGL((conv_fwd_b6_kernel<G, X, false, 4>), grid, blk, 0, s, a);    \
+        }                                                                                         \
+    } while (0)
         if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_B6(FAVAE_GATHER_UPSAMPLE2, 0);
         else if (d->gather == FAVAE_GATHER_DILATE2) FAVAE_LAUNCH_B6(FAVAE_GATHER_DILATE2, 0);
         else if (xf == 0) FAVAE_LAUNCH_B6(FAVAE_GATHER_PLAIN, 0);

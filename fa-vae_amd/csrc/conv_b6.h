@@ -33,15 +33,21 @@ __device__ __forceinline__ void split4(const float4 v, uint2& p0, uint2& p1, uin
 }
 }  // namespace b6
 
-template <int GATHER, int XFORM>
-__global__ __launch_bounds__(256) void conv_fwd_b6_kernel(ConvArgs a) {
-    constexpr int BN = 128, WTM = 64, WTN = 64, MI = 2, NI = 2;
+// W6: the weight operand arrives pre-split (favae_split3: 24-byte records {plane0[4], plane1[4], plane2[4]} per 4 floats),
+// so the B tile is a pure copy global -> LDS and only the activation tile is split in the K loop.
+// NW = waves per workgroup: 4 (2x2 waves of 64x64) or 8 (4x2 waves of 32x64: twice the resident waves for the same LDS
+// footprint, which is what hides the load -> split -> ds_write -> barrier -> ds_read chain of this short-MFMA kernel).
+template <int GATHER, int XFORM, bool W6, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_fwd_b6_kernel(ConvArgs a) {
+    constexpr int BN = 128, WTM = (NW == 4 ? 64 : 32), WTN = 64, MI = WTM / 32, NI = 2;
+    constexpr int R = 8 / NW;                      // staged rows per thread and operand (128 rows x 4 quads / threads)
+    constexpr int RSTEP = 16 * NW;                 // row distance between a thread's staged rows
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * b6::ROWB];
     unsigned char* As = lds;
     unsigned char* Bs = lds + 2 * BM * b6::ROWB;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid >> 1, wn = wid & 1;          // NW/2 x 2 waves
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
     const int q4 = tid & 3, c4 = q4 * 4;
@@ -52,13 +58,13 @@ __global__ __launch_bounds__(256) void conv_fwd_b6_kernel(ConvArgs a) {
     const auto rsc_d = make_rsrc(XFORM ? a.scale : a.x, XFORM ? a.aff_bytes : 0u);
     const auto rsh_d = make_rsrc(XFORM ? a.shift : a.x, XFORM ? a.aff_bytes : 0u);
 
-    int r_n[2], r_oh[2], r_ow[2];
-    bool r_ok[2];
+    int r_n[R], r_oh[R], r_ow[R];
+    bool r_ok[R];
     {
         const int hw = a.Hout * a.Wout;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m = m0 + (tid >> 2) + 64 * j;
+        for (int j = 0; j < R; ++j) {
+            const int m = m0 + (tid >> 2) + RSTEP * j;
             r_ok[j] = m < a.M;
             const int mm = r_ok[j] ? m : 0;
             r_n[j] = mm / hw;
@@ -67,18 +73,18 @@ __global__ __launch_bounds__(256) void conv_fwd_b6_kernel(ConvArgs a) {
             r_ow[j] = r - r_oh[j] * a.Wout;
         }
     }
-    unsigned vob[2];
+    unsigned vob[R];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (tid >> 2) + 64 * j;
-        vob[j] = (n0 + row < a.Cout) ? (unsigned)(((n0 + row) * taps * a.Cin + c4) * 4) : FAVAE_OOB;
+    for (int j = 0; j < R; ++j) {
+        const int row = (tid >> 2) + RSTEP * j;
+        vob[j] = (n0 + row < a.Cout) ? (unsigned)(((n0 + row) * taps * a.Cin + c4) * (W6 ? 6 : 4)) : FAVAE_OOB;
     }
-    unsigned voa[2], vos[2];
+    unsigned voa[R], vos[R];
     int ld_tap = 0, ld_kc = 0;
     auto tap_state = [&](int tap) {
         const int kh = tap / a.KW, kw = tap - kh * a.KW;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < R; ++j) {
             int sh, sw;
             const bool ok = r_ok[j] && gather_src_t<GATHER>(a.stride, a.pad, a.Hin, a.Win, r_oh[j], r_ow[j], kh, kw, sh, sw);
             voa[j] = ok ? (unsigned)((((r_n[j] * a.Hin + sh) * a.Win + sw) * a.Cin + c4) * 4) : FAVAE_OOB;
@@ -87,18 +93,21 @@ __global__ __launch_bounds__(256) void conv_fwd_b6_kernel(ConvArgs a) {
     };
     tap_state(0);
 
-    float4 ra[2], rsc[2], rsh[2], rb[2];
+    float4 ra[R], rsc[R], rsh[R], rb[R];
+    uint2 rb2[R];
     auto load_tiles = [&]() {
         const unsigned sk = (unsigned)(ld_kc * BK * 4);
-        const unsigned sw = (unsigned)((ld_tap * a.Cin + ld_kc * BK) * 4);
+        const unsigned sw = (unsigned)((ld_tap * a.Cin + ld_kc * BK) * (W6 ? 6 : 4));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < R; ++j) {
+            if (a.dbg == 1) break;
             ra[j] = bload(rx, voa[j], sk);
             if (XFORM) {
                 rsc[j] = bload(rsc_d, vos[j], sk);
                 rsh[j] = bload(rsh_d, vos[j], sk);
             }
-            rb[j] = bload(rw, vob[j], sw);
+            rb[j] = bload(rw, vob[j], sw);                       // W6: planes 0 and 1 (16 B)
+            if (W6) rb2[j] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rw, vob[j] + 16u, sw, 0));
         }
         if (++ld_kc == a.kchunks) {
             ld_kc = 0;
@@ -107,15 +116,23 @@ __global__ __launch_bounds__(256) void conv_fwd_b6_kernel(ConvArgs a) {
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = (tid >> 2) + 64 * j;
+        for (int j = 0; j < R; ++j) {
+            const int row = (tid >> 2) + RSTEP * j;
             uint2 p0, p1, p2;
-            b6::split4(xform4_t<XFORM>(ra[j], rsc[j], rsh[j]), p0, p1, p2);
+            if (a.dbg == 3) continue;
+            if (a.dbg == 2) { p0 = make_uint2(__float_as_uint(ra[j].x), __float_as_uint(ra[j].y)); p1 = p0; p2 = p0; }
+            else b6::split4(xform4_t<XFORM>(ra[j], rsc[j], rsh[j]), p0, p1, p2);
             unsigned char* d = As + (buf * BM + row) * b6::ROWB + q4 * 8;
             *reinterpret_cast<uint2*>(d) = p0;
             *reinterpret_cast<uint2*>(d + 32) = p1;
             *reinterpret_cast<uint2*>(d + 64) = p2;
-            b6::split4(rb[j], p0, p1, p2);
+            if (W6) {
+                p0 = make_uint2(__float_as_uint(rb[j].x), __float_as_uint(rb[j].y));
+                p1 = make_uint2(__float_as_uint(rb[j].z), __float_as_uint(rb[j].w));
+                p2 = rb2[j];
+            } else {
+                b6::split4(rb[j], p0, p1, p2);
+            }
             d = Bs + (buf * BN + row) * b6::ROWB + q4 * 8;
             *reinterpret_cast<uint2*>(d) = p0;
             *reinterpret_cast<uint2*>(d + 32) = p1;
@@ -363,4 +380,173 @@ __global__ __launch_bounds__(256) void conv_wgrad_b6_kernel(WgradArgs a) {
                 if (co < a.Cout) a.part[(((size_t)z * a.Cout + co) * taps + tap) * a.Cin + ci] = acc[i][j][r];
             }
         }
+}
+
+
+// out: 24-byte records {plane0[4 bf16], plane1[4], plane2[4]} per 4 consecutive floats of `in` (n % 4 == 0)
+__global__ __launch_bounds__(256) void split3_kernel(const float4* __restrict__ in, unsigned* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        uint2 p0, p1, p2;
+        b6::split4(in[i], p0, p1, p2);
+        unsigned* o = out + i * 6;
+        o[0] = p0.x; o[1] = p0.y; o[2] = p1.x; o[3] = p1.y; o[4] = p2.x; o[5] = p2.y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution with an LDS-staged halo tile (the "LDS-staged 3x3 input tiles" of the north star).
+// A workgroup owns an 8 x 16 pixel tile (= the 128 MFMA rows) x 128 output channels.  Per 16-channel K chunk the
+// (8+2) x (16+2) = 180-pixel input halo is loaded, transformed (fused GroupNorm/SiLU) and split into bf16 planes ONCE and
+// then serves all 9 filter taps as shifted views -- 6.4x fewer activation loads / transforms / splits / LDS stores than the
+// tap-by-tap im2col staging of conv_fwd_b6_kernel (timing ablations: those were ~35 % of that kernel).  Weights arrive
+// pre-split (W6) and are streamed tap by tap through a second, double-buffered LDS tile.
+// Per-thread global offsets are constants of the launch: only the scalar offsets advance (K chunk, tap).
+// Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, H % 8 == 0, W % 16 == 0, Cin % 16 == 0, W6 weights.
+// ---------------------------------------------------------------------------------------------------------------
+template <int XFORM>
+__global__ __launch_bounds__(512) void conv3x3_halo_b6_kernel(ConvArgs a) {
+    constexpr int TH = 8, TW = 16, HW = TW + 2, HROWS = (TH + 2) * HW;          // 180 halo pixels
+    constexpr int HALO_B = HROWS * b6::ROWB, BT_B = 128 * b6::ROWB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO_B + 2 * BT_B];
+    unsigned char* Hs = lds;                    // [2][180][112]
+    unsigned char* Bs = lds + 2 * HALO_B;       // [2][128][112]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;      // 4 x 2 waves of 32 x 64
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % a.tiles_n;
+    int sp = tile / a.tiles_n;                  // spatial tile index
+    const int tiles_w = a.Win / TW, tiles_h = a.Hin / TH;
+    const int tx0 = (sp % tiles_w) * TW; sp /= tiles_w;
+    const int ty0 = (sp % tiles_h) * TH;
+    const int n = sp / tiles_h;
+    const int n0 = tn * 128;
+    const int q4 = tid & 3;
+
+    const auto rx = make_rsrc(a.x, a.x_bytes);
+    const auto rw = make_rsrc(a.w, a.w_bytes);
+    const auto rsc_d = make_rsrc(XFORM ? a.scale : a.x, XFORM ? a.aff_bytes : 0u);
+    const auto rsh_d = make_rsrc(XFORM ? a.shift : a.x, XFORM ? a.aff_bytes : 0u);
+
+    // halo staging slots of this thread (720 float4 over 512 threads): constant offsets
+    unsigned vh[2], vs[2];
+    int hrow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + 512 * j;
+        hrow[j] = i >> 2;
+        const int hy = hrow[j] / HW, hx = hrow[j] - hy * HW;
+        const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+        const bool ok = hrow[j] < HROWS && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
+        vh[j] = ok ? (unsigned)((((n * a.Hin + y) * a.Win + x) * a.Cin + q4 * 4) * 4) : FAVAE_OOB;
+        vs[j] = ok ? (unsigned)((n * a.aff_stride + q4 * 4) * 4) : FAVAE_OOB;
+    }
+    const int brow = tid >> 2;                                           // weight row (output channel) staged by this thread
+    const unsigned vb = (n0 + brow < a.Cout) ? (unsigned)(((n0 + brow) * 9 * a.Cin + q4 * 4) * 6) : FAVAE_OOB;
+
+    float4 rh[2], rsc[2], rsh[2], rb;
+    uint2 rb2;
+    auto load_halo = [&](int kc) {
+        const unsigned sk = (unsigned)(kc * 64);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1 && tid >= HROWS * 4 - 512) continue;              // second slot exists for the first 208 threads only
+            rh[j] = bload(rx, vh[j], sk);
+            if (XFORM) {
+                rsc[j] = bload(rsc_d, vs[j], sk);
+                rsh[j] = bload(rsh_d, vs[j], sk);
+            }
+        }
+    };
+    auto store_halo = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1 && tid >= HROWS * 4 - 512) continue;
+            uint2 p0, p1, p2;
+            b6::split4(xform4_t<XFORM>(rh[j], rsc[j], rsh[j]), p0, p1, p2);
+            unsigned char* d = Hs + buf * HALO_B + hrow[j] * b6::ROWB + q4 * 8;
+            *reinterpret_cast<uint2*>(d) = p0;
+            *reinterpret_cast<uint2*>(d + 32) = p1;
+            *reinterpret_cast<uint2*>(d + 64) = p2;
+        }
+    };
+    auto load_b = [&](int kc, int tap) {
+        const unsigned sw = (unsigned)((tap * a.Cin + kc * 16) * 6);
+        rb = bload(rw, vb, sw);
+        rb2 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rw, vb + 16u, sw, 0));
+    };
+    auto store_b = [&](int buf) {
+        unsigned char* d = Bs + buf * BT_B + brow * b6::ROWB + q4 * 8;
+        *reinterpret_cast<uint2*>(d) = make_uint2(__float_as_uint(rb.x), __float_as_uint(rb.y));
+        *reinterpret_cast<uint2*>(d + 32) = make_uint2(__float_as_uint(rb.z), __float_as_uint(rb.w));
+        *reinterpret_cast<uint2*>(d + 64) = rb2;
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // fragment addressing: MFMA row = pixel p = wm*32 + (lane&31) of the 8x16 tile -> halo row (ty+kh)*18 + tx+kw
+    const int p = wm * 32 + (lane & 31);
+    const int fh = (lane >> 5) * 16;
+    const unsigned char* Afr = Hs + ((p >> 4) * HW + (p & 15)) * b6::ROWB + fh;
+    const unsigned char* Bfr = Bs + (wn * 64 + (lane & 31)) * b6::ROWB + fh;
+
+    const int KC = a.Cin / 16;
+    load_halo(0);
+    load_b(0, 0);
+    store_halo(0);
+    store_b(0);
+    __syncthreads();
+    int it = 0;
+    for (int kc = 0; kc < KC; ++kc) {
+        const int hb = kc & 1;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++it) {
+            const int cur = it & 1;
+            const bool last_tap = tap == 8, more_kc = kc + 1 < KC;
+            if (!last_tap) load_b(kc, tap + 1);
+            else if (more_kc) load_b(kc + 1, 0);
+            if (tap == 4 && more_kc) load_halo(kc + 1);                  // in flight over taps 4..8
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const unsigned char* Ab = Afr + hb * HALO_B + (kh * HW + kw) * b6::ROWB;
+            const unsigned char* Bb = Bfr + cur * BT_B;
+            bf16x8_t af[3], bf[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8_t*>(Ab + pl * 32);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8_t*>(Bb + j * 32 * b6::ROWB + pl * 32);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[j][0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][0], acc[j], 0, 0, 0);
+            }
+            if (!last_tap || more_kc) store_b(cur ^ 1);
+            if (last_tap && more_kc) store_halo(hb ^ 1);
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (col >= a.Cout) continue;
+        const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);          // pixel of the tile
+            const size_t o = ((size_t)((n * a.Hin + ty0 + (pr >> 4)) * a.Win + tx0 + (pr & 15))) * a.Cout + col;
+            float v = acc[j][r] + bv;
+            if (a.resid) v += a.resid[o];
+            a.y[o] = v;
+        }
+    }
 }

@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfavae_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02 = 0, 1, 2
@@ -32,6 +32,9 @@ _P, _S = c_void_p, c_void_p
 SIGNATURES = {
     "favae_abi_version": (c_int, []),
     "favae_conv_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _S]),
+    "favae_conv_wants_split_weights": (c_int, [POINTER(ConvDesc), c_int]),
+    "favae_split3": (c_int, [_P, _P, c_int64, _S]),
+    "favae_conv_fwd_w6": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _S]),
     "favae_conv_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "favae_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, c_int, _P, c_size_t, _S]),
     "favae_weight_flip": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),

@@ -157,6 +157,18 @@ class ConvCfg:
         return Ho, Wo
 
 
+def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y):
+    """conv forward / data gradient; weights are pre-split into the 3 x bf16 record format when the library runs this
+    shape on the bf16x6 matrix path (the split is then done once per call instead of once per tile in the K loop)."""
+    if query("favae_conv_wants_split_weights", byref(d), 0 if scale is None else 1):
+        n = w_ohwi.numel()
+        w6 = torch.empty((n // 4) * 24, dtype=torch.uint8, device=w_ohwi.device)
+        call("favae_split3", ptr(w_ohwi), ptr(w6), n)
+        call("favae_conv_fwd_w6", byref(d), ptr(x), ptr(w6), ptr(b), ptr(resid), ptr(scale), ptr(shift), ptr(y))
+    else:
+        call("favae_conv_fwd", byref(d), ptr(x), ptr(w_ohwi), ptr(b), ptr(resid), ptr(scale), ptr(shift), ptr(y))
+
+
 class FusedConvFn(torch.autograd.Function):
     """y = conv(act(GN(x)), w) + b + resid   -- GN/act optional (gn_w is None -> plain conv).
 
@@ -180,7 +192,7 @@ class FusedConvFn(torch.autograd.Function):
         y = new_cl(N, Cout, Ho, Wo, dev)
         d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad,
                            GATHER_UPSAMPLE2 if cfg.upsample else GATHER_PLAIN, cfg.act if gn_w is not None else ACT_NONE, 1)
-        call("favae_conv_fwd", byref(d), ptr(x), ptr(wk), ptr(b), ptr(resid), ptr(scale), ptr(shift), ptr(y))
+        _conv_launch(d, x, wk, b, resid, scale, shift, y)
         ctx.cfg = cfg
         ctx.has_b = b is not None
         ctx.has_gn = gn_w is not None
@@ -235,7 +247,7 @@ class FusedConvFn(torch.autograd.Function):
                 raise RuntimeError("unsupported conv geometry for the data gradient")
             da = new_cl(N, Cin, Hv, Wv, dev)
             d2 = make_conv_desc(N, Ho, Wo, Cout, Hv, Wv, Cin, cfg.kh, cfg.kw, 1, pad2, g2, ACT_NONE, 1)
-            call("favae_conv_fwd", byref(d2), ptr(dy), ptr(wt), None, None, None, None, ptr(da))
+            _conv_launch(d2, dy, wt, None, None, None, None, da)
             if cfg.upsample:
                 dlow = new_cl(N, Cin, Hin, Win, dev)
                 call("favae_upsample2x_bwd", ptr(da), ptr(dlow), N, Hin, Win, Cin)

@@ -68,6 +68,14 @@ typedef struct {
 int favae_conv_fwd(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                    const float* scale, const float* shift, float* y, favae_stream_t stream);
 
+/* Pre-split weight path (exact 3 x bf16 operand split): favae_conv_wants_split_weights() tells whether the
+ * library would run this conv on the bf16x6 matrix path; if so the caller may split the OHWI weights once with
+ * favae_split3() (out = 6 bytes per input float) and call favae_conv_fwd_w6() -- same semantics as favae_conv_fwd. */
+int favae_conv_wants_split_weights(const favae_conv_desc* d, int has_affine);
+int favae_split3(const float* in, void* out, int64_t n, favae_stream_t stream);
+int favae_conv_fwd_w6(const favae_conv_desc* d, const float* x, const void* w6, const float* bias, const float* resid,
+                      const float* scale, const float* shift, float* y, favae_stream_t stream);
+
 /* dw[co][kh][kw][ci] = sum_{n,oh,ow} dy[n,oh,ow,co] * T(x)[gathered (n,oh,ow,kh,kw), ci]   (split-K, deterministic:
  * partial slabs in `ws`, summed in a fixed order).  autograd's convolution_backward weight path. */
 size_t favae_conv_wgrad_workspace(const favae_conv_desc* d);

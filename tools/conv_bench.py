@@ -34,12 +34,12 @@ for cin, cout, hw, k in SHAPES:
     y = K.new_cl(B, cout, hw, hw, dev)
     d = H.make_conv_desc(B, hw, hw, cin, hw, hw, cout, k, k, 1, k // 2, 0, H.ACT_SILU, 1)
     flops = 2.0 * B * hw * hw * cout * k * k * cin
-    t_f = timeit(lambda: H.call("favae_conv_fwd", byref(d), H.ptr(x), H.ptr(w), H.ptr(b), None, H.ptr(scale), H.ptr(shift), H.ptr(y)))
+    t_f = timeit(lambda: K._conv_launch(d, x, w, b, None, scale, shift, y))
     wt = torch.empty(cin, k, k, cout, device=dev)
     H.call("favae_weight_flip", H.ptr(w), H.ptr(wt), cout, k, k, cin)
     d2 = H.make_conv_desc(B, hw, hw, cout, hw, hw, cin, k, k, 1, k // 2, 0, 0, 1)
     dx = K.new_cl(B, cin, hw, hw, dev)
-    t_d = timeit(lambda: H.call("favae_conv_fwd", byref(d2), H.ptr(y), H.ptr(wt), None, None, None, None, H.ptr(dx)))
+    t_d = timeit(lambda: K._conv_launch(d2, y, wt, None, None, None, None, dx))
     dw = torch.empty(cout, k, k, cin, device=dev)
     ws = H.workspace(H.query("favae_conv_wgrad_workspace", byref(d)), dev)
     t_w = timeit(lambda: H.call("favae_conv_wgrad", byref(d), H.ptr(x), H.ptr(y), H.ptr(scale), H.ptr(shift), H.ptr(dw), 0, H.ptr(ws), ws.numel()))
