@@ -763,7 +763,8 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, yb = (size_t)d->N * d->Hout * d->Wout * d->Cout * 4;
     const size_t ab = (size_t)(d->affine_per_image ? d->N : 1) * d->Cin * 4;
     const int xf = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_LEAKY02 ? 3 : 1)) : 0;
-    const bool buf_ok = !force_generic() && !force_nobuf() && a.vec_i && a.vec_o && d->gather == FAVAE_GATHER_PLAIN &&
+    const bool ups_b6 = d->gather == FAVAE_GATHER_UPSAMPLE2 && xf == 0 && use_b6() && bco == 128 && bci == 128;
+    const bool buf_ok = !force_generic() && !force_nobuf() && a.vec_i && a.vec_o && (d->gather == FAVAE_GATHER_PLAIN || ups_b6) &&
                         d->stride == 1 && d->Wout % 16 == 0 && xb < (1u << 31) && yb < (1u << 31) && xf != 3;
     a.x_bytes = (unsigned)xb; a.aff_bytes = (unsigned)ab;
 #define FAVAE_LAUNCH_WBUF(X)                                                                                       \
@@ -773,10 +774,11 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
         else hipLaunchKernelGGL((conv_wgrad_buf_kernel<128, 32, 4, 1, X>), grid, dim3(256), 0, s, a);                           \
     } while (0)
     if (buf_ok && use_b6() && bco == 128 && bci == 128) {
-        if (xf == 0) hipLaunchKernelGGL((conv_wgrad_b6_kernel<0>), grid, dim3(256), 0, s, a);
-        else if (xf == 1) hipLaunchKernelGGL((conv_wgrad_b6_kernel<1>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv_wgrad_b6_kernel<2>), grid, dim3(256), 0, s, a);
-    } else if (buf_ok) {
+        if (d->gather == FAVAE_GATHER_UPSAMPLE2) hipLaunchKernelGGL((conv_wgrad_b6_kernel<0, true>), grid, dim3(256), 0, s, a);
+        else if (xf == 0) hipLaunchKernelGGL((conv_wgrad_b6_kernel<0, false>), grid, dim3(256), 0, s, a);
+        else if (xf == 1) hipLaunchKernelGGL((conv_wgrad_b6_kernel<1, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_wgrad_b6_kernel<2, false>), grid, dim3(256), 0, s, a);
+    } else if (buf_ok && d->gather == FAVAE_GATHER_PLAIN) {
         if (xf == 0) FAVAE_LAUNCH_WBUF(0);
         else if (xf == 1) FAVAE_LAUNCH_WBUF(1);
         else FAVAE_LAUNCH_WBUF(2);

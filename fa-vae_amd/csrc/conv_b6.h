@@ -229,7 +229,8 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* p) {
 }
 }  // namespace b6
 
-template <int XFORM>
+// UPS: the conv input is the nearest-x2 upsampling of x (Upsample, models/codec.py:17) -- source pixel = virtual >> 1
+template <int XFORM, bool UPS>
 __global__ __launch_bounds__(256) void conv_wgrad_b6_kernel(WgradArgs a) {
     constexpr int BCO = 128, BCI = 128, BKP = 16, MI = 2, NI = 2;
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * b6::OPB];
@@ -284,14 +285,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_b6_kernel(WgradArgs a) {
         const unsigned so = (unsigned)ld_pb * (unsigned)a.Cout * 4u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) ro[j] = bload(rdy, voo[j], so);
-        const int ih = s_oh + kh - a.pad;
-        const bool row_ok = (unsigned)ih < (unsigned)a.Hin;
+        const int vh = s_oh + kh - a.pad;
+        const bool row_ok = (unsigned)vh < (unsigned)(UPS ? 2 * a.Hin : a.Hin);
+        const int ih = UPS ? vh >> 1 : vh;
         const unsigned sx = row_ok ? (unsigned)(((s_n * a.Hin + ih) * a.Win) * a.Cin) * 4u : 0u;
         const unsigned ss = (unsigned)(s_n * a.aff_stride) * 4u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int iw = s_ow + s_p[j] + kw - a.pad;
-            const bool ok = row_ok && i_ok[j] && (unsigned)iw < (unsigned)a.Win && ld_pb + s_p[j] < p_end;
+            const int vw = s_ow + s_p[j] + kw - a.pad;
+            const int iw = UPS ? vw >> 1 : vw;
+            const bool ok = row_ok && i_ok[j] && (unsigned)vw < (unsigned)(UPS ? 2 * a.Win : a.Win) && ld_pb + s_p[j] < p_end;
             const unsigned vx = ok ? (unsigned)((iw * a.Cin + ci0 + s_c[j]) * 4) : FAVAE_OOB;
             ri[j] = bload(rx, vx, sx);
             if (XFORM) {
