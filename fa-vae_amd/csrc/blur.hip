@@ -61,10 +61,12 @@ __device__ __forceinline__ int preimages(int i, int n, int p, int (&j)[3]) {
     return c;
 }
 
-template <int MODE>   // 0 forward, 1 backward
+// KS: compile-time kernel size (3, 5, 9, ...) so that the k-tap loops fully unroll and their LDS reads are issued back to
+// back instead of one per loop trip (the runtime-k version was LDS-latency bound); KS = 0 keeps k a runtime value.
+template <int MODE, int KS>   // MODE 0 forward, 1 backward
 __global__ __launch_bounds__(256) void blur_sep_kernel(BlurArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int k = a.k, p = k / 2, CC = a.CC;
+    const int k = KS ? KS : a.k, p = k / 2, CC = a.CC;
     const int HH = a.TH + k - 1, HW = a.TW + k - 1;
     float* g = sm;                                   // [32]
     float* red = sm + 32;                            // [2*MAXK][4] cross-wave partials (backward)
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(256) void blur_sep_kernel(BlurArgs a) {
             const int hy = q / a.TW, x = q - hy * a.TW;
             const float* row = Xh + (hy * HW + x) * CC + c;
             float acc = 0.f;
+#pragma unroll
             for (int v = 0; v < k; ++v) acc = fmaf(g[v], row[v * CC], acc);
             U[q * CC + c] = acc;
         }
@@ -120,6 +123,7 @@ __global__ __launch_bounds__(256) void blur_sep_kernel(BlurArgs a) {
             float acc = 0.f;
             if (int_y) {                                  // interior tile: no fold, no bounds -> k taps straight down the column
                 const float* col = Dh + ((yy + 2 * p) * HW + hx) * CC + c;
+#pragma unroll
                 for (int u = 0; u < k; ++u) acc = fmaf(g[u], col[-u * HW * CC], acc);
             } else if (y < a.H) {
                 int jy[3];
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(256) void blur_sep_kernel(BlurArgs a) {
             if (y0 + py >= a.H || x0 + px >= a.W) continue;
             const float* col = U + (py * a.TW + px) * CC + c;
             float acc = 0.f;
+#pragma unroll
             for (int u = 0; u < k; ++u) acc = fmaf(g[u], col[u * a.TW * CC], acc);
             out[((size_t)(y0 + py) * a.W + x0 + px) * a.C + c0 + c] = acc;
         }
@@ -160,6 +165,7 @@ __global__ __launch_bounds__(256) void blur_sep_kernel(BlurArgs a) {
             float acc = 0.f;
             if (int_x) {
                 const float* row = V + (py * HW + px + 2 * p) * CC + c;
+#pragma unroll
                 for (int v = 0; v < k; ++v) acc = fmaf(g[v], row[-v * CC], acc);
                 out[((size_t)y * a.W + x) * a.C + c0 + c] = acc;
                 continue;
@@ -272,10 +278,21 @@ extern "C" int favae_blur_fwd(const float* x, const float* sigma, int ksize, int
     a.x = x; a.sigma = sigma; a.y = y;
     const size_t shm = shm_floats(a, false) * sizeof(float);
     static bool attr0 = false;
-    if (!attr0) { (void)hipFuncSetAttribute((const void*)blur_sep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr0 = true; }
+    if (!attr0) {
+        (void)hipFuncSetAttribute((const void*)blur_sep_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)blur_sep_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)blur_sep_kernel<0, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)blur_sep_kernel<0, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr0 = true;
+    }
     const long grid = (long)N * a.tiles_h * a.tiles_w * a.cchunks;
     if (grid >= (1L << 31)) return FAVAE_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((blur_sep_kernel<0>), dim3((unsigned)grid), dim3(256), shm, (hipStream_t)stream, a);
+    const dim3 g3((unsigned)grid), b3(256);
+    hipStream_t s0 = (hipStream_t)stream;
+    if (ksize == 9) hipLaunchKernelGGL((blur_sep_kernel<0, 9>), g3, b3, shm, s0, a);
+    else if (ksize == 5) hipLaunchKernelGGL((blur_sep_kernel<0, 5>), g3, b3, shm, s0, a);
+    else if (ksize == 3) hipLaunchKernelGGL((blur_sep_kernel<0, 3>), g3, b3, shm, s0, a);
+    else hipLaunchKernelGGL((blur_sep_kernel<0, 0>), g3, b3, shm, s0, a);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -305,9 +322,19 @@ extern "C" int favae_blur_bwd(const float* x, const float* dy, const float* sigm
     a.x = x; a.dy = dy; a.sigma = sigma; a.dx = dx; a.part = dsigma ? part : nullptr;
     const size_t shm = shm_floats(a, true) * sizeof(float);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)blur_sep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)blur_sep_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)blur_sep_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)blur_sep_kernel<1, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)blur_sep_kernel<1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL((blur_sep_kernel<1>), dim3((unsigned)grid), dim3(256), shm, s, a);
+    const dim3 g3((unsigned)grid), b3(256);
+    if (ksize == 9) hipLaunchKernelGGL((blur_sep_kernel<1, 9>), g3, b3, shm, s, a);
+    else if (ksize == 5) hipLaunchKernelGGL((blur_sep_kernel<1, 5>), g3, b3, shm, s, a);
+    else if (ksize == 3) hipLaunchKernelGGL((blur_sep_kernel<1, 3>), g3, b3, shm, s, a);
+    else hipLaunchKernelGGL((blur_sep_kernel<1, 0>), g3, b3, shm, s, a);
     FAVAE_CHECK_LAUNCH();
     if (dsigma) {
         int rc = favae_colsum(part, dgv, grid, ksize, 0, p2, cws, stream);
