@@ -34,6 +34,12 @@ bool use_b6() {
     if (v < 0) { const char* e = getenv("FAVAE_CONV_B6"); v = (e && e[0] == '0') ? 0 : 1; }
     return v == 1;
 }
+// FAVAE_WGRAD_ROW3=0 disables the three-taps-per-workgroup weight-gradient kernel (A/B switch)
+bool use_row3() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FAVAE_WGRAD_ROW3"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
 // FAVAE_CONV_HALO=0 disables the LDS-halo 3x3 kernel (A/B switch)
 bool use_halo() {
     static int v = -1;
@@ -773,7 +779,16 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
         else if (bco == 32) hipLaunchKernelGGL((conv_wgrad_buf_kernel<32, 128, 1, 4, X>), grid, dim3(256), 0, s, a);            \
         else hipLaunchKernelGGL((conv_wgrad_buf_kernel<128, 32, 4, 1, X>), grid, dim3(256), 0, s, a);                           \
     } while (0)
-    if (buf_ok && use_b6() && bco == 128 && bci == 128) {
+    const bool row3 = buf_ok && use_b6() && use_row3() && bco == 128 && bci == 128 && d->gather == FAVAE_GATHER_PLAIN &&
+                      d->KH == 3 && d->KW == 3 && d->pad == 1;
+    if (row3) {
+        // three taps per workgroup: grid.x = tiles * 3 filter rows; split-K sized for the smaller grid
+        const int tiles3 = a.tiles_co * a.tiles_ci * 3;
+        const dim3 g3(tiles3, a.splitk);
+        if (xf == 0) hipLaunchKernelGGL((conv_wgrad_row3_b6_kernel<0>), g3, dim3(512), 0, s, a);
+        else if (xf == 1) hipLaunchKernelGGL((conv_wgrad_row3_b6_kernel<1>), g3, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((conv_wgrad_row3_b6_kernel<2>), g3, dim3(512), 0, s, a);
+    } else if (buf_ok && use_b6() && bco == 128 && bci == 128) {
         if (d->gather == FAVAE_GATHER_UPSAMPLE2) hipLaunchKernelGGL((conv_wgrad_b6_kernel<0, true>), grid, dim3(256), 0, s, a);
         else if (xf == 0) hipLaunchKernelGGL((conv_wgrad_b6_kernel<0, false>), grid, dim3(256), 0, s, a);
         else if (xf == 1) hipLaunchKernelGGL((conv_wgrad_b6_kernel<1, false>), grid, dim3(256), 0, s, a);

@@ -553,3 +553,159 @@ __global__ __launch_bounds__(512) void conv3x3_halo_b6_kernel(ConvArgs a) {
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 weight gradient, three taps per workgroup: a workgroup owns (128 co x 128 ci, one filter ROW kh) and accumulates the
+// taps kw = 0,1,2 together.  Per 16-pixel step it stages ONE dy tile (16 px) and ONE 18-pixel input halo row, which serve
+// the three taps as shifted pixel windows of the transposing fragment reads -- 2.8x fewer loads / transforms / splits /
+// LDS stores per MFMA than the tap-per-workgroup conv_wgrad_b6_kernel.  8 waves (4 co x 2 ci, 32 x 64 each, 3 taps).
+// Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, Wout % 16 == 0, channels % 4 == 0, operands < 2 GiB.
+// ---------------------------------------------------------------------------------------------------------------
+template <int XFORM>
+__global__ __launch_bounds__(512) void conv_wgrad_row3_b6_kernel(WgradArgs a) {
+    constexpr int OPL = 16 * b6::RSB, IPL = 18 * b6::RSB;           // bytes per plane (dy: 16 px, x: 18 px)
+    constexpr int OB = 3 * OPL, IB = 3 * IPL;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (OB + IB)];
+    unsigned char* Os = lds;
+    unsigned char* Is = lds + 2 * OB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wo = wid >> 1, wi = wid & 1;
+    int t = blockIdx.x;
+    const int kh = t % 3; t /= 3;
+    const int ci0 = (t % a.tiles_ci) * 128;
+    const int co0 = (t / a.tiles_ci) * 128;
+    const int z = blockIdx.y;
+    const int p_begin = z * a.chunk;
+    const int p_end = min(a.M, p_begin + a.chunk);
+    const int T = (p_end > p_begin) ? (p_end - p_begin + 15) / 16 : 0;
+
+    const auto rx = make_rsrc(a.x, a.x_bytes);
+    const auto rdy = make_rsrc(a.dy, (unsigned)p_end * (unsigned)a.Cout * 4u);
+    const auto rsc_d = make_rsrc(XFORM ? a.scale : a.x, XFORM ? a.aff_bytes : 0u);
+    const auto rsh_d = make_rsrc(XFORM ? a.shift : a.x, XFORM ? a.aff_bytes : 0u);
+
+    const int sp = tid >> 5, sq = (tid & 31) * 4;                   // staging slot: pixel (0..15), channel
+    const bool two = tid < 64;                                      // second x slot: halo pixels 16, 17
+    const unsigned voo = (co0 + sq < a.Cout) ? (unsigned)((sp * a.Cout + co0 + sq) * 4) : FAVAE_OOB;
+    const bool ci_ok = ci0 + sq < a.Cin;
+    const unsigned vsc = (unsigned)((ci0 + sq) * 4);
+
+    int s_n, s_oh, s_ow;
+    {
+        const int hw = a.Hout * a.Wout;
+        const int mb = min(p_begin, a.M - 1);
+        s_n = mb / hw;
+        const int r = mb - s_n * hw;
+        s_oh = r / a.Wout;
+        s_ow = r - s_oh * a.Wout;
+    }
+    int ld_pb = p_begin;
+
+    float4 ro, ri[2], rsc[2], rsh[2];
+    auto load_tiles = [&]() {
+        ro = bload(rdy, voo, (unsigned)ld_pb * (unsigned)a.Cout * 4u);
+        const int ih = s_oh + kh - 1;
+        const bool row_ok = (unsigned)ih < (unsigned)a.Hin;
+        const unsigned sx = row_ok ? (unsigned)(((s_n * a.Hin + ih) * a.Win) * a.Cin) * 4u : 0u;
+        const unsigned ss = (unsigned)(s_n * a.aff_stride) * 4u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1 && !two) continue;
+            const int iw = s_ow - 1 + sp + 16 * j;
+            const bool ok = row_ok && ci_ok && (unsigned)iw < (unsigned)a.Win;
+            ri[j] = bload(rx, ok ? (unsigned)((iw * a.Cin + ci0 + sq) * 4) : FAVAE_OOB, sx);
+            if (XFORM) {
+                rsc[j] = bload(rsc_d, ok ? vsc : FAVAE_OOB, ss);
+                rsh[j] = bload(rsh_d, ok ? vsc : FAVAE_OOB, ss);
+            }
+        }
+        ld_pb += 16;
+        s_ow += 16;
+        if (s_ow >= a.Wout) {
+            s_ow = 0;
+            if (++s_oh >= a.Hout) { s_oh = 0; ++s_n; }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        uint2 p0, p1, p2;
+        b6::split4(ro, p0, p1, p2);
+        unsigned char* d = Os + buf * OB + sp * b6::RSB + sq * 2;
+        *reinterpret_cast<uint2*>(d) = p0;
+        *reinterpret_cast<uint2*>(d + OPL) = p1;
+        *reinterpret_cast<uint2*>(d + 2 * OPL) = p2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1 && !two) continue;
+            b6::split4(xform4_t<XFORM>(ri[j], rsc[j], rsh[j]), p0, p1, p2);
+            d = Is + buf * IB + (sp + 16 * j) * b6::RSB + sq * 2;
+            *reinterpret_cast<uint2*>(d) = p0;
+            *reinterpret_cast<uint2*>(d + IPL) = p1;
+            *reinterpret_cast<uint2*>(d + 2 * IPL) = p2;
+        }
+    };
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][j][r] = 0.f;
+
+    const int s16 = lane & 15, g = lane >> 4;
+    const int frag_off = (8 * (g >> 1) + (s16 >> 2)) * b6::RSB + (16 * (g & 1) + 4 * (s16 & 3)) * 2;
+    const unsigned char* Ofr = Os + frag_off + wo * 32 * 2;
+    const unsigned char* Ifr = Is + frag_off + wi * 64 * 2;
+
+    if (T > 0) {
+        load_tiles();
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < T; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < T) load_tiles();
+        bf16x8_t af[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned char* q = Ofr + cur * OB + p * OPL;
+            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(q));
+            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(q + 4 * b6::RSB));
+            af[p] = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16x8_t bf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const unsigned char* q = Ifr + cur * IB + p * IPL + kw * b6::RSB + j * 64;
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(q));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(q + 4 * b6::RSB));
+                    bf[p] = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                acc[kw][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[kw][j], 0, 0, 0);
+                acc[kw][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[kw][j], 0, 0, 0);
+                acc[kw][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[kw][j], 0, 0, 0);
+                acc[kw][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[kw][j], 0, 0, 0);
+                acc[kw][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[kw][j], 0, 0, 0);
+                acc[kw][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[kw][j], 0, 0, 0);
+            }
+        if (it + 1 < T) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci0 + wi * 64 + j * 32 + (lane & 31);
+            if (ci >= a.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < a.Cout) a.part[(((size_t)z * a.Cout + co) * 9 + kh * 3 + kw) * a.Cin + ci] = acc[kw][j][r];
+            }
+        }
+}
