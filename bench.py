@@ -9,9 +9,9 @@ fused Adam) with the batch already resident in HBM.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement"):
   value      whole-job images/s  (sum over ranks / max-over-ranks time, barrier + synchronize on both sides)
-  roofline   dominant kernel = the conv_fwd_buf_kernel<128,2,2,gather,xform> instantiation with the largest time share (forward + data-gradient implicit GEMM, exact-fp32 MFMA):
+  roofline   dominant kernel = the conv3x3_halo_b6_kernel<xform> instantiation with the largest time share (forward + data-gradient implicit GEMM, exact-fp32 MFMA):
              algorithmic FLOPs (2*M*Cout*KH*KW*Cin per launch) / launch durations measured with HIP events on the launch
-             stream inside the timed region; peak = 157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md)
+             stream inside the timed region; peak = 2500 TFLOP/s dense bf16 MFMA / 6 products per fp32 FMA (exact-split path)
   cpu_baseline  the CPU oracle (kind "port": pure-PyTorch restatement of the reference step, oracle/) timed on this
              host's cores on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -26,7 +26,10 @@ for p in (os.path.join(ROOT, "fa-vae_amd"), os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_F32_MFMA_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA (MI355X_MICROARCH.md)
+B6_PRODUCTS = 6                       # bf16 MFMA products issued per fp32 multiply-add on the exact-split path
+PEAK_B6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / B6_PRODUCTS
 
 
 def parse():
@@ -53,19 +56,22 @@ class ConvEventHook:
         self.enabled = False
 
     @staticmethod
-    def kernel_name(d, has_affine):
-        if d.Cin % 16 or d.Cout <= 64:
-            return None                                    # other tile shapes / non-buffer paths: not the dominant family
+    def kernel_name(name, d, has_affine):
+        """kernel instantiation a favae_conv_fwd[_w6] call dispatches to (mirrors conv_fwd_impl in csrc/conv.hip)"""
+        if name != "favae_conv_fwd_w6" or d.Cin % 16 or d.Cout <= 64:
+            return None                                    # narrow tiles / fp32-MFMA fallbacks: not the dominant family
         xf = 0 if not has_affine else {0: 1, 1: 2, 2: 3}[d.act]
-        if d.gather != 0 and xf != 0:
-            return None
-        return "conv_fwd_buf_kernel<128, 2, 2, %d, %d>" % (d.gather, xf)
+        halo = (d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1 and d.gather == 0 and d.Hout == d.Hin and
+                d.Wout == d.Win and d.Hin % 8 == 0 and d.Win % 16 == 0)
+        if halo:
+            return "conv3x3_halo_b6_kernel<%d>" % xf
+        return "conv_fwd_b6_kernel<%d, %d, true, 8>" % (d.gather, xf)
 
     def __call__(self, name, args, launch):
         if not self.enabled or name not in ("favae_conv_fwd", "favae_conv_fwd_w6"):
             return launch()
         d = args[0]._obj
-        kn = self.kernel_name(d, args[5] is not None)
+        kn = self.kernel_name(name, d, args[5] is not None)
         if kn is None:
             return launch()
         flops = 2.0 * d.N * d.Hout * d.Wout * d.Cout * d.KH * d.KW * d.Cin
@@ -200,8 +206,8 @@ def main():
         }
         if conv:
             def entry(kn, c):
-                return {"bound": "mfma", "achieved": c["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": c["tflops"] / PEAK_F32_MFMA_TFLOPS,
+                return {"bound": "mfma", "achieved": c["tflops"], "peak": PEAK_B6_TFLOPS, "unit": "TFLOP/s",
+                        "frac": c["tflops"] / PEAK_B6_TFLOPS, "vs_fp32_mfma_peak": c["tflops"] / PEAK_F32_MFMA_TFLOPS,
                         "traffic": (traffic.get(kn) or {}).get("hbm_bytes_per_launch_corrected"), "kernel": kn,
                         "launches": c["launches"], "avg_launch_us": c["avg_us"],
                         "avg_algorithmic_gflop_per_launch": c["avg_gflop"], "share_of_step_time": c["total_ms"] / (1e3 * dt)}
@@ -212,8 +218,10 @@ def main():
                 pass
             ranked = sorted(conv.items(), key=lambda kv: -kv[1]["total_ms"])
             res["roofline"] = entry(*ranked[0])            # dominant instantiation (largest share of the timed region)
-            res["roofline"]["note"] = ("implicit-GEMM conv on v_mfma_f32_32x32x2_f32; template args <BN, wavesM, wavesN, gather, "
-                                       "xform>: xform 0 = plain (data gradient / un-normalised convs), 2 = GroupNorm+SiLU fused")
+            res["roofline"]["note"] = ("fp32 implicit-GEMM conv on the bf16 matrix pipe with an exact 3-way operand split: 6 "
+                                       "v_mfma_f32_32x32x16_bf16 products per fp32 multiply-add, so peak = 2500 TFLOP/s dense bf16 / 6; "
+                                       "achieved = algorithmic fp32 FLOPs / launch time; template arg = fused input transform "
+                                       "(0 plain: data gradients and un-normalised convs, 2 GroupNorm+SiLU)")
             res["roofline"]["traffic_note"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the launches of one "
                                                "step, separate rocprofv3 --pmc passes (gfx950 FETCH_SIZE x2 correction of "
                                                "MI355X_MICROARCH.md; fabric-side counter, includes Infinity-Cache hits)")
