@@ -79,7 +79,6 @@ struct ConvArgs {
     int kchunks;      // ceil(Cin/BK)
     int vec;          // Cin % 4 == 0 (16-byte channel loads legal)
     unsigned x_bytes, w_bytes, aff_bytes;   // operand sizes for the buffer-addressed kernels
-    int dbg;          // FAVAE_B6_ABLATE: timing ablations (results invalid): 1 no global loads, 2 no split, 3 no LDS stores
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -669,7 +668,6 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     const bool buf_ok = !force_generic() && !force_nobuf() && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) &&
                         (d->gather == FAVAE_GATHER_PLAIN || xf == 0);
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)(w6 ? wb / 4 * 6 : wb); a.aff_bytes = (unsigned)ab;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("FAVAE_B6_ABLATE"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
 #define FAVAE_LAUNCH_BUF(G, X)                                                                                     \
     do {                                                                                                           \
         if (bn == 128) hipLaunchKernelGGL((conv_fwd_buf_kernel<128, 2, 2, G, X>), grid, blk, 0, s, a);             \

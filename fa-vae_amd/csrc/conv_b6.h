@@ -1,4 +1,6 @@
-// EXPERIMENT (opt-in, FAVAE_CONV_B6=1): fp32 convolution on the bf16 matrix pipe with an exact 3-way operand split.
+// Default conv path (FAVAE_CONV_B6=0 disables it): fp32 convolution on the bf16 matrix pipe with an exact 3-way operand split.
+// Kernels: conv_fwd_b6_kernel (implicit GEMM, any gather), conv3x3_halo_b6_kernel (3x3 s1, input halo staged once per K chunk),
+// conv_wgrad_b6_kernel (per tap) and conv_wgrad_row3_b6_kernel (one filter row per workgroup); split3_kernel pre-splits weights.
 //
 // Every fp32 operand is cut (by truncation, exactly) into three bf16 pieces  a = a1 + a2 + a3  (8 + 8 + 8 significand bits);
 // products of two bf16 are exact in fp32, so  a*b = sum_{i,j} ai*bj  and keeping the six terms with i + j <= 4
@@ -100,7 +102,6 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_b6_kernel(ConvArgs a) {
         const unsigned sw = (unsigned)((ld_tap * a.Cin + ld_kc * BK) * (W6 ? 6 : 4));
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            if (a.dbg == 1) break;
             ra[j] = bload(rx, voa[j], sk);
             if (XFORM) {
                 rsc[j] = bload(rsc_d, vos[j], sk);
@@ -119,9 +120,7 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_b6_kernel(ConvArgs a) {
         for (int j = 0; j < R; ++j) {
             const int row = (tid >> 2) + RSTEP * j;
             uint2 p0, p1, p2;
-            if (a.dbg == 3) continue;
-            if (a.dbg == 2) { p0 = make_uint2(__float_as_uint(ra[j].x), __float_as_uint(ra[j].y)); p1 = p0; p2 = p0; }
-            else b6::split4(xform4_t<XFORM>(ra[j], rsc[j], rsh[j]), p0, p1, p2);
+            b6::split4(xform4_t<XFORM>(ra[j], rsc[j], rsh[j]), p0, p1, p2);
             unsigned char* d = As + (buf * BM + row) * b6::ROWB + q4 * 8;
             *reinterpret_cast<uint2*>(d) = p0;
             *reinterpret_cast<uint2*>(d + 32) = p1;
