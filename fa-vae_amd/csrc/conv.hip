@@ -596,6 +596,27 @@ int wgrad_splitk(const favae_conv_desc* d, int tiles, int* chunk) {
     return (int)sk;
 }
 
+// Split-K for the one-workgroup-per-CU row3 kernel: the grid must be a whole number of 256-CU rounds (all workgroups take
+// the same time, so 513 workgroups cost three rounds, not two).  Picks the round count (1..3) with the best fill, never
+// more splits than wgrad_splitk (the workspace is sized by that one).
+int row3_splitk(const favae_conv_desc* d, int tiles3, int sk_max, int* chunk) {
+    const long M = (long)d->N * d->Hout * d->Wout;
+    long best_sk = 1;
+    double best_eff = 0.0;
+    for (int r = 1; r <= 3; ++r) {
+        long sk = (256L * r) / tiles3;
+        if (sk < 1) sk = 1;
+        if (sk > sk_max) sk = sk_max;
+        const long total = sk * tiles3;
+        const double eff = (double)total / (256.0 * ((total + 255) / 256));
+        if (eff > best_eff + 0.01 || (r == 2 && eff >= best_eff - 0.01)) { best_eff = eff; best_sk = sk; }
+    }
+    long ch = (M + best_sk - 1) / best_sk;
+    ch = (ch + 15) / 16 * 16;
+    *chunk = (int)ch;
+    return (int)((M + ch - 1) / ch);
+}
+
 void wgrad_tiles(const favae_conv_desc* d, int* bco, int* bci) {
     *bco = d->Cout <= 32 ? 32 : 128;
     *bci = (d->Cin <= 32 && *bco == 128) ? 32 : 128;
@@ -782,6 +803,8 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     if (row3) {
         // three taps per workgroup: grid.x = tiles * 3 filter rows; split-K sized for the smaller grid
         const int tiles3 = a.tiles_co * a.tiles_ci * 3;
+        a.splitk = row3_splitk(d, tiles3, a.splitk, &chunk);
+        a.chunk = chunk;
         const dim3 g3(tiles3, a.splitk);
         if (xf == 0) hipLaunchKernelGGL((conv_wgrad_row3_b6_kernel<0>), g3, dim3(512), 0, s, a);
         else if (xf == 1) hipLaunchKernelGGL((conv_wgrad_row3_b6_kernel<1>), g3, dim3(512), 0, s, a);

@@ -408,9 +408,12 @@ __global__ __launch_bounds__(256) void split3_kernel(const float4* __restrict__ 
 template <int XFORM>
 __global__ __launch_bounds__(512) void conv3x3_halo_b6_kernel(ConvArgs a) {
     constexpr int TH = 8, TW = 16, HW = TW + 2, HROWS = (TH + 2) * HW;          // 180 halo pixels
-    constexpr int HALO_B = HROWS * b6::ROWB, BT_B = 128 * b6::ROWB;
+    // halo row pitch 2048 B (18 x 112 + 32 pad): pitch % 256 == 0 puts the second tile row of a wave's 32 MFMA rows on the
+    // same bank phase as pixels 16..31 of a contiguous run -> the ds_read_b128 fragment reads are conflict-free (2-way at 2016)
+    constexpr int HPITCH = 2048;
+    constexpr int HALO_B = (TH + 2) * HPITCH, BT_B = 128 * b6::ROWB;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO_B + 2 * BT_B];
-    unsigned char* Hs = lds;                    // [2][180][112]
+    unsigned char* Hs = lds;                    // [2][10][2048]
     unsigned char* Bs = lds + 2 * HALO_B;       // [2][128][112]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -432,12 +435,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_b6_kernel(ConvArgs a) {
 
     // halo staging slots of this thread (720 float4 over 512 threads): constant offsets
     unsigned vh[2], vs[2];
-    int hrow[2];
+    int hrow[2], hoff[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i = tid + 512 * j;
         hrow[j] = i >> 2;
         const int hy = hrow[j] / HW, hx = hrow[j] - hy * HW;
+        hoff[j] = hy * HPITCH + hx * b6::ROWB;
         const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
         const bool ok = hrow[j] < HROWS && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
         vh[j] = ok ? (unsigned)((((n * a.Hin + y) * a.Win + x) * a.Cin + q4 * 4) * 4) : FAVAE_OOB;
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_b6_kernel(ConvArgs a) {
             if (j == 1 && tid >= HROWS * 4 - 512) continue;
             uint2 p0, p1, p2;
             b6::split4(xform4_t<XFORM>(rh[j], rsc[j], rsh[j]), p0, p1, p2);
-            unsigned char* d = Hs + buf * HALO_B + hrow[j] * b6::ROWB + q4 * 8;
+            unsigned char* d = Hs + buf * HALO_B + hoff[j] + q4 * 8;
             *reinterpret_cast<uint2*>(d) = p0;
             *reinterpret_cast<uint2*>(d + 32) = p1;
             *reinterpret_cast<uint2*>(d + 64) = p2;
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_b6_kernel(ConvArgs a) {
     // fragment addressing: MFMA row = pixel p = wm*32 + (lane&31) of the 8x16 tile -> halo row (ty+kh)*18 + tx+kw
     const int p = wm * 32 + (lane & 31);
     const int fh = (lane >> 5) * 16;
-    const unsigned char* Afr = Hs + ((p >> 4) * HW + (p & 15)) * b6::ROWB + fh;
+    const unsigned char* Afr = Hs + (p >> 4) * HPITCH + (p & 15) * b6::ROWB + fh;
     const unsigned char* Bfr = Bs + (wn * 64 + (lane & 31)) * b6::ROWB + fh;
 
     const int KC = a.Cin / 16;
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_b6_kernel(ConvArgs a) {
             else if (more_kc) load_b(kc + 1, 0);
             if (tap == 4 && more_kc) load_halo(kc + 1);                  // in flight over taps 4..8
             const int kh = tap / 3, kw = tap - kh * 3;
-            const unsigned char* Ab = Afr + hb * HALO_B + (kh * HW + kw) * b6::ROWB;
+            const unsigned char* Ab = Afr + hb * HALO_B + kh * HPITCH + kw * b6::ROWB;
             const unsigned char* Bb = Bfr + cur * BT_B;
             bf16x8_t af[3], bf[2][3];
 #pragma unroll

@@ -23,7 +23,7 @@ dx = K.new_cl(B, cin, hw, hw, dev)
 dw = torch.empty(cout, k, k, cin, device=dev)
 ws = H.workspace(H.query("favae_conv_wgrad_workspace", byref(d)), dev)
 for _ in range(3):
-    H.call("favae_conv_fwd", byref(d), H.ptr(x), H.ptr(w), H.ptr(b), None, H.ptr(scale), H.ptr(shift), H.ptr(y))
-    H.call("favae_conv_fwd", byref(d2), H.ptr(y), H.ptr(wt), None, None, None, None, H.ptr(dx))
+    K._conv_launch(d, x, w, b, None, scale, shift, y)
+    K._conv_launch(d2, y, wt, None, None, None, None, dx)
     H.call("favae_conv_wgrad", byref(d), H.ptr(x), H.ptr(y), H.ptr(scale), H.ptr(shift), H.ptr(dw), 0, H.ptr(ws), ws.numel())
 torch.cuda.synchronize()
