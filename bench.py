@@ -9,9 +9,10 @@ fused Adam) with the batch already resident in HBM.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement"):
   value      whole-job images/s  (sum over ranks / max-over-ranks time, barrier + synchronize on both sides)
-  roofline   dominant kernel = the conv3x3_halo_b6_kernel<xform> instantiation with the largest time share (forward + data-gradient implicit GEMM, exact-fp32 MFMA):
-             algorithmic FLOPs (2*M*Cout*KH*KW*Cin per launch) / launch durations measured with HIP events on the launch
-             stream inside the timed region; peak = 2500 TFLOP/s dense bf16 MFMA / 6 products per fp32 FMA (exact-split path)
+  roofline   dominant kernel = the conv3x3_halo_sp_kernel<xform, planes> instantiation with the largest time share (3x3
+             forward / data-gradient conv on the split-precision matrix path): algorithmic FLOPs (2*M*Cout*KH*KW*Cin per
+             launch) / launch durations measured with HIP events on the launch stream inside the timed region;
+             peak = 2500 TFLOP/s dense 16-bit MFMA / products per fp32 multiply-add (3 with two fp16 planes, 6 with three bf16)
   cpu_baseline  the CPU oracle (kind "port": pure-PyTorch restatement of the reference step, oracle/) timed on this
              host's cores on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -27,9 +28,8 @@ for p in (os.path.join(ROOT, "fa-vae_amd"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
-PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA (MI355X_MICROARCH.md)
-B6_PRODUCTS = 6                       # bf16 MFMA products issued per fp32 multiply-add on the exact-split path
-PEAK_B6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / B6_PRODUCTS
+PEAK_16BIT_MFMA_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
+SPLIT_PRODUCTS = {2: 3, 3: 6}         # 16-bit MFMA products issued per fp32 multiply-add: planes -> products (conv_split.h)
 
 
 def parse():
@@ -56,22 +56,22 @@ class ConvEventHook:
         self.enabled = False
 
     @staticmethod
-    def kernel_name(name, d, has_affine):
-        """kernel instantiation a favae_conv_fwd[_w6] call dispatches to (mirrors conv_fwd_impl in csrc/conv.hip)"""
-        if name != "favae_conv_fwd_w6" or d.Cin % 16 or d.Cout <= 64:
+    def kernel_name(name, d, has_affine, planes):
+        """kernel instantiation a favae_conv_fwd_split call dispatches to (mirrors conv_fwd_impl in csrc/conv.hip)"""
+        if name != "favae_conv_fwd_split" or d.Cin % 16 or d.Cout <= 64:
             return None                                    # narrow tiles / fp32-MFMA fallbacks: not the dominant family
         xf = 0 if not has_affine else {0: 1, 1: 2, 2: 3}[d.act]
         halo = (d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1 and d.gather == 0 and d.Hout == d.Hin and
                 d.Wout == d.Win and d.Hin % 8 == 0 and d.Win % 16 == 0)
         if halo:
-            return "conv3x3_halo_b6_kernel<%d>" % xf
-        return "conv_fwd_b6_kernel<%d, %d, true, 8>" % (d.gather, xf)
+            return "conv3x3_halo_sp_kernel<%d, %d>" % (xf, planes)
+        return "conv_fwd_sp_kernel<%d, %d, true, 8, %d>" % (d.gather, xf, planes)
 
     def __call__(self, name, args, launch):
-        if not self.enabled or name not in ("favae_conv_fwd", "favae_conv_fwd_w6"):
+        if not self.enabled or name != "favae_conv_fwd_split":
             return launch()
-        d = args[0]._obj
-        kn = self.kernel_name(name, d, args[5] is not None)
+        d = args[0]._obj                                   # (desc, x, wsplit, planes, x_absmax, bias, resid, scale, shift, y)
+        kn = self.kernel_name(name, d, args[7] is not None, args[3])
         if kn is None:
             return launch()
         flops = 2.0 * d.N * d.Hout * d.Wout * d.Cout * d.KH * d.KW * d.Cin
@@ -206,8 +206,10 @@ def main():
         }
         if conv:
             def entry(kn, c):
-                return {"bound": "mfma", "achieved": c["tflops"], "peak": PEAK_B6_TFLOPS, "unit": "TFLOP/s",
-                        "frac": c["tflops"] / PEAK_B6_TFLOPS, "vs_fp32_mfma_peak": c["tflops"] / PEAK_F32_MFMA_TFLOPS,
+                planes = int(kn.rstrip(">").split(",")[-1])
+                peak = PEAK_16BIT_MFMA_TFLOPS / SPLIT_PRODUCTS[planes]
+                return {"bound": "mfma", "achieved": c["tflops"], "peak": peak, "unit": "TFLOP/s",
+                        "frac": c["tflops"] / peak, "vs_fp32_mfma_peak": c["tflops"] / PEAK_F32_MFMA_TFLOPS,
                         "traffic": (traffic.get(kn) or {}).get("hbm_bytes_per_launch_corrected"), "kernel": kn,
                         "launches": c["launches"], "avg_launch_us": c["avg_us"],
                         "avg_algorithmic_gflop_per_launch": c["avg_gflop"], "share_of_step_time": c["total_ms"] / (1e3 * dt)}
@@ -218,10 +220,11 @@ def main():
                 pass
             ranked = sorted(conv.items(), key=lambda kv: -kv[1]["total_ms"])
             res["roofline"] = entry(*ranked[0])            # dominant instantiation (largest share of the timed region)
-            res["roofline"]["note"] = ("fp32 implicit-GEMM conv on the bf16 matrix pipe with an exact 3-way operand split: 6 "
-                                       "v_mfma_f32_32x32x16_bf16 products per fp32 multiply-add, so peak = 2500 TFLOP/s dense bf16 / 6; "
-                                       "achieved = algorithmic fp32 FLOPs / launch time; template arg = fused input transform "
-                                       "(0 plain: data gradients and un-normalised convs, 2 GroupNorm+SiLU)")
+            res["roofline"]["note"] = ("fp32 3x3 conv on the 16-bit matrix pipe by operand splitting (conv_split.h): planes=2 -> two "
+                                       "scaled fp16 planes, 3 v_mfma_f32_32x32x16_f16 products per fp32 multiply-add, peak = 2500/3 "
+                                       "TFLOP/s; planes=3 -> three bf16 planes, 6 products, peak = 2500/6; achieved = algorithmic "
+                                       "fp32 FLOPs / launch time; template args = <fused input transform (0 plain: data gradients "
+                                       "and un-normalised convs, 2 GroupNorm+SiLU), planes>")
             res["roofline"]["traffic_note"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the launches of one "
                                                "step, separate rocprofv3 --pmc passes (gfx950 FETCH_SIZE x2 correction of "
                                                "MI355X_MICROARCH.md; fabric-side counter, includes Infinity-Cache hits)")

@@ -27,13 +27,21 @@ bool force_generic() {
     if (v < 0) { const char* e = getenv("FAVAE_CONV_GENERIC"); v = (e && e[0] == '1') ? 1 : 0; }
     return v == 1;
 }
-// 128-wide forward/data-gradient convs run on the exact-split bf16x6 matrix path (conv_b6.h); FAVAE_CONV_B6=0 falls back to
-// the fp32-MFMA kernels (A/B measurements, debugging)
-bool use_b6() {
+// 128-wide convs run on the split-precision matrix path (conv_split.h).  FAVAE_CONV_MODE = h3 (default: two scaled fp16
+// planes, 3 MFMAs, needs operand maxima) | b6 (three bf16 planes, 6 MFMAs) | fp32 (the fp32-MFMA kernels; also FAVAE_CONV_B6=0).
+// Returns the number of planes: 2, 3 or 0.
+int conv_mode() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("FAVAE_CONV_B6"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
+    if (v < 0) {
+        const char* e = getenv("FAVAE_CONV_MODE");
+        const char* b = getenv("FAVAE_CONV_B6");
+        v = 2;
+        if (e && e[0] == 'b') v = 3;
+        else if ((e && e[0] == 'f') || (b && b[0] == '0')) v = 0;
+    }
+    return v;
 }
+bool use_b6() { return conv_mode() != 0; }
 // FAVAE_WGRAD_ROW3=0 disables the three-taps-per-workgroup weight-gradient kernel (A/B switch)
 bool use_row3() {
     static int v = -1;
@@ -79,6 +87,8 @@ struct ConvArgs {
     int kchunks;      // ceil(Cin/BK)
     int vec;          // Cin % 4 == 0 (16-byte channel loads legal)
     unsigned x_bytes, w_bytes, aff_bytes;   // operand sizes for the buffer-addressed kernels
+    const float* x_amax;                    // split-precision fp16 scheme: device-side bound of |transformed x| ...
+    const float* w_amax;                    // ... and of |w| (header of the pre-split weight buffer)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -289,6 +299,8 @@ struct WgradArgs {
     int M, tiles_co, tiles_ci, splitk, chunk;   // chunk = pixels per split (multiple of 16)
     int vec_i, vec_o;
     unsigned x_bytes, aff_bytes;
+    const float* x_amax;                    // split-precision fp16 scheme: device-side bounds of |transformed x| and |dy|
+    const float* dy_amax;
 };
 
 template <int BCO, int BCI, int WAVES_O, int WAVES_I>
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
 #include "conv_fast.h"
 #include "conv_buf.h"
-#include "conv_b6.h"
+#include "conv_split.h"
 
 // out[i] (+)= sum_z part[z][i] in a fixed order (4 interleaved partial sums -> 4 loads in flight per thread)
 __global__ void reduce_slabs_kernel(const float* part, float* out, size_t n, int slabs, int accumulate) {
@@ -624,48 +636,100 @@ void wgrad_tiles(const favae_conv_desc* d, int* bco, int* bci) {
 
 }  // namespace
 
-static bool b6_fwd_eligible(const favae_conv_desc* d, bool has_affine) {
+static bool sp_fwd_eligible(const favae_conv_desc* d, bool has_affine) {
     if (!desc_ok(d) || force_generic() || force_nobuf() || !use_b6()) return false;
     const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, wb = (size_t)d->Cout * d->KH * d->KW * d->Cin * 6;
     return d->Cout > 64 && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) && (d->gather == FAVAE_GATHER_PLAIN || !has_affine);
 }
 
 extern "C" int favae_conv_wants_split_weights(const favae_conv_desc* d, int has_affine) {
-    return b6_fwd_eligible(d, has_affine != 0) ? 1 : 0;
+    return sp_fwd_eligible(d, has_affine != 0) ? conv_mode() : 0;
 }
 
-extern "C" int favae_split3(const float* in, void* out, int64_t n, favae_stream_t stream) {
-    FAVAE_REQUIRE(in && out && n > 0 && n % 4 == 0);
+extern "C" size_t favae_split_weights_bytes(int64_t n, int planes) {
+    if (n <= 0 || n % 4 || (planes != 2 && planes != 3)) return 0;
+    return (size_t)sp::WHDR + (size_t)(n / 4) * (planes == 2 ? sp::Scheme<2>::WREC : sp::Scheme<3>::WREC);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, int vec, unsigned* __restrict__ out) {
+    float m = 0.f;
+    const size_t n4 = vec ? n / 4 : 0;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = x4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));     // non-negative floats order like their bit patterns
+}
+
+int launch_absmax(const float* x, int64_t n, float* out, hipStream_t s) {
+    if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
+    long blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (size_t)n, (((uintptr_t)x) & 15) == 0 ? 1 : 0,
+                       (unsigned*)out);
+    return FAVAE_OK;
+}
+}  // namespace
+
+extern "C" int favae_absmax(const float* x, int64_t n, float* out, favae_stream_t stream) {
+    FAVAE_REQUIRE(x && out && n > 0);
+    const int rc = launch_absmax(x, n, out, (hipStream_t)stream);
+    if (rc != FAVAE_OK) return rc;
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_split_weights(const float* in, void* out, int64_t n, int planes, favae_stream_t stream) {
+    FAVAE_REQUIRE(in && out && n > 0 && n % 4 == 0 && (planes == 2 || planes == 3));
+    FAVAE_REQUIRE((((uintptr_t)out) & 15) == 0);
+    hipStream_t s = (hipStream_t)stream;
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)in, (unsigned*)out,
-                       (size_t)(n / 4));
+    unsigned* rec = (unsigned*)((char*)out + sp::WHDR);
+    if (planes == 2) {
+        const int rc = launch_absmax(in, n, (float*)out, s);
+        if (rc != FAVAE_OK) return rc;
+        hipLaunchKernelGGL((split_w_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
+                           (const float*)out);
+    } else {
+        hipLaunchKernelGGL((split_w_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
+                           (const float*)nullptr);
+    }
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
 
 static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
-                         const float* scale, const float* shift, float* y, bool w6, favae_stream_t stream);
+                         const float* scale, const float* shift, float* y, int wplanes, const float* x_amax,
+                         favae_stream_t stream);
 
 extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const float* w, const float* bias,
                               const float* resid, const float* scale, const float* shift, float* y,
                               favae_stream_t stream) {
-    return conv_fwd_impl(d, x, w, bias, resid, scale, shift, y, false, stream);
+    return conv_fwd_impl(d, x, w, bias, resid, scale, shift, y, 0, nullptr, stream);
 }
 
-extern "C" int favae_conv_fwd_w6(const favae_conv_desc* d, const float* x, const void* w6, const float* bias,
-                                 const float* resid, const float* scale, const float* shift, float* y,
-                                 favae_stream_t stream) {
-    if (!b6_fwd_eligible(d, scale != nullptr)) return FAVAE_ERR_UNSUPPORTED;
-    return conv_fwd_impl(d, x, (const float*)w6, bias, resid, scale, shift, y, true, stream);
+extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, const void* wsplit, int planes,
+                                    const float* x_absmax, const float* bias, const float* resid, const float* scale,
+                                    const float* shift, float* y, favae_stream_t stream) {
+    if (!sp_fwd_eligible(d, scale != nullptr)) return FAVAE_ERR_UNSUPPORTED;
+    FAVAE_REQUIRE(wsplit && (planes == 3 || (planes == 2 && x_absmax)));
+    return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream);
 }
 
 static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
-                         const float* scale, const float* shift, float* y, bool w6, favae_stream_t stream) {
+                         const float* scale, const float* shift, float* y, int wplanes, const float* x_amax,
+                         favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && x && w && y);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
+    const bool w6 = wplanes != 0;                            // pre-split weights: records start behind the header
     ConvArgs a;
-    a.x = x; a.w = w; a.bias = bias; a.resid = resid; a.scale = scale; a.shift = shift; a.y = y;
+    a.x_amax = x_amax; a.w_amax = w;
+    a.x = x; a.w = w6 ? (const float*)((const char*)w + sp::WHDR) : w; a.bias = bias; a.resid = resid; a.scale = scale; a.shift = shift; a.y = y;
     a.N = d->N; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->Cin; a.Hout = d->Hout; a.Wout = d->Wout; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.gather = d->gather; a.act = d->act;
     a.aff_stride = d->affine_per_image ? d->Cin : 0;
@@ -688,7 +752,8 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     const int xf = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_LEAKY02 ? 3 : 1)) : 0;
     const bool buf_ok = !force_generic() && !force_nobuf() && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) &&
                         (d->gather == FAVAE_GATHER_PLAIN || xf == 0);
-    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)(w6 ? wb / 4 * 6 : wb); a.aff_bytes = (unsigned)ab;
+    a.x_bytes = (unsigned)xb; a.aff_bytes = (unsigned)ab;
+    a.w_bytes = (unsigned)(wplanes == 3 ? wb / 16 * sp::Scheme<3>::WREC : (wplanes == 2 ? wb / 16 * sp::Scheme<2>::WREC : wb));
 #define FAVAE_LAUNCH_BUF(G, X)                                                                                     \
     do {                                                                                                           \
         if (bn == 128) hipLaunchKernelGGL((conv_fwd_buf_kernel<128, 2, 2, G, X>), grid, blk, 0, s, a);             \
@@ -701,19 +766,26 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     if (halo_ok) {
         a.tiles_n = cdiv(d->Cout, 128);
         const dim3 hgrid((unsigned)(d->N * (d->Hin / 8) * (d->Win / 16) * a.tiles_n));
-        if (xf == 0) hipLaunchKernelGGL((conv3x3_halo_b6_kernel<0>), hgrid, dim3(512), 0, s, a);
-        else if (xf == 1) hipLaunchKernelGGL((conv3x3_halo_b6_kernel<1>), hgrid, dim3(512), 0, s, a);
-        else if (xf == 2) hipLaunchKernelGGL((conv3x3_halo_b6_kernel<2>), hgrid, dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_halo_b6_kernel<3>), hgrid, dim3(512), 0, s, a);
+#define FAVAE_LAUNCH_HALO(X)                                                                              \
+    do {                                                                                                  \
+        if (wplanes == 2) hipLaunchKernelGGL((conv3x3_halo_sp_kernel<X, 2>), hgrid, dim3(512), 0, s, a);  \
+        else hipLaunchKernelGGL((conv3x3_halo_sp_kernel<X, 3>), hgrid, dim3(512), 0, s, a);               \
+    } while (0)
+        if (xf == 0) FAVAE_LAUNCH_HALO(0);
+        else if (xf == 1) FAVAE_LAUNCH_HALO(1);
+        else if (xf == 2) FAVAE_LAUNCH_HALO(2);
+        else FAVAE_LAUNCH_HALO(3);
+#undef FAVAE_LAUNCH_HALO
     } else if (buf_ok && use_b6() && bn == 128) {
 #define FAVAE_LAUNCH_B6(G, X)                                                                     \
     do {                                                                                          \
-        if (b6_waves() == 8) {                                                                    \
-            if (w6) hipLaunchKernelGGL((conv_fwd_b6_kernel<G, X, true, 8>), grid, dim3(512), 0, s, a);   \
-            else hipLaunchKernelGGL((conv_fwd_b6_kernel<G, X, false, 8>), grid, dim3(512), 0, s, a);     \
+        if (wplanes == 2) hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, true, 8, 2>), grid, dim3(512), 0, s, a);        \
+        else if (b6_waves() == 8) {                                                               \
+            if (w6) hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, true, 8, 3>), grid, dim3(512), 0, s, a);   \
+            else hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, false, 8, 3>), grid, dim3(512), 0, s, a);     \
         } else {                                                                                  \
-            if (w6) hipLaunchKernelGGL((conv_fwd_b6_kernel<G, X, true, 4>), grid, blk, 0, s, a);  \
-            else hipLaunchKernelGGL((conv_fwd_b6_kernel<G, X, false, 4>), grid, blk, 0, s, a);    \
+            if (w6) hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, true, 4, 3>), grid, blk, 0, s, a);  \
+            else hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, false, 4, 3>), grid, blk, 0, s, a);    \
         }                                                                                         \
     } while (0)
         if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_B6(FAVAE_GATHER_UPSAMPLE2, 0);
@@ -757,15 +829,18 @@ extern "C" size_t favae_conv_wgrad_workspace(const favae_conv_desc* d) {
 }
 
 extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const float* dy, const float* scale,
-                                const float* shift, float* dw, int accumulate, void* ws, size_t ws_bytes,
-                                favae_stream_t stream) {
+                                const float* shift, const float* x_absmax, const float* dy_absmax, float* dw, int accumulate,
+                                void* ws, size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && x && dy && dw && ws);
+    // fp16 planes need both operand maxima; without them the bf16 scheme (no range restrictions) runs
+    const int np = (conv_mode() == 2 && x_absmax && dy_absmax) ? 2 : 3;
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     if (ws_bytes < favae_conv_wgrad_workspace(d)) return FAVAE_ERR_WORKSPACE;
     int bco, bci, chunk;
     wgrad_tiles(d, &bco, &bci);
     WgradArgs a;
     a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.part = (float*)ws;
+    a.x_amax = x_absmax; a.dy_amax = dy_absmax;
     a.N = d->N; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->Cin; a.Hout = d->Hout; a.Wout = d->Wout; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.gather = d->gather; a.act = d->act;
     a.aff_stride = d->affine_per_image ? d->Cin : 0;
@@ -806,14 +881,26 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
         a.splitk = row3_splitk(d, tiles3, a.splitk, &chunk);
         a.chunk = chunk;
         const dim3 g3(tiles3, a.splitk);
-        if (xf == 0) hipLaunchKernelGGL((conv_wgrad_row3_b6_kernel<0>), g3, dim3(512), 0, s, a);
-        else if (xf == 1) hipLaunchKernelGGL((conv_wgrad_row3_b6_kernel<1>), g3, dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((conv_wgrad_row3_b6_kernel<2>), g3, dim3(512), 0, s, a);
+#define FAVAE_LAUNCH_ROW3(X)                                                                              \
+    do {                                                                                                  \
+        if (np == 2) hipLaunchKernelGGL((conv_wgrad_row3_sp_kernel<X, 2>), g3, dim3(512), 0, s, a);       \
+        else hipLaunchKernelGGL((conv_wgrad_row3_sp_kernel<X, 3>), g3, dim3(512), 0, s, a);               \
+    } while (0)
+        if (xf == 0) FAVAE_LAUNCH_ROW3(0);
+        else if (xf == 1) FAVAE_LAUNCH_ROW3(1);
+        else FAVAE_LAUNCH_ROW3(2);
+#undef FAVAE_LAUNCH_ROW3
     } else if (buf_ok && use_b6() && bco == 128 && bci == 128) {
-        if (d->gather == FAVAE_GATHER_UPSAMPLE2) hipLaunchKernelGGL((conv_wgrad_b6_kernel<0, true>), grid, dim3(256), 0, s, a);
-        else if (xf == 0) hipLaunchKernelGGL((conv_wgrad_b6_kernel<0, false>), grid, dim3(256), 0, s, a);
-        else if (xf == 1) hipLaunchKernelGGL((conv_wgrad_b6_kernel<1, false>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv_wgrad_b6_kernel<2, false>), grid, dim3(256), 0, s, a);
+#define FAVAE_LAUNCH_WSP(X, U)                                                                            \
+    do {                                                                                                  \
+        if (np == 2) hipLaunchKernelGGL((conv_wgrad_sp_kernel<X, U, 2>), grid, dim3(256), 0, s, a);       \
+        else hipLaunchKernelGGL((conv_wgrad_sp_kernel<X, U, 3>), grid, dim3(256), 0, s, a);               \
+    } while (0)
+        if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_WSP(0, true);
+        else if (xf == 0) FAVAE_LAUNCH_WSP(0, false);
+        else if (xf == 1) FAVAE_LAUNCH_WSP(1, false);
+        else FAVAE_LAUNCH_WSP(2, false);
+#undef FAVAE_LAUNCH_WSP
     } else if (buf_ok && d->gather == FAVAE_GATHER_PLAIN) {
         if (xf == 0) FAVAE_LAUNCH_WBUF(0);
         else if (xf == 1) FAVAE_LAUNCH_WBUF(1);

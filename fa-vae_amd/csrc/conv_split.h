@@ -1,52 +1,146 @@
-// Default conv path (FAVAE_CONV_B6=0 disables it): fp32 convolution on the bf16 matrix pipe with an exact 3-way operand split.
-// Kernels: conv_fwd_b6_kernel (implicit GEMM, any gather), conv3x3_halo_b6_kernel (3x3 s1, input halo staged once per K chunk),
-// conv_wgrad_b6_kernel (per tap) and conv_wgrad_row3_b6_kernel (one filter row per workgroup); split3_kernel pre-splits weights.
+// fp32 convolutions on the 16-bit matrix pipe by exact operand splitting (included by conv.hip).  Default conv path;
+// FAVAE_CONV_MODE=h3|b6|fp32 selects the scheme (fp32 = the fp32-MFMA kernels of conv_buf.h / conv_fast.h / conv.hip).
 //
-// Every fp32 operand is cut (by truncation, exactly) into three bf16 pieces  a = a1 + a2 + a3  (8 + 8 + 8 significand bits);
-// products of two bf16 are exact in fp32, so  a*b = sum_{i,j} ai*bj  and keeping the six terms with i + j <= 4
-// (a1b1, a1b2, a2b1, a2b2, a1b3, a3b1) leaves a relative error of ~2^-24 per product -- the same class as the rounding of an
-// fp32 FMA -- while v_mfma_f32_32x32x16_bf16 runs at 16x the rate of v_mfma_f32_32x32x2_f32: 6/16 of the matrix-pipe time.
-// Same tiling as conv_fwd_buf_kernel (128x128x16, 4 waves of 64x64); LDS holds the three bf16 planes of each row
-// ([row][plane][16 k] + 16 B pad = 112 B rows -> conflict-free ds_read_b128 fragment reads).
+// Scheme<3> "b6" -- three bf16 planes by truncation, a = a1 + a2 + a3 (8 + 8 + 8 significand bits, exact); products of two
+//   bf16 are exact in fp32, and keeping the six terms with i + j <= 4 (a1b1, a1b2, a2b1, a2b2, a1b3, a3b1) leaves a relative
+//   error of ~2^-24 per product.  6 x v_mfma_f32_32x32x16_bf16 per fp32 product block (6/16 of the fp32-MFMA pipe time).
+//   No range restrictions (bf16 has the fp32 exponent).
+// Scheme<2> "h3" -- two fp16 planes by round-to-nearest of the operand scaled by a power of two S (exact):
+//   a S = a1 + a2 + e, |e| <= 2^-22 |a S| (or 2^-25 absolute once a2 is subnormal); a b ~ a1b1 + a1b2 + a2b1, the dropped
+//   a2b2 is <= 2^-22 |a b|.  3 x v_mfma_f32_32x32x16_f16 -- half the matrix work of b6.  The per-product error (~2^-22.5,
+//   random sign) stays below the fp32 accumulation rounding that every scheme shares (measured rms vs fp64: tools/
+//   conv_accuracy.py).  fp16 has 5 exponent bits, so every operand tensor carries a device-side |max| (or upper bound)
+//   from which the kernel derives S = 2^(14 - floor(log2 amax)): S amax in [2^14, 2^15) -- no overflow, and elements down to
+//   2^-17 of the maximum keep full relative precision.  The accumulator is un-scaled in the epilogue (exact, powers of two).
+//
+// Kernels: conv_fwd_sp_kernel (implicit GEMM, any gather), conv3x3_halo_sp_kernel (3x3 s1, input halo staged once per
+// K chunk), conv_wgrad_sp_kernel (per tap), conv_wgrad_row3_sp_kernel (one filter row per workgroup); split_w*_kernel
+// pre-split the weights once per call into per-4-float records.
 #pragma once
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
-namespace b6 {
-constexpr int ROWB = 112;                 // bytes per LDS row: 3 planes x 32 B + 16 B pad
+namespace sp {
 constexpr unsigned TOP = 0xFFFF0000u;
+constexpr int WHDR = 256;                  // bytes of header in front of the weight records (float[0] = |max| of the weights)
 
-// split four consecutive-k floats into three planes of 4 bf16 (2 dwords each), exact by truncation
-__device__ __forceinline__ void split4(const float4 v, uint2& p0, uint2& p1, uint2& p2) {
-    const float a[4] = {v.x, v.y, v.z, v.w};
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        h[e] = __float_as_uint(a[e]);
-        const float r1 = a[e] - __uint_as_float(h[e] & TOP);
-        m[e] = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(m[e] & TOP);
-        l[e] = __float_as_uint(r2);
-    }
-    // pack the upper halves of two words: low 16 bits <- even k, high 16 bits <- odd k
-    p0 = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
-    p1 = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
-    p2 = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+// S = 2^(14 - floor(log2 amax)) from a device-side maximum (1 for zero / non-finite maxima)
+__device__ __forceinline__ float pow2_scale(const float* amax) {
+    const int e = (int)((__float_as_uint(*amax) & 0x7FFFFFFFu) >> 23);
+    if (e == 0 || e == 255) return 1.f;
+    int se = 268 - e;                      // biased exponent of S
+    se = se < 2 ? 2 : (se > 252 ? 252 : se);
+    return __uint_as_float((unsigned)se << 23);
 }
-}  // namespace b6
+__device__ __forceinline__ float pow2_inv(float S) {
+    return __uint_as_float((254u - (__float_as_uint(S) >> 23)) << 23);
+}
 
-// W6: the weight operand arrives pre-split (favae_split3: 24-byte records {plane0[4], plane1[4], plane2[4]} per 4 floats),
-// so the B tile is a pure copy global -> LDS and only the activation tile is split in the K loop.
+template <int NP> struct Scheme;
+
+template <> struct Scheme<3> {
+    static constexpr int ROWB = 112;       // LDS row: 3 planes x 32 B (16 k) + 16 B pad -> conflict-free ds_read_b128
+    static constexpr int WREC = 24;        // bytes per pre-split 4-float weight record {plane0[4], plane1[4], plane2[4]}
+    // split four consecutive-k floats into three planes of 4 bf16 (2 dwords each), exact by truncation
+    static __device__ __forceinline__ void split4(const float4 v, float, uint2 (&p)[3]) {
+        const float a[4] = {v.x, v.y, v.z, v.w};
+        unsigned h[4], m[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = __float_as_uint(a[e]);
+            const float r1 = a[e] - __uint_as_float(h[e] & TOP);
+            m[e] = __float_as_uint(r1);
+            const float r2 = r1 - __uint_as_float(m[e] & TOP);
+            l[e] = __float_as_uint(r2);
+        }
+        // pack the upper halves of two words: low 16 bits <- even k, high 16 bits <- odd k
+        p[0] = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+        p[1] = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+        p[2] = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+    }
+    // smallest terms first
+    static __device__ __forceinline__ void mma(const bf16x8_t (&a)[3], const bf16x8_t (&b)[3], f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    }
+};
+
+template <> struct Scheme<2> {
+    static constexpr int ROWB = 80;        // 2 planes x 32 B + 16 B pad (20-bank row stride: conflict-free ds_read_b128)
+    static constexpr int WREC = 16;        // {plane0[4 fp16], plane1[4]}
+    static __device__ __forceinline__ void split4(const float4 v, float S, uint2 (&p)[2]) {
+        const float a[4] = {v.x * S, v.y * S, v.z * S, v.w * S};
+        _Float16 h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (_Float16)a[e];                                  // round to nearest
+            l[e] = (_Float16)(a[e] - (float)h[e]);                  // the residual is exact in fp32
+        }
+        const half2_t h01 = {h[0], h[1]}, h23 = {h[2], h[3]}, l01 = {l[0], l[1]}, l23 = {l[2], l[3]};
+        p[0] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+        p[1] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+    }
+    static __device__ __forceinline__ void mma(const bf16x8_t (&a)[2], const bf16x8_t (&b)[2], f32x16& c) {
+        const half8_t a0 = __builtin_bit_cast(half8_t, a[0]), a1 = __builtin_bit_cast(half8_t, a[1]);
+        const half8_t b0 = __builtin_bit_cast(half8_t, b[0]), b1 = __builtin_bit_cast(half8_t, b[1]);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
+    }
+};
+
+// one pre-split weight record (4 consecutive k) -> NP plane pieces
+template <int NP, typename R>
+__device__ __forceinline__ void load_wrec(R rw, unsigned voff, unsigned soff, uint2 (&p)[NP]) {
+    const float4 t = bload(rw, voff, soff);
+    p[0] = make_uint2(__float_as_uint(t.x), __float_as_uint(t.y));
+    p[1] = make_uint2(__float_as_uint(t.z), __float_as_uint(t.w));
+    if constexpr (NP == 3) p[2] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rw, voff + 16u, soff, 0));
+}
+
+template <int NP>
+__device__ __forceinline__ void store_planes(unsigned char* d, int plane_stride, const uint2 (&p)[NP]) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) *reinterpret_cast<uint2*>(d + i * plane_stride) = p[i];
+}
+
+// ---- transposing fragment reads of the weight-gradient kernels --------------------------------------------------------
+constexpr int RSB = 320;                   // bytes per pixel row of a plane (128 ch x 2 B + 64 B pad: conflict-free tr reads)
+constexpr int PLB = 16 * RSB;              // bytes per plane (16 pixels)
+
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* p) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + 4 * RSB));
+    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+}  // namespace sp
+
+// ---------------------------------------------------------------------------------------------------------------
+// implicit-GEMM forward / data gradient, 128 x 128 x 16 tiles.  WS: the weight operand arrives pre-split (favae_split_weights),
+// so the B tile is a pure copy global -> LDS and only the activation tile is split in the K loop (WS = false: NP = 3 only).
 // NW = waves per workgroup: 4 (2x2 waves of 64x64) or 8 (4x2 waves of 32x64: twice the resident waves for the same LDS
 // footprint, which is what hides the load -> split -> ds_write -> barrier -> ds_read chain of this short-MFMA kernel).
-template <int GATHER, int XFORM, bool W6, int NW>
-__global__ __launch_bounds__(64 * NW) void conv_fwd_b6_kernel(ConvArgs a) {
+// ---------------------------------------------------------------------------------------------------------------
+template <int GATHER, int XFORM, bool WS, int NW, int NP>
+__global__ __launch_bounds__(64 * NW) void conv_fwd_sp_kernel(ConvArgs a) {
+    using S = sp::Scheme<NP>;
+    static_assert(WS || NP == 3, "in-kernel weight split exists for the bf16 scheme only");
     constexpr int BN = 128, WTM = (NW == 4 ? 64 : 32), WTN = 64, MI = WTM / 32, NI = 2;
     constexpr int R = 8 / NW;                      // staged rows per thread and operand (128 rows x 4 quads / threads)
     constexpr int RSTEP = 16 * NW;                 // row distance between a thread's staged rows
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * b6::ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * S::ROWB];
     unsigned char* As = lds;
-    unsigned char* Bs = lds + 2 * BM * b6::ROWB;
+    unsigned char* Bs = lds + 2 * BM * S::ROWB;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;          // NW/2 x 2 waves
@@ -54,6 +148,7 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_b6_kernel(ConvArgs a) {
     const int m0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
     const int q4 = tid & 3, c4 = q4 * 4;
     const int taps = a.KH * a.KW;
+    const float Sa = NP == 2 ? sp::pow2_scale(a.x_amax) : 1.f;
 
     const auto rx = make_rsrc(a.x, a.x_bytes);
     const auto rw = make_rsrc(a.w, a.w_bytes);
@@ -75,11 +170,12 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_b6_kernel(ConvArgs a) {
             r_ow[j] = r - r_oh[j] * a.Wout;
         }
     }
+    constexpr int WB = WS ? S::WREC : 16;           // bytes per 4 weights in global memory
     unsigned vob[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int row = (tid >> 2) + RSTEP * j;
-        vob[j] = (n0 + row < a.Cout) ? (unsigned)(((n0 + row) * taps * a.Cin + c4) * (W6 ? 6 : 4)) : FAVAE_OOB;
+        vob[j] = (n0 + row < a.Cout) ? (unsigned)(((n0 + row) * taps * a.Cin + c4) / 4 * WB) : FAVAE_OOB;
     }
     unsigned voa[R], vos[R];
     int ld_tap = 0, ld_kc = 0;
@@ -96,10 +192,10 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_b6_kernel(ConvArgs a) {
     tap_state(0);
 
     float4 ra[R], rsc[R], rsh[R], rb[R];
-    uint2 rb2[R];
+    uint2 rbp[R][NP];
     auto load_tiles = [&]() {
         const unsigned sk = (unsigned)(ld_kc * BK * 4);
-        const unsigned sw = (unsigned)((ld_tap * a.Cin + ld_kc * BK) * (W6 ? 6 : 4));
+        const unsigned sw = (unsigned)((ld_tap * a.Cin + ld_kc * BK) / 4 * WB);
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             ra[j] = bload(rx, voa[j], sk);
@@ -107,8 +203,8 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_b6_kernel(ConvArgs a) {
                 rsc[j] = bload(rsc_d, vos[j], sk);
                 rsh[j] = bload(rsh_d, vos[j], sk);
             }
-            rb[j] = bload(rw, vob[j], sw);                       // W6: planes 0 and 1 (16 B)
-            if (W6) rb2[j] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rw, vob[j] + 16u, sw, 0));
+            if constexpr (WS) sp::load_wrec<NP>(rw, vob[j], sw, rbp[j]);
+            else rb[j] = bload(rw, vob[j], sw);
         }
         if (++ld_kc == a.kchunks) {
             ld_kc = 0;
@@ -119,23 +215,15 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_b6_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int row = (tid >> 2) + RSTEP * j;
-            uint2 p0, p1, p2;
-            b6::split4(xform4_t<XFORM>(ra[j], rsc[j], rsh[j]), p0, p1, p2);
-            unsigned char* d = As + (buf * BM + row) * b6::ROWB + q4 * 8;
-            *reinterpret_cast<uint2*>(d) = p0;
-            *reinterpret_cast<uint2*>(d + 32) = p1;
-            *reinterpret_cast<uint2*>(d + 64) = p2;
-            if (W6) {
-                p0 = make_uint2(__float_as_uint(rb[j].x), __float_as_uint(rb[j].y));
-                p1 = make_uint2(__float_as_uint(rb[j].z), __float_as_uint(rb[j].w));
-                p2 = rb2[j];
+            uint2 p[NP];
+            S::split4(xform4_t<XFORM>(ra[j], rsc[j], rsh[j]), Sa, p);
+            sp::store_planes<NP>(As + (buf * BM + row) * S::ROWB + q4 * 8, 32, p);
+            if constexpr (WS) {
+                sp::store_planes<NP>(Bs + (buf * BN + row) * S::ROWB + q4 * 8, 32, rbp[j]);
             } else {
-                b6::split4(rb[j], p0, p1, p2);
+                S::split4(rb[j], 1.f, p);
+                sp::store_planes<NP>(Bs + (buf * BN + row) * S::ROWB + q4 * 8, 32, p);
             }
-            d = Bs + (buf * BN + row) * b6::ROWB + q4 * 8;
-            *reinterpret_cast<uint2*>(d) = p0;
-            *reinterpret_cast<uint2*>(d + 32) = p1;
-            *reinterpret_cast<uint2*>(d + 64) = p2;
         }
     };
 
@@ -155,33 +243,27 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_b6_kernel(ConvArgs a) {
     for (int it = 0; it < T; ++it) {
         const int cur = it & 1;
         if (it + 1 < T) load_tiles();
-        bf16x8_t af[MI][3], bf[NI][3];
+        bf16x8_t af[MI][NP], bf[NI][NP];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                af[i][p] = *reinterpret_cast<const bf16x8_t*>(As + (cur * BM + wm * WTM + i * 32 + frow) * b6::ROWB + p * 32 + fh);
+            for (int p = 0; p < NP; ++p)
+                af[i][p] = *reinterpret_cast<const bf16x8_t*>(As + (cur * BM + wm * WTM + i * 32 + frow) * S::ROWB + p * 32 + fh);
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                bf[j][p] = *reinterpret_cast<const bf16x8_t*>(Bs + (cur * BN + wn * WTN + j * 32 + frow) * b6::ROWB + p * 32 + fh);
+            for (int p = 0; p < NP; ++p)
+                bf[j][p] = *reinterpret_cast<const bf16x8_t*>(Bs + (cur * BN + wn * WTN + j * 32 + frow) * S::ROWB + p * 32 + fh);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                // smallest terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < NI; ++j) S::mma(af[i], bf[j], acc[i][j]);
         if (it + 1 < T) store_tiles(cur ^ 1);
         __syncthreads();
     }
 
+    float un_a = 1.f, un_w = 1.f;
+    if constexpr (NP == 2) { un_a = sp::pow2_inv(Sa); un_w = sp::pow2_inv(sp::pow2_scale(a.w_amax)); }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -194,7 +276,9 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_b6_kernel(ConvArgs a) {
                 const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < a.M) {
                     const size_t o = (size_t)row * a.Cout + col;
-                    float v = acc[i][j][r] + bv;
+                    float v = acc[i][j][r];
+                    if constexpr (NP == 2) v = v * un_a * un_w;
+                    v += bv;
                     if (a.resid) v += a.resid[o];
                     a.y[o] = v;
                 }
@@ -203,38 +287,23 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_b6_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// weight gradient on the bf16x6 path.  K = pixels, but NHWC tiles are pixel-major: the three bf16 planes are stored
-// [plane][pixel][channel] exactly as they arrive (one ds_write_b64 per plane per float4) and the MFMA fragments
-// (8 consecutive pixels of one channel per lane) are fetched with gfx950's transposing LDS read ds_read_b64_tr_b16:
-// in every 16-lane group lane s supplies the address of 4 consecutive channels of pixel row (s>>2), and lane c receives
-// element (c&3) of the chunks of lanes {c>>2, 4+(c>>2), 8+(c>>2), 12+(c>>2)}  (probed on hardware, tools/experiments/tr_b16.hip).
+// weight gradient.  K = pixels, but NHWC tiles are pixel-major: the planes are stored [plane][pixel][channel] exactly as
+// they arrive (one ds_write_b64 per plane per float4) and the MFMA fragments (8 consecutive pixels of one channel per lane)
+// are fetched with gfx950's transposing LDS read ds_read_b64_tr_b16: in every 16-lane group lane s supplies the address of
+// 4 consecutive channels of pixel row (s>>2), and lane c receives element (c&3) of the chunks of lanes
+// {c>>2, 4+(c>>2), 8+(c>>2), 12+(c>>2)}  (probed on hardware, tools/experiments/tr_b16.hip).
 // Pixel rows are padded to 320 B so that the 4 rows x 2 channel blocks a 32-lane half touches fall on different banks.
 // Preconditions as conv_wgrad_buf_kernel (plain gather, stride 1, Wout % 16 == 0, channels % 4 == 0), 128x128 tiles.
-// ---------------------------------------------------------------------------------------------------------------
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-typedef short s16x8_t __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
-
-namespace b6 {
-constexpr int RSB = 320;                   // bytes per pixel row of a plane (128 ch x 2 B + 64 B pad: conflict-free tr reads)
-constexpr int PLB = 16 * RSB;              // bytes per plane (16 pixels)
-constexpr int OPB = 3 * PLB;               // bytes per operand buffer
-
-__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* p) {
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + 4 * RSB));
-    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8_t, v);
-}
-}  // namespace b6
-
 // UPS: the conv input is the nearest-x2 upsampling of x (Upsample, models/codec.py:17) -- source pixel = virtual >> 1
-template <int XFORM, bool UPS>
-__global__ __launch_bounds__(256) void conv_wgrad_b6_kernel(WgradArgs a) {
+// ---------------------------------------------------------------------------------------------------------------
+template <int XFORM, bool UPS, int NP>
+__global__ __launch_bounds__(256) void conv_wgrad_sp_kernel(WgradArgs a) {
+    using S = sp::Scheme<NP>;
     constexpr int BCO = 128, BCI = 128, BKP = 16, MI = 2, NI = 2;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * b6::OPB];
-    unsigned char* Os = lds;                   // [2][3 planes][16 px][288 B]
-    unsigned char* Is = lds + 2 * b6::OPB;
+    constexpr int OPB = NP * sp::PLB;          // bytes per operand buffer
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * OPB];
+    unsigned char* Os = lds;                   // [2][NP planes][16 px][320 B]
+    unsigned char* Is = lds + 2 * OPB;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wo = wid >> 1, wi = wid & 1;
@@ -248,6 +317,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_b6_kernel(WgradArgs a) {
     const int p_begin = z * a.chunk;
     const int p_end = min(a.M, p_begin + a.chunk);
     const int T = (p_end > p_begin) ? (p_end - p_begin + BKP - 1) / BKP : 0;
+    const float So = NP == 2 ? sp::pow2_scale(a.dy_amax) : 1.f, Si = NP == 2 ? sp::pow2_scale(a.x_amax) : 1.f;
 
     const auto rx = make_rsrc(a.x, a.x_bytes);
     const auto rdy = make_rsrc(a.dy, (unsigned)p_end * (unsigned)a.Cout * 4u);
@@ -312,16 +382,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_b6_kernel(WgradArgs a) {
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            uint2 p0, p1, p2;
-            const int off = buf * b6::OPB + s_p[j] * b6::RSB + s_c[j] * 2;
-            b6::split4(ro[j], p0, p1, p2);
-            *reinterpret_cast<uint2*>(Os + off) = p0;
-            *reinterpret_cast<uint2*>(Os + off + b6::PLB) = p1;
-            *reinterpret_cast<uint2*>(Os + off + 2 * b6::PLB) = p2;
-            b6::split4(xform4_t<XFORM>(ri[j], rsc[j], rsh[j]), p0, p1, p2);
-            *reinterpret_cast<uint2*>(Is + off) = p0;
-            *reinterpret_cast<uint2*>(Is + off + b6::PLB) = p1;
-            *reinterpret_cast<uint2*>(Is + off + 2 * b6::PLB) = p2;
+            uint2 p[NP];
+            const int off = buf * OPB + s_p[j] * sp::RSB + s_c[j] * 2;
+            S::split4(ro[j], So, p);
+            sp::store_planes<NP>(Os + off, sp::PLB, p);
+            S::split4(xform4_t<XFORM>(ri[j], rsc[j], rsh[j]), Si, p);
+            sp::store_planes<NP>(Is + off, sp::PLB, p);
         }
     };
 
@@ -335,7 +401,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_b6_kernel(WgradArgs a) {
 
     // transposing fragment reads: lane = 16 g + s ; pixel row 8 (g>>1) + (s>>2) (+4 for the second read), channels 16 (g&1) + 4 (s&3)
     const int s16 = lane & 15, g = lane >> 4;
-    const int frag_off = (8 * (g >> 1) + (s16 >> 2)) * b6::RSB + (16 * (g & 1) + 4 * (s16 & 3)) * 2;
+    const int frag_off = (8 * (g >> 1) + (s16 >> 2)) * sp::RSB + (16 * (g & 1) + 4 * (s16 & 3)) * 2;
     const unsigned char* Ofr = Os + frag_off + wo * 64 * 2;
     const unsigned char* Ifr = Is + frag_off + wi * 64 * 2;
 
@@ -347,29 +413,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_b6_kernel(WgradArgs a) {
     for (int it = 0; it < T; ++it) {
         const int cur = it & 1;
         if (it + 1 < T) load_tiles();
-        bf16x8_t af[MI][3], bf[NI][3];
+        bf16x8_t af[MI][NP], bf[NI][NP];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[i][p] = b6::tr_frag(Ofr + cur * b6::OPB + p * b6::PLB + i * 64);
+            for (int p = 0; p < NP; ++p) af[i][p] = sp::tr_frag(Ofr + cur * OPB + p * sp::PLB + i * 64);
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[j][p] = b6::tr_frag(Ifr + cur * b6::OPB + p * b6::PLB + j * 64);
+            for (int p = 0; p < NP; ++p) bf[j][p] = sp::tr_frag(Ifr + cur * OPB + p * sp::PLB + j * 64);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < NI; ++j) S::mma(af[i], bf[j], acc[i][j]);
         if (it + 1 < T) store_tiles(cur ^ 1);
         __syncthreads();
     }
+    float un_o = 1.f, un_i = 1.f;
+    if constexpr (NP == 2) { un_o = sp::pow2_inv(So); un_i = sp::pow2_inv(Si); }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -379,54 +440,63 @@ __global__ __launch_bounds__(256) void conv_wgrad_b6_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wo * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < a.Cout) a.part[(((size_t)z * a.Cout + co) * taps + tap) * a.Cin + ci] = acc[i][j][r];
+                float v = acc[i][j][r];
+                if constexpr (NP == 2) v = v * un_o * un_i;
+                if (co < a.Cout) a.part[(((size_t)z * a.Cout + co) * taps + tap) * a.Cin + ci] = v;
             }
         }
 }
 
-
-// out: 24-byte records {plane0[4 bf16], plane1[4], plane2[4]} per 4 consecutive floats of `in` (n % 4 == 0)
-__global__ __launch_bounds__(256) void split3_kernel(const float4* __restrict__ in, unsigned* __restrict__ out, size_t n4) {
+// ---- weight pre-split ---------------------------------------------------------------------------------------------------
+// out: WREC-byte records {plane0[4], plane1[4] (, plane2[4])} per 4 consecutive floats of `in` (n % 4 == 0)
+template <int NP>
+__global__ __launch_bounds__(256) void split_w_kernel(const float4* __restrict__ in, unsigned* __restrict__ out, size_t n4,
+                                                      const float* __restrict__ amax) {
+    const float Sw = NP == 2 ? sp::pow2_scale(amax) : 1.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        uint2 p0, p1, p2;
-        b6::split4(in[i], p0, p1, p2);
-        unsigned* o = out + i * 6;
-        o[0] = p0.x; o[1] = p0.y; o[2] = p1.x; o[3] = p1.y; o[4] = p2.x; o[5] = p2.y;
+        uint2 p[NP];
+        sp::Scheme<NP>::split4(in[i], Sw, p);
+        unsigned* o = out + i * (2 * NP);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { o[2 * k] = p[k].x; o[2 * k + 1] = p[k].y; }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution with an LDS-staged halo tile (the "LDS-staged 3x3 input tiles" of the north star).
 // A workgroup owns an 8 x 16 pixel tile (= the 128 MFMA rows) x 128 output channels.  Per 16-channel K chunk the
-// (8+2) x (16+2) = 180-pixel input halo is loaded, transformed (fused GroupNorm/SiLU) and split into bf16 planes ONCE and
+// (8+2) x (16+2) = 180-pixel input halo is loaded, transformed (fused GroupNorm/SiLU) and split into planes ONCE and
 // then serves all 9 filter taps as shifted views -- 6.4x fewer activation loads / transforms / splits / LDS stores than the
-// tap-by-tap im2col staging of conv_fwd_b6_kernel (timing ablations: those were ~35 % of that kernel).  Weights arrive
-// pre-split (W6) and are streamed tap by tap through a second, double-buffered LDS tile.
+// tap-by-tap im2col staging of conv_fwd_sp_kernel (timing ablations: those were ~35 % of that kernel).  Weights arrive
+// pre-split and are streamed tap by tap through a second, double-buffered LDS tile.
 // Per-thread global offsets are constants of the launch: only the scalar offsets advance (K chunk, tap).
-// Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, H % 8 == 0, W % 16 == 0, Cin % 16 == 0, W6 weights.
+// Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, H % 8 == 0, W % 16 == 0, Cin % 16 == 0, pre-split weights.
 // ---------------------------------------------------------------------------------------------------------------
-template <int XFORM>
-__global__ __launch_bounds__(512) void conv3x3_halo_b6_kernel(ConvArgs a) {
+template <int XFORM, int NP>
+__global__ __launch_bounds__(512) void conv3x3_halo_sp_kernel(ConvArgs a) {
+    using S = sp::Scheme<NP>;
     constexpr int TH = 8, TW = 16, HW = TW + 2, HROWS = (TH + 2) * HW;          // 180 halo pixels
-    // halo row pitch 2048 B (18 x 112 + 32 pad): pitch % 256 == 0 puts the second tile row of a wave's 32 MFMA rows on the
-    // same bank phase as pixels 16..31 of a contiguous run -> the ds_read_b128 fragment reads are conflict-free (2-way at 2016)
-    constexpr int HPITCH = 2048;
-    constexpr int HALO_B = (TH + 2) * HPITCH, BT_B = 128 * b6::ROWB;
+    // halo row pitch = 18 rows rounded up to a multiple of 256 B: pitch % 256 == 0 puts the second tile row of a wave's 32 MFMA
+    // rows on the same bank phase as pixels 16..31 of a contiguous run -> the ds_read_b128 fragment reads are conflict-free
+    constexpr int HPITCH = (HW * S::ROWB + 255) / 256 * 256;
+    static_assert((16 * S::ROWB) % 256 == 0, "row stride must keep 16-pixel runs bank-periodic");
+    constexpr int HALO_B = (TH + 2) * HPITCH, BT_B = 128 * S::ROWB;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO_B + 2 * BT_B];
-    unsigned char* Hs = lds;                    // [2][10][2048]
-    unsigned char* Bs = lds + 2 * HALO_B;       // [2][128][112]
+    unsigned char* Hs = lds;                    // [2][10][HPITCH]
+    unsigned char* Bs = lds + 2 * HALO_B;       // [2][128][ROWB]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;      // 4 x 2 waves of 32 x 64
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = tile % a.tiles_n;
-    int sp = tile / a.tiles_n;                  // spatial tile index
+    int spt = tile / a.tiles_n;                 // spatial tile index
     const int tiles_w = a.Win / TW, tiles_h = a.Hin / TH;
-    const int tx0 = (sp % tiles_w) * TW; sp /= tiles_w;
-    const int ty0 = (sp % tiles_h) * TH;
-    const int n = sp / tiles_h;
+    const int tx0 = (spt % tiles_w) * TW; spt /= tiles_w;
+    const int ty0 = (spt % tiles_h) * TH;
+    const int n = spt / tiles_h;
     const int n0 = tn * 128;
     const int q4 = tid & 3;
+    const float Sa = NP == 2 ? sp::pow2_scale(a.x_amax) : 1.f;
 
     const auto rx = make_rsrc(a.x, a.x_bytes);
     const auto rw = make_rsrc(a.w, a.w_bytes);
@@ -435,23 +505,23 @@ __global__ __launch_bounds__(512) void conv3x3_halo_b6_kernel(ConvArgs a) {
 
     // halo staging slots of this thread (720 float4 over 512 threads): constant offsets
     unsigned vh[2], vs[2];
-    int hrow[2], hoff[2];
+    int hoff[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i = tid + 512 * j;
-        hrow[j] = i >> 2;
-        const int hy = hrow[j] / HW, hx = hrow[j] - hy * HW;
-        hoff[j] = hy * HPITCH + hx * b6::ROWB;
+        const int hrow = i >> 2;
+        const int hy = hrow / HW, hx = hrow - hy * HW;
+        hoff[j] = hy * HPITCH + hx * S::ROWB;
         const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
-        const bool ok = hrow[j] < HROWS && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
+        const bool ok = hrow < HROWS && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
         vh[j] = ok ? (unsigned)((((n * a.Hin + y) * a.Win + x) * a.Cin + q4 * 4) * 4) : FAVAE_OOB;
         vs[j] = ok ? (unsigned)((n * a.aff_stride + q4 * 4) * 4) : FAVAE_OOB;
     }
     const int brow = tid >> 2;                                           // weight row (output channel) staged by this thread
-    const unsigned vb = (n0 + brow < a.Cout) ? (unsigned)(((n0 + brow) * 9 * a.Cin + q4 * 4) * 6) : FAVAE_OOB;
+    const unsigned vb = (n0 + brow < a.Cout) ? (unsigned)(((n0 + brow) * 9 * a.Cin + q4 * 4) / 4 * S::WREC) : FAVAE_OOB;
 
-    float4 rh[2], rsc[2], rsh[2], rb;
-    uint2 rb2;
+    float4 rh[2], rsc[2], rsh[2];
+    uint2 rbp[NP];
     auto load_halo = [&](int kc) {
         const unsigned sk = (unsigned)(kc * 64);
 #pragma unroll
@@ -468,25 +538,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_b6_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && tid >= HROWS * 4 - 512) continue;
-            uint2 p0, p1, p2;
-            b6::split4(xform4_t<XFORM>(rh[j], rsc[j], rsh[j]), p0, p1, p2);
-            unsigned char* d = Hs + buf * HALO_B + hoff[j] + q4 * 8;
-            *reinterpret_cast<uint2*>(d) = p0;
-            *reinterpret_cast<uint2*>(d + 32) = p1;
-            *reinterpret_cast<uint2*>(d + 64) = p2;
+            uint2 p[NP];
+            S::split4(xform4_t<XFORM>(rh[j], rsc[j], rsh[j]), Sa, p);
+            sp::store_planes<NP>(Hs + buf * HALO_B + hoff[j] + q4 * 8, 32, p);
         }
     };
-    auto load_b = [&](int kc, int tap) {
-        const unsigned sw = (unsigned)((tap * a.Cin + kc * 16) * 6);
-        rb = bload(rw, vb, sw);
-        rb2 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rw, vb + 16u, sw, 0));
-    };
-    auto store_b = [&](int buf) {
-        unsigned char* d = Bs + buf * BT_B + brow * b6::ROWB + q4 * 8;
-        *reinterpret_cast<uint2*>(d) = make_uint2(__float_as_uint(rb.x), __float_as_uint(rb.y));
-        *reinterpret_cast<uint2*>(d + 32) = make_uint2(__float_as_uint(rb.z), __float_as_uint(rb.w));
-        *reinterpret_cast<uint2*>(d + 64) = rb2;
-    };
+    auto load_b = [&](int kc, int tap) { sp::load_wrec<NP>(rw, vb, (unsigned)((tap * a.Cin + kc * 16) / 4 * S::WREC), rbp); };
+    auto store_b = [&](int buf) { sp::store_planes<NP>(Bs + buf * BT_B + brow * S::ROWB + q4 * 8, 32, rbp); };
 
     f32x16 acc[2];
 #pragma unroll
@@ -494,11 +552,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_b6_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // fragment addressing: MFMA row = pixel p = wm*32 + (lane&31) of the 8x16 tile -> halo row (ty+kh)*18 + tx+kw
+    // fragment addressing: MFMA row = pixel p = wm*32 + (lane&31) of the 8x16 tile -> halo row (ty+kh), column tx+kw
     const int p = wm * 32 + (lane & 31);
     const int fh = (lane >> 5) * 16;
-    const unsigned char* Afr = Hs + (p >> 4) * HPITCH + (p & 15) * b6::ROWB + fh;
-    const unsigned char* Bfr = Bs + (wn * 64 + (lane & 31)) * b6::ROWB + fh;
+    const unsigned char* Afr = Hs + (p >> 4) * HPITCH + (p & 15) * S::ROWB + fh;
+    const unsigned char* Bfr = Bs + (wn * 64 + (lane & 31)) * S::ROWB + fh;
 
     const int KC = a.Cin / 16;
     load_halo(0);
@@ -517,30 +575,25 @@ __global__ __launch_bounds__(512) void conv3x3_halo_b6_kernel(ConvArgs a) {
             else if (more_kc) load_b(kc + 1, 0);
             if (tap == 4 && more_kc) load_halo(kc + 1);                  // in flight over taps 4..8
             const int kh = tap / 3, kw = tap - kh * 3;
-            const unsigned char* Ab = Afr + hb * HALO_B + kh * HPITCH + kw * b6::ROWB;
+            const unsigned char* Ab = Afr + hb * HALO_B + kh * HPITCH + kw * S::ROWB;
             const unsigned char* Bb = Bfr + cur * BT_B;
-            bf16x8_t af[3], bf[2][3];
+            bf16x8_t af[NP], bf[2][NP];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8_t*>(Ab + pl * 32);
+            for (int pl = 0; pl < NP; ++pl) af[pl] = *reinterpret_cast<const bf16x8_t*>(Ab + pl * 32);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8_t*>(Bb + j * 32 * b6::ROWB + pl * 32);
+                for (int pl = 0; pl < NP; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8_t*>(Bb + j * 32 * S::ROWB + pl * 32);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[j][0], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][2], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][1], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][0], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][1], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][0], acc[j], 0, 0, 0);
-            }
+            for (int j = 0; j < 2; ++j) S::mma(af, bf[j], acc[j]);
             if (!last_tap || more_kc) store_b(cur ^ 1);
             if (last_tap && more_kc) store_halo(hb ^ 1);
             __syncthreads();
         }
     }
 
+    float un_a = 1.f, un_w = 1.f;
+    if constexpr (NP == 2) { un_a = sp::pow2_inv(Sa); un_w = sp::pow2_inv(sp::pow2_scale(a.w_amax)); }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + (lane & 31);
@@ -550,7 +603,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_b6_kernel(ConvArgs a) {
         for (int r = 0; r < 16; ++r) {
             const int pr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);          // pixel of the tile
             const size_t o = ((size_t)((n * a.Hin + ty0 + (pr >> 4)) * a.Win + tx0 + (pr & 15))) * a.Cout + col;
-            float v = acc[j][r] + bv;
+            float v = acc[j][r];
+            if constexpr (NP == 2) v = v * un_a * un_w;
+            v += bv;
             if (a.resid) v += a.resid[o];
             a.y[o] = v;
         }
@@ -561,13 +616,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_b6_kernel(ConvArgs a) {
 // 3x3 weight gradient, three taps per workgroup: a workgroup owns (128 co x 128 ci, one filter ROW kh) and accumulates the
 // taps kw = 0,1,2 together.  Per 16-pixel step it stages ONE dy tile (16 px) and ONE 18-pixel input halo row, which serve
 // the three taps as shifted pixel windows of the transposing fragment reads -- 2.8x fewer loads / transforms / splits /
-// LDS stores per MFMA than the tap-per-workgroup conv_wgrad_b6_kernel.  8 waves (4 co x 2 ci, 32 x 64 each, 3 taps).
+// LDS stores per MFMA than the tap-per-workgroup conv_wgrad_sp_kernel.  8 waves (4 co x 2 ci, 32 x 64 each, 3 taps).
 // Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, Wout % 16 == 0, channels % 4 == 0, operands < 2 GiB.
 // ---------------------------------------------------------------------------------------------------------------
-template <int XFORM>
-__global__ __launch_bounds__(512) void conv_wgrad_row3_b6_kernel(WgradArgs a) {
-    constexpr int OPL = 16 * b6::RSB, IPL = 18 * b6::RSB;           // bytes per plane (dy: 16 px, x: 18 px)
-    constexpr int OB = 3 * OPL, IB = 3 * IPL;
+template <int XFORM, int NP>
+__global__ __launch_bounds__(512) void conv_wgrad_row3_sp_kernel(WgradArgs a) {
+    using S = sp::Scheme<NP>;
+    constexpr int OPL = 16 * sp::RSB, IPL = 18 * sp::RSB;           // bytes per plane (dy: 16 px, x: 18 px)
+    constexpr int OB = NP * OPL, IB = NP * IPL;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (OB + IB)];
     unsigned char* Os = lds;
     unsigned char* Is = lds + 2 * OB;
@@ -582,15 +638,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_b6_kernel(WgradArgs a) {
     const int p_begin = z * a.chunk;
     const int p_end = min(a.M, p_begin + a.chunk);
     const int T = (p_end > p_begin) ? (p_end - p_begin + 15) / 16 : 0;
+    const float So = NP == 2 ? sp::pow2_scale(a.dy_amax) : 1.f, Si = NP == 2 ? sp::pow2_scale(a.x_amax) : 1.f;
 
     const auto rx = make_rsrc(a.x, a.x_bytes);
     const auto rdy = make_rsrc(a.dy, (unsigned)p_end * (unsigned)a.Cout * 4u);
     const auto rsc_d = make_rsrc(XFORM ? a.scale : a.x, XFORM ? a.aff_bytes : 0u);
     const auto rsh_d = make_rsrc(XFORM ? a.shift : a.x, XFORM ? a.aff_bytes : 0u);
 
-    const int sp = tid >> 5, sq = (tid & 31) * 4;                   // staging slot: pixel (0..15), channel
+    const int spx = tid >> 5, sq = (tid & 31) * 4;                  // staging slot: pixel (0..15), channel
     const bool two = tid < 64;                                      // second x slot: halo pixels 16, 17
-    const unsigned voo = (co0 + sq < a.Cout) ? (unsigned)((sp * a.Cout + co0 + sq) * 4) : FAVAE_OOB;
+    const unsigned voo = (co0 + sq < a.Cout) ? (unsigned)((spx * a.Cout + co0 + sq) * 4) : FAVAE_OOB;
     const bool ci_ok = ci0 + sq < a.Cin;
     const unsigned vsc = (unsigned)((ci0 + sq) * 4);
 
@@ -615,7 +672,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_b6_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && !two) continue;
-            const int iw = s_ow - 1 + sp + 16 * j;
+            const int iw = s_ow - 1 + spx + 16 * j;
             const bool ok = row_ok && ci_ok && (unsigned)iw < (unsigned)a.Win;
             ri[j] = bload(rx, ok ? (unsigned)((iw * a.Cin + ci0 + sq) * 4) : FAVAE_OOB, sx);
             if (XFORM) {
@@ -631,20 +688,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_b6_kernel(WgradArgs a) {
         }
     };
     auto store_tiles = [&](int buf) {
-        uint2 p0, p1, p2;
-        b6::split4(ro, p0, p1, p2);
-        unsigned char* d = Os + buf * OB + sp * b6::RSB + sq * 2;
-        *reinterpret_cast<uint2*>(d) = p0;
-        *reinterpret_cast<uint2*>(d + OPL) = p1;
-        *reinterpret_cast<uint2*>(d + 2 * OPL) = p2;
+        uint2 p[NP];
+        S::split4(ro, So, p);
+        sp::store_planes<NP>(Os + buf * OB + spx * sp::RSB + sq * 2, OPL, p);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && !two) continue;
-            b6::split4(xform4_t<XFORM>(ri[j], rsc[j], rsh[j]), p0, p1, p2);
-            d = Is + buf * IB + (sp + 16 * j) * b6::RSB + sq * 2;
-            *reinterpret_cast<uint2*>(d) = p0;
-            *reinterpret_cast<uint2*>(d + IPL) = p1;
-            *reinterpret_cast<uint2*>(d + 2 * IPL) = p2;
+            S::split4(xform4_t<XFORM>(ri[j], rsc[j], rsh[j]), Si, p);
+            sp::store_planes<NP>(Is + buf * IB + (spx + 16 * j) * sp::RSB + sq * 2, IPL, p);
         }
     };
 
@@ -657,7 +708,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_b6_kernel(WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[k][j][r] = 0.f;
 
     const int s16 = lane & 15, g = lane >> 4;
-    const int frag_off = (8 * (g >> 1) + (s16 >> 2)) * b6::RSB + (16 * (g & 1) + 4 * (s16 & 3)) * 2;
+    const int frag_off = (8 * (g >> 1) + (s16 >> 2)) * sp::RSB + (16 * (g & 1) + 4 * (s16 & 3)) * 2;
     const unsigned char* Ofr = Os + frag_off + wo * 32 * 2;
     const unsigned char* Ifr = Is + frag_off + wi * 64 * 2;
 
@@ -669,36 +720,23 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_b6_kernel(WgradArgs a) {
     for (int it = 0; it < T; ++it) {
         const int cur = it & 1;
         if (it + 1 < T) load_tiles();
-        bf16x8_t af[3];
+        bf16x8_t af[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const unsigned char* q = Ofr + cur * OB + p * OPL;
-            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(q));
-            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(q + 4 * b6::RSB));
-            af[p] = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        }
+        for (int p = 0; p < NP; ++p) af[p] = sp::tr_frag(Ofr + cur * OB + p * OPL);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                bf16x8_t bf[3];
+                bf16x8_t bf[NP];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    const unsigned char* q = Ifr + cur * IB + p * IPL + kw * b6::RSB + j * 64;
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(q));
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(q + 4 * b6::RSB));
-                    bf[p] = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
-                acc[kw][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[kw][j], 0, 0, 0);
-                acc[kw][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[kw][j], 0, 0, 0);
-                acc[kw][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[kw][j], 0, 0, 0);
-                acc[kw][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[kw][j], 0, 0, 0);
-                acc[kw][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[kw][j], 0, 0, 0);
-                acc[kw][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[kw][j], 0, 0, 0);
+                for (int p = 0; p < NP; ++p) bf[p] = sp::tr_frag(Ifr + cur * IB + p * IPL + kw * sp::RSB + j * 64);
+                S::mma(af, bf, acc[kw][j]);
             }
         if (it + 1 < T) store_tiles(cur ^ 1);
         __syncthreads();
     }
+    float un_o = 1.f, un_i = 1.f;
+    if constexpr (NP == 2) { un_o = sp::pow2_inv(So); un_i = sp::pow2_inv(Si); }
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
@@ -708,7 +746,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_b6_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < a.Cout) a.part[(((size_t)z * a.Cout + co) * 9 + kh * 3 + kw) * a.Cin + ci] = acc[kw][j][r];
+                float v = acc[kw][j][r];
+                if constexpr (NP == 2) v = v * un_o * un_i;
+                if (co < a.Cout) a.part[(((size_t)z * a.Cout + co) * 9 + kh * 3 + kw) * a.Cin + ci] = v;
             }
         }
 }

@@ -122,7 +122,7 @@ int diff_sum(const float* a, const float* b, int64_t n, float scale, float* loss
 
 }  // namespace
 
-extern "C" int favae_abi_version(void) { return 3; }
+extern "C" int favae_abi_version(void) { return 4; }
 
 extern "C" size_t favae_reduce_workspace(int64_t n) { (void)n; return RED_BLOCKS * sizeof(double); }
 

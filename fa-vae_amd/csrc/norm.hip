@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
                                                           const float* __restrict__ beta, float* __restrict__ mean,
                                                           float* __restrict__ rstd, float* __restrict__ scale,
                                                           float* __restrict__ shift, double* __restrict__ acc, long HW, int C,
-                                                          int G, int S, float eps) {
+                                                          int G, int S, float eps, unsigned* __restrict__ absmax) {
     const int n = blockIdx.x;
     const int cpg = C / G;
     double* a = acc + (size_t)n * C * 2;
@@ -136,7 +136,11 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
         rstd[n * G + g] = (float)(1.0 / sqrt(var + (double)eps));
     }
     __syncthreads();
+    float bound = 0.f;
     if (scale) {
+        // |gamma (x - mu) rstd + beta| <= |gamma| sqrt(count) + |beta|  (sum of squares of the normalised group = count), and
+        // |SiLU(t)|, |LeakyReLU(t)| <= |t|: an upper bound of the transformed activations for the fp16 split scale (conv_split.h)
+        const float root = sqrtf((float)cpg * (float)HW);
         for (int c = threadIdx.x; c < C; c += 256) {
             const int g = c / cpg;
             const float mu = mean[n * G + g], rs = rstd[n * G + g];
@@ -144,7 +148,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
             const float sc = rs * ga;
             scale[(size_t)n * C + c] = sc;
             shift[(size_t)n * C + c] = be - mu * sc;
+            bound = fmaxf(bound, fmaf(fabsf(ga), root, fabsf(be)));
         }
+    }
+    if (absmax) {
+        bound = wave_max(bound);
+        if ((threadIdx.x & 63) == 0) atomicMax(absmax, __float_as_uint(bound));
     }
 }
 
@@ -289,18 +298,20 @@ extern "C" size_t favae_gn_workspace(int N, int64_t HW, int C) {
 }
 
 extern "C" int favae_gn_stats(const float* x, const float* gamma, const float* beta, int N, int64_t HW, int C, int G,
-                              float eps, float* mean, float* rstd, float* scale, float* shift, void* ws, size_t ws_bytes,
-                              favae_stream_t stream) {
+                              float eps, float* mean, float* rstd, float* scale, float* shift, float* absmax_out, void* ws,
+                              size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(x && mean && rstd && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     if (ws_bytes < favae_gn_workspace(N, HW, C)) return FAVAE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     double* part = (double*)ws;
     double* acc = (double*)((char*)ws + part_bytes(N, HW, C));
+    FAVAE_REQUIRE(!absmax_out || scale);
+    if (absmax_out && hipMemsetAsync(absmax_out, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
     launch_partial<0>(x, nullptr, gamma, beta, nullptr, nullptr, part, N, (long)HW, C, G, 0, s);
     FAVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
-                       acc, (long)HW, C, G, gn_splits(N, HW), eps);
+                       acc, (long)HW, C, G, gn_splits(N, HW), eps, (unsigned*)absmax_out);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }

@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfavae_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02 = 0, 1, 2
@@ -33,16 +33,18 @@ SIGNATURES = {
     "favae_abi_version": (c_int, []),
     "favae_conv_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _S]),
     "favae_conv_wants_split_weights": (c_int, [POINTER(ConvDesc), c_int]),
-    "favae_split3": (c_int, [_P, _P, c_int64, _S]),
-    "favae_conv_fwd_w6": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _S]),
+    "favae_split_weights_bytes": (c_size_t, [c_int64, c_int]),
+    "favae_split_weights": (c_int, [_P, _P, c_int64, c_int, _S]),
+    "favae_conv_fwd_split": (c_int, [POINTER(ConvDesc), _P, _P, c_int, _P, _P, _P, _P, _P, _P, _S]),
+    "favae_absmax": (c_int, [_P, c_int64, _P, _S]),
     "favae_conv_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
-    "favae_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, c_int, _P, c_size_t, _S]),
+    "favae_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _S]),
     "favae_weight_flip": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     "favae_colsum_workspace": (c_size_t, [c_int64, c_int]),
     "favae_colsum": (c_int, [_P, _P, c_int64, c_int, c_int, _P, c_size_t, _S]),
     "favae_upsample2x_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     "favae_gn_workspace": (c_size_t, [c_int, c_int64, c_int]),
-    "favae_gn_stats": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_size_t, _S]),
+    "favae_gn_stats": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _S]),
     "favae_gn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_size_t, _S]),
     "favae_bn_update_running": (c_int, [_P, _P, c_int, c_int64, c_float, c_float, _P, _P, _S]),
     "favae_bgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int64, c_int64, _P, c_int64, c_int64, _P,

@@ -114,18 +114,42 @@ def weight_ohwi(w):
 # ---------------------------------------------------------------------------------------------------------------
 # GroupNorm statistics (no autograd by itself; used inside FusedConv)
 # ---------------------------------------------------------------------------------------------------------------
-def gn_stats(x, gamma, beta, groups, eps=1e-5):
+def gn_stats(x, gamma, beta, groups, eps=1e-5, with_bound=False):
+    """GroupNorm statistics + the per-(image, channel) affine the conv kernels apply on load.  with_bound: also return the
+    device scalar bounding |act(GN(x))| that the fp16 split-precision conv kernels scale their operand with."""
     N, C, H, W = x.shape
     dev = x.device
     mean = torch.empty((N, groups), dtype=torch.float32, device=dev)
     rstd = torch.empty_like(mean)
     scale = torch.empty((N, C), dtype=torch.float32, device=dev)
     shift = torch.empty_like(scale)
+    bound = torch.empty((1,), dtype=torch.float32, device=dev) if with_bound else None
     nb = query("favae_gn_workspace", N, H * W, C)
     ws = workspace(nb, dev)
     call("favae_gn_stats", ptr(x), ptr(gamma), ptr(beta), N, H * W, C, groups, eps, ptr(mean), ptr(rstd), ptr(scale),
-         ptr(shift), ptr(ws), ws.numel())
+         ptr(shift), ptr(bound), ptr(ws), ws.numel())
+    if with_bound:
+        return mean, rstd, scale, shift, bound
     return mean, rstd, scale, shift
+
+
+_FP16_PLANES = None
+
+
+def _fp16_planes():
+    """True when the library runs its split-precision convs with two scaled fp16 planes (FAVAE_CONV_MODE=h3, the default)."""
+    global _FP16_PLANES
+    if _FP16_PLANES is None:
+        d = make_conv_desc(1, 16, 16, 128, 16, 16, 128, 3, 3, 1, 1, GATHER_PLAIN, ACT_NONE, 1)
+        _FP16_PLANES = query("favae_conv_wants_split_weights", byref(d), 0) == 2
+    return _FP16_PLANES
+
+
+def absmax(t):
+    """device scalar max|t| (operand range of the fp16 split-precision conv kernels)"""
+    out = torch.empty((1,), dtype=torch.float32, device=t.device)
+    call("favae_absmax", ptr(t), t.numel(), ptr(out))
+    return out
 
 
 def _direct_grad(p):
@@ -157,14 +181,21 @@ class ConvCfg:
         return Ho, Wo
 
 
-def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y):
-    """conv forward / data gradient; weights are pre-split into the 3 x bf16 record format when the library runs this
-    shape on the bf16x6 matrix path (the split is then done once per call instead of once per tile in the K loop)."""
-    if query("favae_conv_wants_split_weights", byref(d), 0 if scale is None else 1):
+def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None):
+    """conv forward / data gradient.  When the library runs this shape on the split-precision matrix path the weights are
+    pre-split once per call (instead of once per tile in the K loop); the fp16 scheme (2 planes) also needs the operand
+    range: `x_bound` = device scalar >= max|T(x)| (computed here for an un-transformed operand when not supplied)."""
+    planes = query("favae_conv_wants_split_weights", byref(d), 0 if scale is None else 1)
+    if planes:
         n = w_ohwi.numel()
-        w6 = torch.empty((n // 4) * 24, dtype=torch.uint8, device=w_ohwi.device)
-        call("favae_split3", ptr(w_ohwi), ptr(w6), n)
-        call("favae_conv_fwd_w6", byref(d), ptr(x), ptr(w6), ptr(b), ptr(resid), ptr(scale), ptr(shift), ptr(y))
+        wsp = torch.empty(query("favae_split_weights_bytes", n, planes), dtype=torch.uint8, device=w_ohwi.device)
+        call("favae_split_weights", ptr(w_ohwi), ptr(wsp), n, planes)
+        if planes == 2 and x_bound is None:
+            if scale is not None:
+                raise RuntimeError("a transformed conv operand needs its range bound (gn_stats(with_bound=True))")
+            x_bound = absmax(x)
+        call("favae_conv_fwd_split", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
+             ptr(shift), ptr(y))
     else:
         call("favae_conv_fwd", byref(d), ptr(x), ptr(w_ohwi), ptr(b), ptr(resid), ptr(scale), ptr(shift), ptr(y))
 
@@ -184,27 +215,29 @@ class FusedConvFn(torch.autograd.Function):
         Cout = w4.shape[0]
         Ho, Wo = cfg.out_hw(Hin, Win)
         dev = x.device
-        mean = rstd = scale = shift = None
+        mean = rstd = scale = shift = xb = None
         if gn_w is not None:
-            mean, rstd, scale, shift = gn_stats(x, gn_w, gn_b, cfg.groups, cfg.eps)
+            mean, rstd, scale, shift, xb = gn_stats(x, gn_w, gn_b, cfg.groups, cfg.eps, with_bound=True)
         if resid is not None:
             resid = to_cl(resid)
         y = new_cl(N, Cout, Ho, Wo, dev)
         d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad,
                            GATHER_UPSAMPLE2 if cfg.upsample else GATHER_PLAIN, cfg.act if gn_w is not None else ACT_NONE, 1)
-        _conv_launch(d, x, wk, b, resid, scale, shift, y)
+        if xb is None and query("favae_conv_wants_split_weights", byref(d), 0) == 2:
+            xb = absmax(x)
+        _conv_launch(d, x, wk, b, resid, scale, shift, y, xb)
         ctx.cfg = cfg
         ctx.has_b = b is not None
         ctx.has_gn = gn_w is not None
         ctx.has_res = resid is not None
         ctx.w_dim = w.dim()
         ctx.params = (w, b, gn_w, gn_b)           # to reach pre-assigned flat-buffer gradients (see _direct_grad)
-        ctx.save_for_backward(x, wk, gn_w, gn_b, mean, rstd, scale, shift)
+        ctx.save_for_backward(x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, wk, gn_w, gn_b, mean, rstd, scale, shift = ctx.saved_tensors
+        x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb = ctx.saved_tensors
         cfg = ctx.cfg
         dy = to_cl(dy)
         N, Cin, Hin, Win = x.shape
@@ -222,18 +255,21 @@ class FusedConvFn(torch.autograd.Function):
             if tgt is None:
                 db = torch.empty((Cout,), dtype=torch.float32, device=dev)
             call("favae_colsum", ptr(dy), ptr(db if tgt is None else tgt), M, Cout, 0 if tgt is None else 1, ptr(ws), ws.numel())
+        dyb = absmax(dy) if (xb is not None and _fp16_planes()) else None     # range of dy for the fp16 split scheme
         if need_w:
             d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad, gather, act, 1)
             ws = workspace(query("favae_conv_wgrad_workspace", byref(d)), dev)
             tgt = _direct_grad(p_w)
             if tgt is None:
                 dwk = torch.empty((Cout, cfg.kh, cfg.kw, Cin), dtype=torch.float32, device=dev)
-                call("favae_conv_wgrad", byref(d), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(dwk), 0, ptr(ws), ws.numel())
+                call("favae_conv_wgrad", byref(d), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(dwk), 0,
+                     ptr(ws), ws.numel())
                 dw = dwk.permute(0, 3, 1, 2)                  # (Cout,Cin,KH,KW) view with channels-last strides
                 if ctx.w_dim == 2:
                     dw = dwk.view(Cout, Cin)
             else:                                             # accumulate straight into the flat gradient buffer
-                call("favae_conv_wgrad", byref(d), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(tgt), 1, ptr(ws), ws.numel())
+                call("favae_conv_wgrad", byref(d), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(tgt), 1,
+                     ptr(ws), ws.numel())
         if need_x or ctx.has_gn:
             wt = torch.empty((Cin, cfg.kh, cfg.kw, Cout), dtype=torch.float32, device=dev)
             call("favae_weight_flip", ptr(wk), ptr(wt), Cout, cfg.kh, cfg.kw, Cin)
@@ -247,7 +283,7 @@ class FusedConvFn(torch.autograd.Function):
                 raise RuntimeError("unsupported conv geometry for the data gradient")
             da = new_cl(N, Cin, Hv, Wv, dev)
             d2 = make_conv_desc(N, Ho, Wo, Cout, Hv, Wv, Cin, cfg.kh, cfg.kw, 1, pad2, g2, ACT_NONE, 1)
-            _conv_launch(d2, dy, wt, None, None, None, None, da)
+            _conv_launch(d2, dy, wt, None, None, None, None, da, dyb)
             if cfg.upsample:
                 dlow = new_cl(N, Cin, Hin, Win, dev)
                 call("favae_upsample2x_bwd", ptr(da), ptr(dlow), N, Hin, Win, Cin)

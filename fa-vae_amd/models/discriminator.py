@@ -75,7 +75,7 @@ class Discriminator(nn.Module):
                 shift = torch.empty_like(scale)
                 ws = H.workspace(H.query("favae_gn_workspace", 1, N * Hh * Ww, C), dev)
                 H.call("favae_gn_stats", H.ptr(h), H.ptr(bn.weight), H.ptr(bn.bias), 1, N * Hh * Ww, C, C, bn.eps, H.ptr(mean),
-                       H.ptr(rstd), H.ptr(scale), H.ptr(shift), H.ptr(ws), ws.numel())
+                       H.ptr(rstd), H.ptr(scale), H.ptr(shift), None, H.ptr(ws), ws.numel())
                 if self.training and bn.track_running_stats:
                     H.call("favae_bn_update_running", H.ptr(mean), H.ptr(rstd), C, N * Hh * Ww, bn.eps, bn.momentum,
                            H.ptr(bn.running_mean), H.ptr(bn.running_var))

@@ -68,19 +68,30 @@ typedef struct {
 int favae_conv_fwd(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                    const float* scale, const float* shift, float* y, favae_stream_t stream);
 
-/* Pre-split weight path (exact 3 x bf16 operand split): favae_conv_wants_split_weights() tells whether the
- * library would run this conv on the bf16x6 matrix path; if so the caller may split the OHWI weights once with
- * favae_split3() (out = 6 bytes per input float) and call favae_conv_fwd_w6() -- same semantics as favae_conv_fwd. */
+/* Split-precision path (fp32 convolution on the 16-bit matrix pipe).
+ * favae_conv_wants_split_weights() returns the number of planes the library would run this conv with: 0 (fp32-MFMA kernels,
+ * use favae_conv_fwd), 3 (three bf16 planes, six products) or 2 (two scaled fp16 planes, three products).  For 2 or 3 the
+ * caller splits the OHWI weights once with favae_split_weights() into a buffer of favae_split_weights_bytes() and calls
+ * favae_conv_fwd_split() -- same semantics as favae_conv_fwd.  With planes == 2 the kernels also need `x_absmax`: a device
+ * float holding an upper bound of |T(x)| (favae_absmax() of x for T = identity; the bound favae_gn_stats() emits otherwise);
+ * planes == 3 has no range restriction and ignores it.  Both schemes keep fp32-grade products (tools/conv_accuracy.py). */
 int favae_conv_wants_split_weights(const favae_conv_desc* d, int has_affine);
-int favae_split3(const float* in, void* out, int64_t n, favae_stream_t stream);
-int favae_conv_fwd_w6(const favae_conv_desc* d, const float* x, const void* w6, const float* bias, const float* resid,
-                      const float* scale, const float* shift, float* y, favae_stream_t stream);
+size_t favae_split_weights_bytes(int64_t n, int planes);
+int favae_split_weights(const float* in, void* out, int64_t n, int planes, favae_stream_t stream);
+int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, const void* wsplit, int planes, const float* x_absmax,
+                         const float* bias, const float* resid, const float* scale, const float* shift, float* y,
+                         favae_stream_t stream);
+/* out[0] = max |x[i]| (device scalar) */
+int favae_absmax(const float* x, int64_t n, float* out, favae_stream_t stream);
 
 /* dw[co][kh][kw][ci] = sum_{n,oh,ow} dy[n,oh,ow,co] * T(x)[gathered (n,oh,ow,kh,kw), ci]   (split-K, deterministic:
  * partial slabs in `ws`, summed in a fixed order).  autograd's convolution_backward weight path. */
 size_t favae_conv_wgrad_workspace(const favae_conv_desc* d);
+/* x_absmax / dy_absmax: device bounds of |T(x)| and |dy| as for favae_conv_fwd_split (both or neither; NULL -> the bf16
+ * planes or the fp32-MFMA kernels run). */
 int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const float* dy, const float* scale, const float* shift,
-                     float* dw, int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream);
+                     const float* x_absmax, const float* dy_absmax, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                     favae_stream_t stream);
 
 /* wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]  (weights of the data-gradient convolution) */
 int favae_weight_flip(const float* w, float* wt, int Cout, int KH, int KW, int Cin, favae_stream_t stream);
@@ -101,9 +112,12 @@ int favae_upsample2x_bwd(const float* du, float* dx, int N, int H, int W, int C,
  * ---------------------------------------------------------------------------------------------------------- */
 /* mean/rstd: [N][G] (biased variance, eps inside the sqrt); scale[n][c] = rstd*gamma[c], shift[n][c] = beta[c] -
  * mean*rstd*gamma[c] -- the per-(image,channel) affine the conv kernels apply on load. */
+/* absmax_out (optional device float): upper bound of |act(x*scale+shift)| over the whole tensor, max_c |gamma_c| sqrt(group
+ * size) + |beta_c| -- the operand range the fp16 split-precision conv kernels need (favae_conv_fwd_split). */
 size_t favae_gn_workspace(int N, int64_t HW, int C);
 int favae_gn_stats(const float* x, const float* gamma, const float* beta, int N, int64_t HW, int C, int G, float eps,
-                   float* mean, float* rstd, float* scale, float* shift, void* ws, size_t ws_bytes, favae_stream_t stream);
+                   float* mean, float* rstd, float* scale, float* shift, float* absmax_out, void* ws, size_t ws_bytes,
+                   favae_stream_t stream);
 
 /* Given da = dL/d act(GN(x)): dx, dgamma[C], dbeta[C].  act as in favae_conv_desc.  If `dx_add` != NULL it is
  * added to dx (fused skip-connection gradient).  dx may alias da. */

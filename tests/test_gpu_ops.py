@@ -55,6 +55,13 @@ CONV_CASES = [
     (2, 256, 8, 8, 128, 1, 1, 0, 0, False, None, True),        # 1x1 shortcut + residual
     (1, 8, 6, 7, 8, 3, 1, 1, 1, False, 4, False),              # tiny channels, groups=4
     (3, 40, 17, 13, 200, 3, 1, 1, 1, False, 8, True),          # ragged tiles everywhere
+    # split-precision matrix path (Cin % 16 == 0, Cout > 64): LDS-halo 3x3 kernel, row3 / per-tap weight gradients
+    (2, 128, 16, 32, 128, 3, 1, 1, 1, False, 32, True),        # halo fwd (GN+SiLU) + halo dgrad + row3 wgrad + residual
+    (1, 128, 24, 16, 256, 3, 1, 1, 1, False, None, False),     # halo, plain operand (range from favae_absmax), 2 Cout tiles
+    (1, 144, 8, 16, 160, 3, 1, 1, 1, False, 16, False),        # halo with ragged channel tiles
+    (2, 128, 10, 12, 128, 3, 2, 0, 1, False, None, False),     # Downsample at 128 ch: implicit-GEMM split kernel, dilated dgrad
+    (2, 128, 8, 8, 128, 3, 1, 1, 1, True, None, False),        # Upsample at 128 ch: upsample gather fwd + wgrad
+    (2, 128, 6, 10, 384, 1, 1, 0, 0, False, 32, False),        # 1x1 with GN+SiLU, 3 Cout tiles
 ]
 
 
@@ -116,6 +123,47 @@ def test_conv_large_tile_shapes(K):
     d = dev()
     yd = K.fused_conv(x.to(d), w.to(d), b.to(d), gw.to(d), gb.to(d), None, K.ConvCfg(3, 3, 1, 1))
     check(yd, y, 2e-5, "y")
+
+
+def test_absmax(K):
+    for n, scale in [(7, 1.0), (4096, 3e-12), (100003, 1e20)]:
+        t = rnd((n,), 21, scale)
+        got = K.absmax(t.to(dev()))
+        assert float(got) == float(t.abs().max())
+    t = torch.zeros(64)
+    assert float(K.absmax(t.to(dev()))) == 0.0
+
+
+@pytest.mark.parametrize("xs,gs", [(1.0, 1.0), (1e-12, 1e-20), (1e8, 1e-9), (3e-30, 1.0)])
+def test_split_conv_operand_ranges(K, xs, gs):
+    """The fp16 planes carry a per-tensor power-of-two scale: any operand magnitude (tiny gradients, huge activations) and a
+    2^-20 spread inside a tensor must keep fp32-grade results."""
+    N, C, H = 1, 128, 16
+    spread = torch.exp2(-torch.randint(0, 21, (N, C, H, H), generator=torch.Generator().manual_seed(5)).float())
+    x = (rnd((N, C, H, H), 31) * spread * xs).requires_grad_(True)
+    w = rnd((C, C, 3, 3), 32, math.sqrt(3.0 / (C * 9))).requires_grad_(True)
+    gy = rnd((N, C, H, H), 33) * gs
+    y = F.conv2d(x.double(), w.double(), None, padding=1)
+    gx, gw = torch.autograd.grad(y, (x, w), gy.double())
+    d = dev()
+    xd = x.detach().to(d).requires_grad_(True)
+    wd = w.detach().to(d).requires_grad_(True)
+    yd = K.fused_conv(xd, wd, None, None, None, None, K.ConvCfg(3, 3, 1, 1))
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), gy.to(d))
+    check(yd, y, 5e-6, "y")
+    check(gxd, gx, 5e-6, "dx")
+    check(gwd, gw, 5e-6, "dw")
+
+
+@pytest.mark.parametrize("mode", ["b6", "fp32"])
+def test_conv_other_modes(mode):
+    """FAVAE_CONV_MODE is read once per process: the bf16x6 and fp32-MFMA kernels are exercised in a child process."""
+    import subprocess, sys
+    env = dict(os.environ, FAVAE_CONV_MODE=mode)
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_mode_probe.py")
+    r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "PROBE OK" in r.stdout
 
 
 BLOCK_DIMS = {"res_same": ("res", (64, 64)), "res_short": ("res", (32, 96)), "nonres": ("nonres", (64, 64)),

@@ -30,17 +30,18 @@ for cin, cout, hw, k in SHAPES:
     w = (torch.randn(cout, cin, k, k, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
     b = torch.zeros(cout, device=dev)
     gw, gb = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
-    mean, rstd, scale, shift = K.gn_stats(x, gw, gb, 32)
+    mean, rstd, scale, shift, xb = K.gn_stats(x, gw, gb, 32, with_bound=True)
     y = K.new_cl(B, cout, hw, hw, dev)
     d = H.make_conv_desc(B, hw, hw, cin, hw, hw, cout, k, k, 1, k // 2, 0, H.ACT_SILU, 1)
     flops = 2.0 * B * hw * hw * cout * k * k * cin
-    t_f = timeit(lambda: K._conv_launch(d, x, w, b, None, scale, shift, y))
+    t_f = timeit(lambda: K._conv_launch(d, x, w, b, None, scale, shift, y, xb))
+    yb = K.absmax(y)
     wt = torch.empty(cin, k, k, cout, device=dev)
     H.call("favae_weight_flip", H.ptr(w), H.ptr(wt), cout, k, k, cin)
     d2 = H.make_conv_desc(B, hw, hw, cout, hw, hw, cin, k, k, 1, k // 2, 0, 0, 1)
     dx = K.new_cl(B, cin, hw, hw, dev)
-    t_d = timeit(lambda: K._conv_launch(d2, y, wt, None, None, None, None, dx))
+    t_d = timeit(lambda: K._conv_launch(d2, y, wt, None, None, None, None, dx, yb))
     dw = torch.empty(cout, k, k, cin, device=dev)
     ws = H.workspace(H.query("favae_conv_wgrad_workspace", byref(d)), dev)
-    t_w = timeit(lambda: H.call("favae_conv_wgrad", byref(d), H.ptr(x), H.ptr(y), H.ptr(scale), H.ptr(shift), H.ptr(dw), 0, H.ptr(ws), ws.numel()))
+    t_w = timeit(lambda: H.call("favae_conv_wgrad", byref(d), H.ptr(x), H.ptr(y), H.ptr(scale), H.ptr(shift), H.ptr(xb), H.ptr(yb), H.ptr(dw), 0, H.ptr(ws), ws.numel()))
     print(f"{cin:4d}->{cout:4d} @{hw:3d} k{k}: fwd {flops/t_f*1e-12:6.1f}  dgrad {flops/t_d*1e-12:6.1f}  wgrad {flops/t_w*1e-12:6.1f} TFLOP/s   ({t_f*1e3:.2f} / {t_d*1e3:.2f} / {t_w*1e3:.2f} ms)", flush=True)

@@ -13,7 +13,7 @@ x = torch.randn(B, cin, hw, hw, device=dev).contiguous(memory_format=torch.chann
 w = (torch.randn(cout, cin, k, k, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
 b = torch.zeros(cout, device=dev)
 gw, gb = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
-mean, rstd, scale, shift = K.gn_stats(x, gw, gb, 32)
+mean, rstd, scale, shift, xb = K.gn_stats(x, gw, gb, 32, with_bound=True)
 y = K.new_cl(B, cout, hw, hw, dev)
 d = H.make_conv_desc(B, hw, hw, cin, hw, hw, cout, k, k, 1, k // 2, 0, H.ACT_SILU, 1)
 wt = torch.empty(cin, k, k, cout, device=dev)
@@ -22,8 +22,10 @@ d2 = H.make_conv_desc(B, hw, hw, cout, hw, hw, cin, k, k, 1, k // 2, 0, 0, 1)
 dx = K.new_cl(B, cin, hw, hw, dev)
 dw = torch.empty(cout, k, k, cin, device=dev)
 ws = H.workspace(H.query("favae_conv_wgrad_workspace", byref(d)), dev)
+K._conv_launch(d, x, w, b, None, scale, shift, y, xb)
+yb = K.absmax(y)
 for _ in range(3):
-    K._conv_launch(d, x, w, b, None, scale, shift, y)
-    K._conv_launch(d2, y, wt, None, None, None, None, dx)
-    H.call("favae_conv_wgrad", byref(d), H.ptr(x), H.ptr(y), H.ptr(scale), H.ptr(shift), H.ptr(dw), 0, H.ptr(ws), ws.numel())
+    K._conv_launch(d, x, w, b, None, scale, shift, y, xb)
+    K._conv_launch(d2, y, wt, None, None, None, None, dx, yb)
+    H.call("favae_conv_wgrad", byref(d), H.ptr(x), H.ptr(y), H.ptr(scale), H.ptr(shift), H.ptr(xb), H.ptr(yb), H.ptr(dw), 0, H.ptr(ws), ws.numel())
 torch.cuda.synchronize()
