@@ -13,8 +13,8 @@
 #include "common.h"
 
 extern "C" size_t favae_colsum_workspace(int64_t M, int C);
-extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, int accumulate, void* ws, size_t ws_bytes,
-                            favae_stream_t stream);
+extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, int accumulate, float* absmax_out, void* ws,
+                            size_t ws_bytes, favae_stream_t stream);
 
 namespace {
 
@@ -337,7 +337,7 @@ extern "C" int favae_blur_bwd(const float* x, const float* dy, const float* sigm
     else hipLaunchKernelGGL((blur_sep_kernel<1, 0>), g3, b3, shm, s, a);
     FAVAE_CHECK_LAUNCH();
     if (dsigma) {
-        int rc = favae_colsum(part, dgv, grid, ksize, 0, p2, cws, stream);
+        int rc = favae_colsum(part, dgv, grid, ksize, 0, nullptr, p2, cws, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(blur_dsigma_kernel, dim3(1), dim3(64), 0, s, (const float*)dgv, sigma, ksize, dsigma);
         FAVAE_CHECK_LAUNCH();

@@ -511,26 +511,35 @@ __global__ void weight_flip_kernel(const float* w, float* wt, int Cout, int KH, 
 }
 
 // column sums: stage 1 = per-block partial over a row range, stage 2 = reduce_slabs_kernel
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* a, float* part, long M, int C, long rows_per_block) {
+// amax (optional): max |a| of the whole matrix, one atomicMax per wave on the bit pattern (order-independent)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* a, float* part, long M, int C, long rows_per_block,
+                                                             unsigned* amax) {
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const long r0 = (long)blockIdx.y * rows_per_block;
-    const long r1 = min(M, r0 + rows_per_block);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    long r = r0;
-    for (; r + 3 < r1; r += 4) {
-        s0 += a[r * C + c];
-        s1 += a[(r + 1) * C + c];
-        s2 += a[(r + 2) * C + c];
-        s3 += a[(r + 3) * C + c];
+    float mx = 0.f;
+    if (c < C) {
+        const long r0 = (long)blockIdx.y * rows_per_block;
+        const long r1 = min(M, r0 + rows_per_block);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        long r = r0;
+        for (; r + 3 < r1; r += 4) {
+            const float v0 = a[r * C + c], v1 = a[(r + 1) * C + c], v2 = a[(r + 2) * C + c], v3 = a[(r + 3) * C + c];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));
+        }
+        for (; r < r1; ++r) { const float v = a[r * C + c]; s0 += v; mx = fmaxf(mx, fabsf(v)); }
+        part[(size_t)blockIdx.y * C + c] = (s0 + s1) + (s2 + s3);
     }
-    for (; r < r1; ++r) s0 += a[r * C + c];
-    part[(size_t)blockIdx.y * C + c] = (s0 + s1) + (s2 + s3);
+    if (amax) {
+        mx = wave_max(mx);
+        if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(mx));
+    }
 }
 
 // vector version (C % 4 == 0): thread = (channel quad, row lane), 16-byte loads, LDS reduce over the row lanes
-__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float* a, float* part, long M, int C, long rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float* a, float* part, long M, int C, long rows_per_block,
+                                                                 unsigned* amax) {
     __shared__ float4 sm[256];
+    float mx = 0.f;
     const int QT = C / 4;
     const int Q = QT < 256 ? QT : 256, RL = 256 / Q;
     const int qi = threadIdx.x % Q, li = threadIdx.x / Q;
@@ -547,10 +556,13 @@ __global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float* a,
                 const float4 u = p[r * QT], v = p[(r + RL) * QT];
                 s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
                 s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))),
+                                     fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))));
             }
             if (r < r1) {
                 const float4 u = p[r * QT];
                 s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))));
             }
             s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w;
         }
@@ -563,6 +575,16 @@ __global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float* a,
                 s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
             }
             reinterpret_cast<float4*>(part + (size_t)blockIdx.y * C)[q] = s0;
+        }
+    }
+    if (amax) {
+        mx = wave_max(mx);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) reinterpret_cast<float*>(sm)[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float* w = reinterpret_cast<const float*>(sm);
+            atomicMax(amax, __float_as_uint(fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]))));
         }
     }
 }
@@ -662,13 +684,18 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     }
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));     // non-negative floats order like their bit patterns
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per block (thousands of same-address atomics serialise at ~10 ns each); non-negative floats order like
+    // their bit patterns, and a maximum is order-independent -> deterministic
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 
 int launch_absmax(const float* x, int64_t n, float* out, hipStream_t s) {
     if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
     long blocks = (n / 4 + 255) / 256;
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (size_t)n, (((uintptr_t)x) & 15) == 0 ? 1 : 0,
                        (unsigned*)out);
     return FAVAE_OK;
@@ -941,17 +968,19 @@ static int colsum_blocks(int64_t M) {
 
 extern "C" size_t favae_colsum_workspace(int64_t M, int C) { return (size_t)colsum_blocks(M) * C * sizeof(float); }
 
-extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, int accumulate, void* ws, size_t ws_bytes,
-                            favae_stream_t stream) {
+extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, int accumulate, float* absmax_out, void* ws,
+                            size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(a && out && ws && M > 0 && C > 0);
     if (ws_bytes < favae_colsum_workspace(M, C)) return FAVAE_ERR_WORKSPACE;
     const int nb = colsum_blocks(M);
     const long rpb = (M + nb - 1) / nb;
     hipStream_t s = (hipStream_t)stream;
+    unsigned* amax = (unsigned*)absmax_out;
+    if (amax && hipMemsetAsync(amax, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
     if (C % 4 == 0 && ((((uintptr_t)a) & 15) == 0))
-        hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3(1, nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb);
+        hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3(1, nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb, amax);
     else
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C, 256), nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C, 256), nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb, amax);
     FAVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const float*)ws, out, (size_t)C, nb, accumulate);
     FAVAE_CHECK_LAUNCH();

@@ -248,14 +248,19 @@ class FusedConvFn(torch.autograd.Function):
         gather = GATHER_UPSAMPLE2 if cfg.upsample else GATHER_PLAIN
         act = cfg.act if ctx.has_gn else ACT_NONE
         p_w, p_b, p_gw, p_gb = ctx.params
+        # range of dy for the fp16 split scheme: read off the bias-gradient pass when there is one
+        want_range = xb is not None and _fp16_planes()
+        dyb = torch.empty((1,), dtype=torch.float32, device=dev) if want_range else None
         if ctx.has_b and ctx.needs_input_grad[2]:
             M = N * Ho * Wo
             ws = workspace(query("favae_colsum_workspace", M, Cout), dev)
             tgt = _direct_grad(p_b)
             if tgt is None:
                 db = torch.empty((Cout,), dtype=torch.float32, device=dev)
-            call("favae_colsum", ptr(dy), ptr(db if tgt is None else tgt), M, Cout, 0 if tgt is None else 1, ptr(ws), ws.numel())
-        dyb = absmax(dy) if (xb is not None and _fp16_planes()) else None     # range of dy for the fp16 split scheme
+            call("favae_colsum", ptr(dy), ptr(db if tgt is None else tgt), M, Cout, 0 if tgt is None else 1, ptr(dyb), ptr(ws),
+                 ws.numel())
+        elif want_range:
+            call("favae_absmax", ptr(dy), dy.numel(), ptr(dyb))
         if need_w:
             d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad, gather, act, 1)
             ws = workspace(query("favae_conv_wgrad_workspace", byref(d)), dev)

@@ -99,7 +99,9 @@ int favae_weight_flip(const float* w, float* wt, int Cout, int KH, int KW, int C
 /* out[c] (+)= sum_m a[m][c]  (bias gradient; M rows of C) ; deterministic two-stage.  `accumulate` != 0 adds to `out`
  * (gradients written straight into a pre-zeroed flat gradient buffer, as favae_conv_wgrad / favae_gn_act_bwd do). */
 size_t favae_colsum_workspace(int64_t M, int C);
-int favae_colsum(const float* a, float* out, int64_t M, int C, int accumulate, void* ws, size_t ws_bytes,
+/* absmax_out (optional device float) receives max |a| -- the range of dy the fp16 split-precision conv kernels need, read
+ * off the pass that already streams dy for the bias gradient. */
+int favae_colsum(const float* a, float* out, int64_t M, int C, int accumulate, float* absmax_out, void* ws, size_t ws_bytes,
                  favae_stream_t stream);
 
 /* adjoint of nearest x2 upsampling: dx[n,h,w,c] = sum of the 2x2 children of du (N,2H,2W,C) */
