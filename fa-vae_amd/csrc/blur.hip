@@ -11,6 +11,7 @@
 //   dsigma = sum_j dp_j p_j t_j^2 / sigma^3,  dp = (dg - <dg,g>) / sum(p)
 // Lanes run along channels: all global accesses are contiguous channel segments, all LDS accesses conflict-free.
 #include "common.h"
+#include <stdlib.h>
 
 extern "C" size_t favae_colsum_workspace(int64_t M, int C);
 extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, int accumulate, float* absmax_out, void* ws,
@@ -236,6 +237,10 @@ __global__ void blur_dsigma_kernel(const float* dgv, const float* sigma, int k, 
     dsigma[0] = (float)ds;
 }
 
+}  // namespace
+#include "blur_stream.h"
+namespace {
+
 size_t shm_floats(const BlurArgs& a, bool bwd) {
     const size_t HH = a.TH + a.k - 1, HW = a.TW + a.k - 1;
     size_t f = 32 + 8 * MAXK + HH * HW * a.CC + HH * a.TW * a.CC;
@@ -273,6 +278,18 @@ bool blur_ok(int ksize, int N, int H, int W, int C) {
 extern "C" int favae_blur_fwd(const float* x, const float* sigma, int ksize, int N, int H, int W, int C, float* y,
                               favae_stream_t stream) {
     FAVAE_REQUIRE(x && sigma && y && blur_ok(ksize, N, H, W, C));
+    if (stream_ok(ksize, N, H, W, C) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+        StreamArgs sa{};
+        stream_plan(N, H, W, C, sa);
+        sa.x = x; sa.sigma = sigma; sa.y = y;
+        const long sgrid = (long)N * sa.segs * sa.strips * sa.cchunks;
+        if (sgrid < (1L << 31)) {
+            hipLaunchKernelGGL((blur9_stream_kernel<0, STREAM_COLS>), dim3((unsigned)sgrid), dim3(STREAM_COLS * 8), 0,
+                               (hipStream_t)stream, sa);
+            FAVAE_CHECK_LAUNCH();
+            return FAVAE_OK;
+        }
+    }
     BlurArgs a{};
     if (!plan(ksize, N, H, W, C, false, a)) return FAVAE_ERR_UNSUPPORTED;
     a.x = x; a.sigma = sigma; a.y = y;
@@ -301,7 +318,13 @@ extern "C" size_t favae_blur_bwd_workspace(int ksize, int N, int H, int W, int C
     if (!blur_ok(ksize, N, H, W, C)) return 0;
     BlurArgs a{};
     if (!plan(ksize, N, H, W, C, true, a)) return 0;
-    const size_t blocks = (size_t)N * a.tiles_h * a.tiles_w * a.cchunks;
+    size_t blocks = (size_t)N * a.tiles_h * a.tiles_w * a.cchunks;
+    if (stream_ok(ksize, N, H, W, C)) {                       // either kernel may run (pointer alignment decides): size for both
+        StreamArgs sa{};
+        stream_plan(N, H, W, C, sa);
+        const size_t sb = (size_t)N * sa.segs * sa.strips * sa.cchunks;
+        if (sb > blocks) blocks = sb;
+    }
     return blocks * ksize * sizeof(float) + favae_colsum_workspace((int64_t)blocks, ksize) + MAXK * sizeof(float) + 512;
 }
 
@@ -312,7 +335,15 @@ extern "C" int favae_blur_bwd(const float* x, const float* dy, const float* sigm
     BlurArgs a{};
     if (!plan(ksize, N, H, W, C, true, a)) return FAVAE_ERR_UNSUPPORTED;
     if (ws_bytes < favae_blur_bwd_workspace(ksize, N, H, W, C)) return FAVAE_ERR_WORKSPACE;
-    const long grid = (long)N * a.tiles_h * a.tiles_w * a.cchunks;
+    StreamArgs sa{};
+    bool stream_path = stream_ok(ksize, N, H, W, C) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+    long grid = (long)N * a.tiles_h * a.tiles_w * a.cchunks;
+    if (stream_path) {
+        stream_plan(N, H, W, C, sa);
+        const long sgrid = (long)N * sa.segs * sa.strips * sa.cchunks;
+        if (sgrid < (1L << 31)) grid = sgrid;
+        else stream_path = false;
+    }
     if (grid >= (1L << 31)) return FAVAE_ERR_UNSUPPORTED;
     float* part = (float*)ws;
     char* p2 = (char*)ws + (((size_t)grid * ksize * sizeof(float) + 255) / 256) * 256;
@@ -331,7 +362,10 @@ extern "C" int favae_blur_bwd(const float* x, const float* dy, const float* sigm
     }
     hipStream_t s = (hipStream_t)stream;
     const dim3 g3((unsigned)grid), b3(256);
-    if (ksize == 9) hipLaunchKernelGGL((blur_sep_kernel<1, 9>), g3, b3, shm, s, a);
+    if (stream_path) {
+        sa.x = x; sa.dy = dy; sa.sigma = sigma; sa.dx = dx; sa.part = a.part;
+        hipLaunchKernelGGL((blur9_stream_kernel<1, STREAM_COLS>), g3, dim3(STREAM_COLS * 8), 0, s, sa);
+    } else if (ksize == 9) hipLaunchKernelGGL((blur_sep_kernel<1, 9>), g3, b3, shm, s, a);
     else if (ksize == 5) hipLaunchKernelGGL((blur_sep_kernel<1, 5>), g3, b3, shm, s, a);
     else if (ksize == 3) hipLaunchKernelGGL((blur_sep_kernel<1, 3>), g3, b3, shm, s, a);
     else hipLaunchKernelGGL((blur_sep_kernel<1, 0>), g3, b3, shm, s, a);

@@ -246,7 +246,10 @@ def test_blur_against_reference_golden(K, golden_dir):
         assert float(got[0]) == 0.0 and float(got[2]) == 0.0 and float(got[3]) == 0.0
 
 
-@pytest.mark.parametrize("shape,ks", [((2, 128, 32, 32), 9), ((1, 512, 16, 16), 9), ((2, 3, 64, 64), 5), ((1, 40, 20, 33), 15)])
+@pytest.mark.parametrize("shape,ks", [((2, 128, 32, 32), 9), ((1, 512, 16, 16), 9), ((2, 3, 64, 64), 5), ((1, 40, 20, 33), 15),
+                                      # row-streaming kernel (k = 9, C % 32 == 0): ragged strips / segments, both folds in one window
+                                      ((1, 32, 80, 70), 9), ((2, 64, 6, 7), 9), ((1, 32, 33, 113), 9), ((1, 32, 130, 20), 9),
+                                      ((1, 40, 24, 24), 9)])
 def test_blur_vs_oracle(K, shape, ks):
     x = rnd(shape, 31).requires_grad_(True)
     s = torch.tensor(2.5, requires_grad=True)
