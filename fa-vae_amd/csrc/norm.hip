@@ -59,19 +59,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
             }
             const float* xp = x + ((size_t)n * HW) * C + c;
             const float* dp = MODE == 1 ? da + ((size_t)n * HW) * C + c : nullptr;
-            for (long r = r0 + li; r < r1; r += RL) {
-                float xv[V], dv[V];
-                if (V == 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(xp + r * C);
-                    xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-                    if (MODE == 1) {
-                        const float4 d = *reinterpret_cast<const float4*>(dp + r * C);
-                        dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
-                    }
-                } else {
-                    xv[0] = xp[r * C];
-                    if (MODE == 1) dv[0] = dp[r * C];
-                }
+            auto accum = [&](const float (&xv)[V], const float (&dv)[V]) {
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     if (MODE == 0) {
@@ -85,6 +73,40 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
                         s2[e] += (double)dy * (double)xh;
                     }
                 }
+            };
+            long r = r0 + li;
+            if constexpr (V == 4) {
+                constexpr int U = 4;                                  // rows in flight per thread (HBM latency hiding)
+                for (; r + (U - 1) * RL < r1; r += U * RL) {
+                    float4 t[U], d[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        t[u] = *reinterpret_cast<const float4*>(xp + (r + u * RL) * C);
+                        if (MODE == 1) d[u] = *reinterpret_cast<const float4*>(dp + (r + u * RL) * C);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const float xv[V] = {t[u].x, t[u].y, t[u].z, t[u].w};
+                        float dv[V] = {0.f, 0.f, 0.f, 0.f};
+                        if (MODE == 1) { dv[0] = d[u].x; dv[1] = d[u].y; dv[2] = d[u].z; dv[3] = d[u].w; }
+                        accum(xv, dv);
+                    }
+                }
+            }
+            for (; r < r1; r += RL) {
+                float xv[V], dv[V];
+                if (V == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(xp + r * C);
+                    xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                    if (MODE == 1) {
+                        const float4 d = *reinterpret_cast<const float4*>(dp + r * C);
+                        dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
+                    }
+                } else {
+                    xv[0] = xp[r * C];
+                    if (MODE == 1) dv[0] = dp[r * C];
+                }
+                accum(xv, dv);
             }
             double* o = sm + ((size_t)li * Q + qi) * 2 * V;
 #pragma unroll
@@ -248,6 +270,68 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// Same result as gn_bwd_apply_kernel<true>, organised like gn_partial_kernel: thread = (channel quad, row lane) of image
+// blockIdx.y, so the per-channel constants live in registers (no per-element parameter loads, no 64-bit index divisions)
+// and four rows are in flight per thread.  Requires C % 4 == 0, C / 4 <= 256 and 16-byte aligned tensors.
+__global__ __launch_bounds__(256) void gn_bwd_apply_rows_kernel(const float* __restrict__ da, const float* __restrict__ x,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ k1, const float* __restrict__ k2,
+                                                                const float* __restrict__ dx_add, float* __restrict__ dx,
+                                                                long HW, int C, int G, int act, long rows_per_block) {
+    const int n = blockIdx.y;
+    const int Q = C / 4, RL = 256 / Q;
+    const int qi = threadIdx.x % Q, li = threadIdx.x / Q;
+    if (li >= RL) return;
+    const int cpg = C / G, c = qi * 4;
+    float a_[4], b_[4], k_[4], ga[4], be[4];          // xh = x*a + b ; dx = rs*ga*dy - (rs*k1 + rs*k2*xh)
+    float rsg[4], rk1[4], rk2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int g = (c + e) / cpg;
+        const float mu = mean[n * G + g], rs = rstd[n * G + g];
+        a_[e] = rs; b_[e] = mu; ga[e] = gamma[c + e]; be[e] = beta[c + e];
+        rsg[e] = rs; rk1[e] = k1[n * G + g]; rk2[e] = k2[n * G + g];
+        k_[e] = 0.f;
+    }
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(HW, r0 + rows_per_block);
+    const size_t base = ((size_t)n * HW) * C + c;
+    auto one = [&](const float4 t, const float4 d, const float4 q) -> float4 {
+        const float xv[4] = {t.x, t.y, t.z, t.w}, dv[4] = {d.x, d.y, d.z, d.w}, av[4] = {q.x, q.y, q.z, q.w};
+        float ov[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xv[e] - b_[e]) * a_[e];
+            const float y = fmaf(xh, ga[e], be[e]);
+            const float dy = dv[e] * act_grad(y, act);
+            float o = rsg[e] * (dy * ga[e] - rk1[e] - xh * rk2[e]);
+            if (dx_add) o += av[e];
+            ov[e] = o;
+        }
+        return make_float4(ov[0], ov[1], ov[2], ov[3]);
+    };
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int U = 4;
+    long r = r0 + li;
+    for (; r + (U - 1) * RL < r1; r += U * RL) {
+        float4 t[U], d[U], q[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t o = base + (size_t)(r + u * RL) * C;
+            t[u] = *reinterpret_cast<const float4*>(x + o);
+            d[u] = *reinterpret_cast<const float4*>(da + o);
+            q[u] = dx_add ? *reinterpret_cast<const float4*>(dx_add + o) : z4;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) *reinterpret_cast<float4*>(dx + base + (size_t)(r + u * RL) * C) = one(t[u], d[u], q[u]);
+    }
+    for (; r < r1; r += RL) {
+        const size_t o = base + (size_t)r * C;
+        const float4 q = dx_add ? *reinterpret_cast<const float4*>(dx_add + o) : z4;
+        *reinterpret_cast<float4*>(dx + o) = one(*reinterpret_cast<const float4*>(x + o), *reinterpret_cast<const float4*>(da + o), q);
+    }
+}
+
 __global__ void bn_update_running_kernel(const float* mean, const float* rstd, int C, double count, float eps, float mom,
                                          float* rm, float* rv) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -339,7 +423,14 @@ extern "C" int favae_gn_act_bwd(const float* da, const float* x, const float* ga
     }
     const size_t total = (size_t)N * HW * C;
     const bool vec = (C % 4 == 0) && (((((uintptr_t)da) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)dx_add)) & 15) == 0);
-    if (vec) {
+    if (vec && C / 4 <= 256 && 256 % (C / 4) == 0) {
+        long S = (HW + 255) / 256;                           // >= 256 pixels per block, ~2048 blocks in total
+        const long cap = (2048 + N - 1) / N;
+        S = S > cap ? cap : (S < 1 ? 1 : S);
+        const long rpb = (HW + S - 1) / S;
+        hipLaunchKernelGGL(gn_bwd_apply_rows_kernel, dim3((unsigned)S, N), dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2,
+                           dx_add, dx, (long)HW, C, G, act, rpb);
+    } else if (vec) {
         int blocks = (int)((total / 4 + 255) / 256);
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL((gn_bwd_apply_kernel<true>), dim3(blocks), dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2,
