@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void split_w_kernel(const float4* __restrict__
 // Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, H % 8 == 0, W % 16 == 0, Cin % 16 == 0, pre-split weights.
 // ---------------------------------------------------------------------------------------------------------------
 template <int XFORM, int NP>
-__global__ __launch_bounds__(512) void conv3x3_halo_sp_kernel(ConvArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP == 2 ? 6 : 4, 8))) void conv3x3_halo_sp_kernel(ConvArgs a) {
     using S = sp::Scheme<NP>;
     constexpr int TH = 8, TW = 16, HW = TW + 2, HROWS = (TH + 2) * HW;          // 180 halo pixels
     // halo row pitch = 18 rows rounded up to a multiple of 256 B: pitch % 256 == 0 puts the second tile row of a wave's 32 MFMA
@@ -503,9 +503,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_sp_kernel(ConvArgs a) {
     const auto rsc_d = make_rsrc(XFORM ? a.scale : a.x, XFORM ? a.aff_bytes : 0u);
     const auto rsh_d = make_rsrc(XFORM ? a.shift : a.x, XFORM ? a.aff_bytes : 0u);
 
-    // halo staging slots of this thread (720 float4 over 512 threads): constant offsets
-    unsigned vh[2], vs[2];
+    // halo staging slots of this thread (720 float4 over 512 threads): constant offsets.  The fused-transform operands
+    // (scale, shift) depend on (image, channel quad) only: one load per K chunk serves both slots; padding pixels must
+    // stay exactly zero after the transform, so they are masked with a select instead of zeroed operands.
+    unsigned vh[2];
     int hoff[2];
+    bool hok[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i = tid + 512 * j;
@@ -513,14 +516,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_sp_kernel(ConvArgs a) {
         const int hy = hrow / HW, hx = hrow - hy * HW;
         hoff[j] = hy * HPITCH + hx * S::ROWB;
         const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
-        const bool ok = hrow < HROWS && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
-        vh[j] = ok ? (unsigned)((((n * a.Hin + y) * a.Win + x) * a.Cin + q4 * 4) * 4) : FAVAE_OOB;
-        vs[j] = ok ? (unsigned)((n * a.aff_stride + q4 * 4) * 4) : FAVAE_OOB;
+        hok[j] = hrow < HROWS && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
+        vh[j] = hok[j] ? (unsigned)((((n * a.Hin + y) * a.Win + x) * a.Cin + q4 * 4) * 4) : FAVAE_OOB;
     }
+    const unsigned vs = (unsigned)((n * a.aff_stride + q4 * 4) * 4);
     const int brow = tid >> 2;                                           // weight row (output channel) staged by this thread
     const unsigned vb = (n0 + brow < a.Cout) ? (unsigned)(((n0 + brow) * 9 * a.Cin + q4 * 4) / 4 * S::WREC) : FAVAE_OOB;
 
-    float4 rh[2], rsc[2], rsh[2];
+    float4 rh[2], rsc, rsh;
     uint2 rbp[NP];
     auto load_halo = [&](int kc) {
         const unsigned sk = (unsigned)(kc * 64);
@@ -528,10 +531,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_sp_kernel(ConvArgs a) {
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && tid >= HROWS * 4 - 512) continue;              // second slot exists for the first 208 threads only
             rh[j] = bload(rx, vh[j], sk);
-            if (XFORM) {
-                rsc[j] = bload(rsc_d, vs[j], sk);
-                rsh[j] = bload(rsh_d, vs[j], sk);
-            }
+        }
+        if (XFORM) {
+            rsc = bload(rsc_d, vs, sk);
+            rsh = bload(rsh_d, vs, sk);
         }
     };
     auto store_halo = [&](int buf) {
@@ -539,7 +542,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_sp_kernel(ConvArgs a) {
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && tid >= HROWS * 4 - 512) continue;
             uint2 p[NP];
-            S::split4(xform4_t<XFORM>(rh[j], rsc[j], rsh[j]), Sa, p);
+            float4 t = xform4_t<XFORM>(rh[j], rsc, rsh);
+            if (XFORM && !hok[j]) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            S::split4(t, Sa, p);
             sp::store_planes<NP>(Hs + buf * HALO_B + hoff[j] + q4 * 8, 32, p);
         }
     };
