@@ -473,6 +473,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #include "conv_fast.h"
 #include "conv_buf.h"
 #include "conv_split.h"
+#include "conv_thin.h"
 
 // out[i] (+)= sum_z part[z][i] in a fixed order (4 interleaved partial sums -> 4 loads in flight per thread)
 __global__ void reduce_slabs_kernel(const float* part, float* out, size_t n, int slabs, int accumulate) {
@@ -658,6 +659,26 @@ void wgrad_tiles(const favae_conv_desc* d, int* bco, int* bci) {
 
 }  // namespace
 
+// RGB ends of the codec (conv_thin.h): 1 = thin input (Cin = 3), 2 = thin output (Cout = 3), 0 = neither.  FAVAE_CONV_THIN=0
+// sends them back to the implicit-GEMM kernels (A/B switch).
+constexpr int THIN_WGRAD_BLOCKS = 1024;
+static bool thin_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FAVAE_CONV_THIN"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+static int thin_kind(const favae_conv_desc* d, bool has_affine) {
+    if (!desc_ok(d) || force_generic() || !thin_enabled()) return 0;
+    if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->gather == FAVAE_GATHER_PLAIN && d->Hout == d->Hin &&
+          d->Wout == d->Win))
+        return 0;
+    if ((size_t)d->N * d->Hin * d->Win >= ((size_t)1 << 31)) return 0;
+    if (d->Cin == 3 && (d->Cout == 64 || d->Cout == 128) && !has_affine) return 1;
+    if (d->Cout == 3 && (d->Cin == 64 || d->Cin == 128)) return 2;
+    return 0;
+}
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
 static bool sp_fwd_eligible(const favae_conv_desc* d, bool has_affine) {
     if (!desc_ok(d) || force_generic() || force_nobuf() || !use_b6()) return false;
     const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, wb = (size_t)d->Cout * d->KH * d->KW * d->Cin * 6;
@@ -754,6 +775,35 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     FAVAE_REQUIRE(desc_ok(d) && x && w && y);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     const bool w6 = wplanes != 0;                            // pre-split weights: records start behind the header
+    if (!w6) {
+        const int tk = thin_kind(d, scale != nullptr);
+        const int xf0 = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_LEAKY02 ? 3 : 1)) : 0;
+        if (tk && al16(x) && al16(y) && al16(resid) && al16(scale) && al16(shift)) {
+            ThinArgs t{};
+            t.x = x; t.w = w; t.bias = bias; t.resid = resid; t.scale = scale; t.shift = shift; t.y = y;
+            t.N = d->N; t.H = d->Hin; t.W = d->Win;
+            t.aff_stride = d->affine_per_image ? d->Cin : 0;
+            hipStream_t s = (hipStream_t)stream;
+            if (tk == 1) {
+                t.Cw = d->Cout; t.xb = 64;
+                const int items = d->N * d->Hin * cdiv(d->Win, t.xb);
+                hipLaunchKernelGGL((thin_in_kernel<3, false>), dim3(items), dim3(256), 0, s, t);
+            } else {
+                t.Cw = d->Cin;
+                const int PL = 256 / (t.Cw / 4);
+                int seg = cdiv(d->Win, PL);
+                seg = seg < 4 ? 4 : (seg > 32 ? 32 : seg);
+                t.xb = seg * PL;
+                const int items = d->N * d->Hin * cdiv(d->Win, t.xb);
+                if (xf0 == 0) hipLaunchKernelGGL((thin_out_kernel<3, 0, false>), dim3(items), dim3(256), 0, s, t);
+                else if (xf0 == 1) hipLaunchKernelGGL((thin_out_kernel<3, 1, false>), dim3(items), dim3(256), 0, s, t);
+                else if (xf0 == 2) hipLaunchKernelGGL((thin_out_kernel<3, 2, false>), dim3(items), dim3(256), 0, s, t);
+                else hipLaunchKernelGGL((thin_out_kernel<3, 3, false>), dim3(items), dim3(256), 0, s, t);
+            }
+            FAVAE_CHECK_LAUNCH();
+            return FAVAE_OK;
+        }
+    }
     ConvArgs a;
     a.x_amax = x_amax; a.w_amax = w;
     a.x = x; a.w = w6 ? (const float*)((const char*)w + sp::WHDR) : w; a.bias = bias; a.resid = resid; a.scale = scale; a.shift = shift; a.y = y;
@@ -851,7 +901,8 @@ extern "C" size_t favae_conv_wgrad_workspace(const favae_conv_desc* d) {
     int bco, bci, chunk;
     wgrad_tiles(d, &bco, &bci);
     const int tiles = cdiv(d->Cout, bco) * cdiv(d->Cin, bci) * d->KH * d->KW;
-    const int sk = wgrad_splitk(d, tiles, &chunk);
+    int sk = wgrad_splitk(d, tiles, &chunk);
+    if (thin_kind(d, false) && sk < THIN_WGRAD_BLOCKS) sk = THIN_WGRAD_BLOCKS;     // either kernel family may run: size for both
     return (size_t)sk * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
 }
 
@@ -863,6 +914,41 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     const int np = (conv_mode() == 2 && x_absmax && dy_absmax) ? 2 : 3;
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     if (ws_bytes < favae_conv_wgrad_workspace(d)) return FAVAE_ERR_WORKSPACE;
+    {
+        const int tk = thin_kind(d, scale != nullptr);
+        const int xf0 = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_LEAKY02 ? 3 : 1)) : 0;
+        if (tk && xf0 != 3 && al16(x) && al16(dy) && al16(scale) && al16(shift) && al16(ws)) {
+            ThinArgs t{};
+            t.x = x; t.dy = dy; t.scale = scale; t.shift = shift; t.part = (float*)ws;
+            t.N = d->N; t.H = d->Hin; t.W = d->Win;
+            t.aff_stride = d->affine_per_image ? d->Cin : 0;
+            hipStream_t s = (hipStream_t)stream;
+            int blocks;
+            if (tk == 1) {
+                t.Cw = d->Cout; t.xb = 64;
+                const int items = d->N * d->Hin * cdiv(d->Win, t.xb);
+                blocks = items < THIN_WGRAD_BLOCKS ? items : THIN_WGRAD_BLOCKS;
+                hipLaunchKernelGGL((thin_in_kernel<3, true>), dim3(blocks), dim3(256), (size_t)3 * 27 * t.Cw * sizeof(float), s, t);
+            } else {
+                t.Cw = d->Cin;
+                const int PL = 256 / (t.Cw / 4);
+                int seg = cdiv(d->Win, PL);
+                seg = seg < 4 ? 4 : (seg > 32 ? 32 : seg);
+                t.xb = seg * PL;
+                const int items = d->N * d->Hin * cdiv(d->Win, t.xb);
+                blocks = items < THIN_WGRAD_BLOCKS ? items : THIN_WGRAD_BLOCKS;
+                const size_t shm = (size_t)3 * 27 * t.Cw * sizeof(float);
+                if (xf0 == 0) hipLaunchKernelGGL((thin_out_kernel<3, 0, true>), dim3(blocks), dim3(256), shm, s, t);
+                else if (xf0 == 1) hipLaunchKernelGGL((thin_out_kernel<3, 1, true>), dim3(blocks), dim3(256), shm, s, t);
+                else hipLaunchKernelGGL((thin_out_kernel<3, 2, true>), dim3(blocks), dim3(256), shm, s, t);
+            }
+            FAVAE_CHECK_LAUNCH();
+            const size_t nw = (size_t)d->Cout * 9 * d->Cin;
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, s, (const float*)ws, dw, nw, blocks, accumulate);
+            FAVAE_CHECK_LAUNCH();
+            return FAVAE_OK;
+        }
+    }
     int bco, bci, chunk;
     wgrad_tiles(d, &bco, &bci);
     WgradArgs a;

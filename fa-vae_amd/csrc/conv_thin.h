@@ -1,0 +1,280 @@
+// 3x3 stride-1 convolutions with a THIN channel side (<= 4 channels: the RGB ends of the codec -- conv_in, conv_out and
+// their gradients; models/codec.py:140,175).  These layers are HBM-bound (one side is a 128-channel 256x256 tensor, the
+// arithmetic is 27 multiply-adds per wide element), so they do not go to the matrix pipe: the implicit-GEMM kernels pad the
+// thin side to a 32-wide MFMA tile and re-read the wide tensor once per filter tap (9.3 GB of fabric traffic for a 1.07 GB
+// tensor, profiles/r01_hbm_traffic.json).  Here every wide element is read once (~3x through L2 for the row halo), lanes run
+// along the wide channel dimension (4 channels = one float4 per lane, 128-byte..512-byte coalesced segments), the thin side
+// lives in registers, and all arithmetic is fp32 FMA on the vector ALUs.
+//
+//   thin_in_fwd    y[p][co4]   = bias + sum_{tap,ci} x[p+tap][ci] w[co][tap][ci]                  Cin  <= 4 (also: dgrad of a thin-out conv)
+//   thin_in_wgrad  dw[co4][tap][ci] = sum_p dy[p][co4] x[p+tap][ci]
+//   thin_out_fwd   y[p][co]    = bias + sum_lanes sum_tap <T(x)[p+tap][c4], w[co][tap][c4]>     Cout <= 4, T = fused GroupNorm/SiLU
+//   thin_out_wgrad dw[co][tap][c4] = sum_p dy[p][co] T(x)[p+tap][c4]
+// The thin-out kernels march along an image row keeping the 3x3 window of transformed float4s in registers (3 new loads per
+// pixel).  Weight gradients: grid-stride workgroups, one partial slab per workgroup (waves folded through LDS in a fixed
+// order), slabs summed in a fixed order by reduce_slabs_kernel -> deterministic.
+// Preconditions (dispatcher): KH = KW = 3, stride 1, pad 1, plain gather; thin side = 3 channels, wide side 64 or 128
+// channels, 16-byte aligned activations (parameters are read with scalar loads: flat-buffer views may be 4-byte aligned).
+#pragma once
+
+struct ThinArgs {
+    const float* x;       // conv input (thin_in: N,H,W,CT ; thin_out: N,H,W,Cw)
+    const float* w;       // OHWI weights
+    const float* bias;
+    const float* resid;
+    const float* scale;   // thin_out: fused input transform (per image, per wide channel)
+    const float* shift;
+    const float* dy;      // wgrad: output gradient
+    float* y;             // forward output
+    float* part;          // wgrad: partial slabs [slab][Cout][9][Cin]
+    int N, H, W, Cw;      // Cw = wide channel count
+    int aff_stride;       // Cw if the affine is per image, 0 otherwise
+    int xb;               // pixels of one row per workgroup
+};
+
+
+template <int XFORM>
+__device__ __forceinline__ float4 thin_xform(float4 v, float4 sc, float4 sh, bool ok) {
+    if (XFORM == 0) return v;                                   // out-of-image loads already returned zeros
+    v = xform4_t<XFORM>(v, sc, sh);
+    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---- thin input --------------------------------------------------------------------------------------------------------
+// thread = (pixel lane, output-channel quad); the 9*CT inputs of a pixel are the same for all lanes of the quad group
+// (broadcast loads), the 9*CT*4 weights of the thread stay in registers.
+template <int CT, bool WGRAD>
+__global__ __launch_bounds__(256) void thin_in_kernel(ThinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float thin_red[];
+    const int QW = a.Cw >> 2, PL = 256 / QW;
+    const int q = threadIdx.x % QW, pl = threadIdx.x / QW;
+    const int xblocks = (a.W + a.xb - 1) / a.xb;
+    const int items = a.N * a.H * xblocks;                      // work item = (image, row, block of xb pixels)
+    float4 wr[9 * CT];                                          // forward: weights ; wgrad: accumulators  [tap][ci] x 4 co
+#pragma unroll
+    for (int i = 0; i < 9 * CT; ++i) {
+        if (WGRAD) wr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else {
+            const float* wp = a.w + (size_t)(4 * q) * 9 * CT + i;
+            wr[i] = make_float4(wp[0], wp[9 * CT], wp[18 * CT], wp[27 * CT]);
+        }
+    }
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!WGRAD && a.bias) bv = make_float4(a.bias[4 * q], a.bias[4 * q + 1], a.bias[4 * q + 2], a.bias[4 * q + 3]);
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    int b = item;
+    const int xb0 = (b % xblocks) * a.xb; b /= xblocks;
+    const int y = b % a.H;
+    const int n = b / a.H;
+    const int x_end = min(a.W, xb0 + a.xb);
+    for (int xx = xb0 + pl; xx < x_end; xx += PL) {
+        float in[9 * CT];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int yy = y + kh - 1;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int xc = xx + kw - 1;
+                const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xc < (unsigned)a.W;
+                const float* xp = a.x + ((size_t)(n * a.H + (ok ? yy : 0)) * a.W + (ok ? xc : 0)) * CT;
+#pragma unroll
+                for (int ci = 0; ci < CT; ++ci) in[(kh * 3 + kw) * CT + ci] = ok ? xp[ci] : 0.f;
+            }
+        }
+        const size_t o = ((size_t)(n * a.H + y) * a.W + xx) * a.Cw + 4 * q;
+        if (WGRAD) {
+            const float4 d = *reinterpret_cast<const float4*>(a.dy + o);
+#pragma unroll
+            for (int i = 0; i < 9 * CT; ++i) {
+                wr[i].x = fmaf(d.x, in[i], wr[i].x); wr[i].y = fmaf(d.y, in[i], wr[i].y);
+                wr[i].z = fmaf(d.z, in[i], wr[i].z); wr[i].w = fmaf(d.w, in[i], wr[i].w);
+            }
+        } else {
+            float4 acc = bv;
+#pragma unroll
+            for (int i = 0; i < 9 * CT; ++i) {
+                acc.x = fmaf(in[i], wr[i].x, acc.x); acc.y = fmaf(in[i], wr[i].y, acc.y);
+                acc.z = fmaf(in[i], wr[i].z, acc.z); acc.w = fmaf(in[i], wr[i].w, acc.w);
+            }
+            if (a.resid) {
+                const float4 r = *reinterpret_cast<const float4*>(a.resid + o);
+                acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+            }
+            *reinterpret_cast<float4*>(a.y + o) = acc;
+        }
+    }
+    }
+    if (WGRAD) {
+        // pixel lanes of one wave hold partial sums of the same channels: fold them with shuffles, fold the four waves through
+        // LDS in a fixed order, then one slab per workgroup
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        for (int off = QW; off < 64; off <<= 1) {
+#pragma unroll
+            for (int i = 0; i < 9 * CT; ++i) {
+                wr[i].x += __shfl_xor(wr[i].x, off); wr[i].y += __shfl_xor(wr[i].y, off);
+                wr[i].z += __shfl_xor(wr[i].z, off); wr[i].w += __shfl_xor(wr[i].w, off);
+            }
+        }
+        const bool owner = lane < QW;                           // QW = 64: every lane; the waves then hold different pixel lanes
+        float4* red = reinterpret_cast<float4*>(thin_red);      // [3 waves][9*CT][QW]
+        if (owner && wid > 0) {
+#pragma unroll
+            for (int i = 0; i < 9 * CT; ++i) red[((wid - 1) * 9 * CT + i) * QW + q] = wr[i];
+        }
+        __syncthreads();
+        if (owner && wid == 0) {
+            float* out = a.part + (size_t)blockIdx.x * (size_t)a.Cw * 9 * CT;
+#pragma unroll
+            for (int i = 0; i < 9 * CT; ++i) {
+                float4 v = wr[i];
+                for (int w2 = 0; w2 < 3; ++w2) {
+                    const float4 t = red[(w2 * 9 * CT + i) * QW + q];
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                float* o4 = out + (size_t)(4 * q) * 9 * CT + i;
+                o4[0] = v.x; o4[9 * CT] = v.y; o4[18 * CT] = v.z; o4[27 * CT] = v.w;
+            }
+        }
+    }
+}
+
+// ---- thin output -------------------------------------------------------------------------------------------------------
+// thread = (pixel lane, input-channel quad); a pixel lane marches along a row segment of `seg` pixels.
+template <int CT, int XFORM, bool WGRAD>
+__global__ __launch_bounds__(256) void thin_out_kernel(ThinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float thin_red[];
+    const int QW = a.Cw >> 2, PL = 256 / QW;
+    const int q = threadIdx.x % QW, pl = threadIdx.x / QW;
+    const int seg = a.xb / PL;                                  // pixels per pixel lane
+    const int xblocks = (a.W + a.xb - 1) / a.xb;
+    const int items = a.N * a.H * xblocks;
+
+    float4 wr[CT][9];                                           // forward: weights ; wgrad: accumulators
+#pragma unroll
+    for (int co = 0; co < CT; ++co)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if (WGRAD) wr[co][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            else {
+                const float* wp = a.w + ((size_t)(co * 9 + t)) * a.Cw + 4 * q;
+                wr[co][t] = make_float4(wp[0], wp[1], wp[2], wp[3]);
+            }
+    float bias[CT];
+#pragma unroll
+    for (int co = 0; co < CT; ++co) bias[co] = (!WGRAD && a.bias) ? a.bias[co] : 0.f;
+
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    int b = item;
+    const int xs = (b % xblocks) * a.xb + pl * seg; b /= xblocks;
+    const int y = b % a.H;
+    const int n = b / a.H;
+    const int x_end = min(a.W, xs + seg);
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+    if (XFORM) {
+        sc = *reinterpret_cast<const float4*>(a.scale + (size_t)n * a.aff_stride + 4 * q);
+        sh = *reinterpret_cast<const float4*>(a.shift + (size_t)n * a.aff_stride + 4 * q);
+    }
+    // transformed input column xc (rows y-1, y, y+1)
+    auto load_col = [&](int xc, float4 (&c)[3]) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = y + r - 1;
+            const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xc < (unsigned)a.W;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + yy) * a.W + xc) * a.Cw + 4 * q);
+            c[r] = thin_xform<XFORM>(v, sc, sh, ok);
+        }
+    };
+    auto pixel = [&](int xx, const float4 (&L)[3], const float4 (&M)[3], const float4 (&R)[3]) {
+        if (WGRAD) {
+            float d[CT];
+            const float* dp = a.dy + ((size_t)(n * a.H + y) * a.W + xx) * CT;
+#pragma unroll
+            for (int co = 0; co < CT; ++co) d[co] = dp[co];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int co = 0; co < CT; ++co) {
+                    float4& a0 = wr[co][r * 3 + 0];
+                    float4& a1 = wr[co][r * 3 + 1];
+                    float4& a2 = wr[co][r * 3 + 2];
+                    a0.x = fmaf(d[co], L[r].x, a0.x); a0.y = fmaf(d[co], L[r].y, a0.y); a0.z = fmaf(d[co], L[r].z, a0.z); a0.w = fmaf(d[co], L[r].w, a0.w);
+                    a1.x = fmaf(d[co], M[r].x, a1.x); a1.y = fmaf(d[co], M[r].y, a1.y); a1.z = fmaf(d[co], M[r].z, a1.z); a1.w = fmaf(d[co], M[r].w, a1.w);
+                    a2.x = fmaf(d[co], R[r].x, a2.x); a2.y = fmaf(d[co], R[r].y, a2.y); a2.z = fmaf(d[co], R[r].z, a2.z); a2.w = fmaf(d[co], R[r].w, a2.w);
+                }
+        } else {
+            float s[CT];
+#pragma unroll
+            for (int co = 0; co < CT; ++co) {
+                float acc = 0.f;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float4 w0 = wr[co][r * 3 + 0], w1 = wr[co][r * 3 + 1], w2 = wr[co][r * 3 + 2];
+                    acc = fmaf(L[r].x, w0.x, fmaf(L[r].y, w0.y, fmaf(L[r].z, w0.z, fmaf(L[r].w, w0.w, acc))));
+                    acc = fmaf(M[r].x, w1.x, fmaf(M[r].y, w1.y, fmaf(M[r].z, w1.z, fmaf(M[r].w, w1.w, acc))));
+                    acc = fmaf(R[r].x, w2.x, fmaf(R[r].y, w2.y, fmaf(R[r].z, w2.z, fmaf(R[r].w, w2.w, acc))));
+                }
+                for (int off = QW >> 1; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+                s[co] = acc;
+            }
+            if (q == 0) {
+                float* op = a.y + ((size_t)(n * a.H + y) * a.W + xx) * CT;
+#pragma unroll
+                for (int co = 0; co < CT; ++co) {
+                    float v = s[co] + bias[co];
+                    if (a.resid) v += a.resid[((size_t)(n * a.H + y) * a.W + xx) * CT + co];
+                    op[co] = v;
+                }
+            }
+        }
+    };
+
+    if (xs < x_end) {                                           // (uniform per pixel lane; shuffles stay inside the lane group)
+        float4 c0[3], c1[3], c2[3];
+        load_col(xs - 1, c0);
+        load_col(xs, c1);
+        int xx = xs;
+        // rotate the roles of the three column registers instead of moving them
+        while (true) {
+            load_col(xx + 1, c2); pixel(xx, c0, c1, c2); if (++xx >= x_end) break;
+            load_col(xx + 1, c0); pixel(xx, c1, c2, c0); if (++xx >= x_end) break;
+            load_col(xx + 1, c1); pixel(xx, c2, c0, c1); if (++xx >= x_end) break;
+        }
+    }
+    }
+    if (WGRAD) {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        for (int off = QW; off < 64; off <<= 1) {
+#pragma unroll
+            for (int co = 0; co < CT; ++co)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    wr[co][t].x += __shfl_xor(wr[co][t].x, off); wr[co][t].y += __shfl_xor(wr[co][t].y, off);
+                    wr[co][t].z += __shfl_xor(wr[co][t].z, off); wr[co][t].w += __shfl_xor(wr[co][t].w, off);
+                }
+        }
+        const bool owner = lane < QW;
+        float4* red = reinterpret_cast<float4*>(thin_red);      // [3 waves][CT*9][QW]
+        if (owner && wid > 0) {
+#pragma unroll
+            for (int co = 0; co < CT; ++co)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) red[((wid - 1) * CT * 9 + co * 9 + t) * QW + q] = wr[co][t];
+        }
+        __syncthreads();
+        if (owner && wid == 0) {
+            float* out = a.part + (size_t)blockIdx.x * (size_t)CT * 9 * a.Cw;
+#pragma unroll
+            for (int co = 0; co < CT; ++co)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    float4 v = wr[co][t];
+                    for (int w2 = 0; w2 < 3; ++w2) {
+                        const float4 u = red[(w2 * CT * 9 + co * 9 + t) * QW + q];
+                        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                    }
+                    *reinterpret_cast<float4*>(out + ((size_t)(co * 9 + t)) * a.Cw + 4 * q) = v;
+                }
+        }
+    }
+}
