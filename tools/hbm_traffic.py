@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from two separate rocprofv3 --pmc passes over the same bench command (FETCH_SIZE, WRITE_SIZE; KiB per
+dispatch summed over the XCDs).  bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- the gfx950 FETCH_SIZE x2
+correction of MI355X_MICROARCH.md -- averaged over the launches of the profiled run.
+usage: tools/hbm_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps in the run> <out.json>
+
+collect with (separately, no other tracing):
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d <dir> -o f -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d <dir> -o w -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([\w:]+(<.*?>)?)\(", name)
+    return (m.group(1) if m else name)[:110]
+
+
+def collect(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    f, w = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    steps = int(sys.argv[3])
+    out = {}
+    for k in sorted(set(f) | set(w), key=lambda k: -(sum(f.get(k, [0])) + sum(w.get(k, [0])))):
+        fv, wv = f.get(k, [0.0]), w.get(k, [0.0])
+        fa, wa = sum(fv) / len(fv), sum(wv) / len(wv)
+        out[k] = {"launches_per_step": max(len(fv), len(wv)) / steps, "fetch_size_kb_avg": fa, "write_size_kb_avg": wa,
+                  "hbm_bytes_per_launch_corrected": (2.0 * fa + wa) * 1024.0}
+    json.dump(out, open(sys.argv[4], "w"), indent=1)
+    for k in list(out)[:12]:
+        print("%-70s %8.1f MB/launch" % (k[:70], out[k]["hbm_bytes_per_launch_corrected"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
