@@ -59,7 +59,8 @@ SIGNATURES = {
     "favae_ffl_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _S]),
     "favae_vq_workspace": (c_size_t, [c_int, c_int, c_int]),
     "favae_vq_lookup": (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_size_t, _S]),
-    "favae_vq_segment_sum": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _S]),
+    "favae_vq_segment_workspace": (c_size_t, [c_int, c_int]),
+    "favae_vq_segment_sum": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _S]),
     "favae_vq_ema_update": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _S]),
     "favae_vq_ste": (c_int, [_P, _P, _P, c_int64, _S]),
     "favae_reduce_workspace": (c_size_t, [c_int64]),

@@ -453,7 +453,8 @@ def vq_segment_sum(zn, idx, C):
     T, d = zn.shape
     bins = torch.empty((C,), dtype=torch.float32, device=zn.device)
     esum = torch.empty((C, d), dtype=torch.float32, device=zn.device)
-    call("favae_vq_segment_sum", ptr(zn), ptr(idx), T, d, C, ptr(bins), ptr(esum))
+    ws = workspace(query("favae_vq_segment_workspace", T, C), zn.device)
+    call("favae_vq_segment_sum", ptr(zn), ptr(idx), T, d, C, ptr(bins), ptr(esum), ptr(ws), ws.numel())
     return bins, esum
 
 

@@ -178,9 +178,11 @@ int favae_ffl_bwd(const float* spec, const float* gloss, int N, int H, int W, in
 size_t favae_vq_workspace(int T, int d, int C);
 int favae_vq_lookup(const float* z, const float* embed, int T, int d, int C, float tie_eps, int64_t* idx, float* zq,
                     float* zn, float* en, void* ws, size_t ws_bytes, favae_stream_t stream);
-/* bins[c] = #tokens with idx==c ; embed_sum[c] = sum of zn rows with idx==c (deterministic: ascending token order) */
-int favae_vq_segment_sum(const float* zn, const int64_t* idx, int T, int d, int C, float* bins, float* embed_sum,
-                         favae_stream_t stream);
+/* bins[c] = #tokens with idx==c ; embed_sum[c] = sum of zn rows with idx==c (deterministic: stable counting sort of the
+ * tokens by code, rows added in ascending token order) */
+size_t favae_vq_segment_workspace(int T, int C);
+int favae_vq_segment_sum(const float* zn, const int64_t* idx, int T, int d, int C, float* bins, float* embed_sum, void* ws,
+                         size_t ws_bytes, favae_stream_t stream);
 /* EMA (l2_quantize.py:421-438): cluster_size = decay*cluster_size + (1-decay)*bins;
  * embed = decay*embed + (1-decay)*(bins==0 ? en : l2norm(embed_sum/bins)) */
 int favae_vq_ema_update(float* embed, float* cluster_size, const float* en, const float* bins, const float* embed_sum,
