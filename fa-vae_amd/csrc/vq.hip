@@ -256,6 +256,7 @@ __global__ __launch_bounds__(1024) void vq_scan_kernel(const int* count, int* of
     }
     int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
     for (int c = c0; c < c1; ++c) { offs[c] = run; run += count[c]; }
+    if (threadIdx.x == 1023) offs[C] = part[1023];             // number of tokens with a valid code
 }
 
 constexpr int VQ_PLACE_WAVES = 256;
@@ -290,8 +291,49 @@ __global__ __launch_bounds__(64) void vq_place_kernel(const long long* idx, int 
     }
 }
 
+// Codes that own more than 64 tokens (a collapsed codebook puts thousands on one code: one wave adding them one after the
+// other took 3.7 ms) are summed in two levels: wave j adds the rows of sorted positions [64 j, 64 j + 64) that belong to such
+// a code into part[j][slot] (slot 0: the run that covers the chunk's first position, slot 1: a run starting inside the
+// chunk -- a run longer than 64 cannot start and end inside one chunk), and the code's wave then adds its chunks in order.
+constexpr int VQ_LONG = 64;
+
+__global__ __launch_bounds__(256) void vq_long_partial_kernel(const float* zn, const long long* idx, const int* list,
+                                                              const int* offs, const int* count, int C, int d, float* part) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int p0 = j * VQ_LONG, total = offs[C];
+    if (p0 >= total) return;
+    const int p1 = min(total, p0 + VQ_LONG);
+    constexpr int MAXV = 8;
+    int p = p0;
+    while (p < p1) {
+        const int code = (int)idx[list[p]];
+        const int b = offs[code], n = count[code];
+        const int e = min(p1, b + n);                           // end of this code's run inside the chunk
+        if (n > VQ_LONG) {
+            float acc[MAXV];
+#pragma unroll
+            for (int v = 0; v < MAXV; ++v) acc[v] = 0.f;
+            for (int k = p; k < e; ++k) {
+                const float* row = zn + (size_t)list[k] * d;
+#pragma unroll
+                for (int v = 0; v < MAXV; ++v) {
+                    const int kk = lane + 64 * v;
+                    if (kk < d) acc[v] += row[kk];
+                }
+            }
+            float* o = part + ((size_t)j * 2 + (b > p0 ? 1 : 0)) * d;
+#pragma unroll
+            for (int v = 0; v < MAXV; ++v) {
+                const int kk = lane + 64 * v;
+                if (kk < d) o[kk] = acc[v];
+            }
+        }
+        p = e;
+    }
+}
+
 __global__ __launch_bounds__(256) void vq_segment_sum_kernel(const float* zn, const int* list, const int* offs, const int* count,
-                                                             int d, int C, float* bins, float* embed_sum) {
+                                                             const float* part, int d, int C, float* bins, float* embed_sum) {
     const int code = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (code >= C) return;
     constexpr int MAXV = 8;                      // d <= 64*MAXV
@@ -299,6 +341,16 @@ __global__ __launch_bounds__(256) void vq_segment_sum_kernel(const float* zn, co
 #pragma unroll
     for (int v = 0; v < MAXV; ++v) acc[v] = 0.f;
     const int n = count[code], base = offs[code];
+    if (n > VQ_LONG) {
+        for (int j = base / VQ_LONG; j <= (base + n - 1) / VQ_LONG; ++j) {
+            const float* row = part + ((size_t)j * 2 + (base > j * VQ_LONG ? 1 : 0)) * d;
+#pragma unroll
+            for (int v = 0; v < MAXV; ++v) {
+                const int kk = lane + 64 * v;
+                if (kk < d) acc[v] += row[kk];
+            }
+        }
+    } else
     for (int k = 0; k < n; ++k) {
         const float* row = zn + (size_t)list[base + k] * d;
 #pragma unroll
@@ -377,7 +429,7 @@ extern "C" int favae_vq_lookup(const float* z, const float* embed, int T, int d,
 
 extern "C" size_t favae_vq_segment_workspace(int T, int C) {
     if (T <= 0 || C <= 0) return 0;
-    return ((size_t)2 * C + (size_t)T) * sizeof(int) + 256;
+    return ((size_t)2 * C + 1 + (size_t)T) * sizeof(int) + 256 + (size_t)cdiv(T, VQ_LONG) * 2 * 512 * sizeof(float);
 }
 
 extern "C" int favae_vq_segment_sum(const float* zn, const int64_t* idx, int T, int d, int C, float* bins, float* embed_sum,
@@ -388,7 +440,8 @@ extern "C" int favae_vq_segment_sum(const float* zn, const int64_t* idx, int T, 
     hipStream_t s = (hipStream_t)stream;
     int* count = (int*)ws;
     int* offs = count + C;
-    int* list = offs + C;
+    int* list = offs + C + 1;
+    float* part = (float*)((char*)ws + ((((size_t)2 * C + 1 + (size_t)T) * sizeof(int) + 255) / 256) * 256);
     if (hipMemsetAsync(count, 0, (size_t)C * sizeof(int), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
     int hb = cdiv(T, 256);
     if (hb > 1024) hb = 1024;
@@ -400,8 +453,11 @@ extern "C" int favae_vq_segment_sum(const float* zn, const int64_t* idx, int T, 
     hipLaunchKernelGGL(vq_place_kernel, dim3(G), dim3(64), (size_t)cdiv(C, G) * sizeof(int), s, (const long long*)idx, T, C,
                        (const int*)offs, list);
     FAVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vq_long_partial_kernel, dim3(cdiv(cdiv(T, VQ_LONG), 4)), dim3(256), 0, s, zn, (const long long*)idx,
+                       (const int*)list, (const int*)offs, (const int*)count, C, d, part);
+    FAVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(vq_segment_sum_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, zn, (const int*)list, (const int*)offs,
-                       (const int*)count, d, C, bins, embed_sum);
+                       (const int*)count, (const float*)part, d, C, bins, embed_sum);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
