@@ -204,10 +204,14 @@ class FusedConvFn(torch.autograd.Function):
     """y = conv(act(GN(x)), w) + b + resid   -- GN/act optional (gn_w is None -> plain conv).
 
     Reference sites: ResnetBlock/NonResnetBlock halves (models/codec.py:38-46), Downsample (:26-29), Upsample (:17-18),
-    conv_in/final (:140,170-175), attention in/out projections (:92)."""
+    conv_in/final (:140,170-175), attention in/out projections (:92).
+
+    pass_input=True additionally returns x itself as a second output.  A caller that also feeds x to a later op (the skip
+    connection of a ResnetBlock / AttnBlock) uses that alias instead of x: the skip gradient then arrives HERE, next to dy,
+    and is added inside the GroupNorm-backward kernel (dx_add) instead of by a separate autograd accumulation kernel."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gn_w, gn_b, resid, cfg):
+    def forward(ctx, x, w, b, gn_w, gn_b, resid, cfg, pass_input=False):
         x = to_cl(x)
         N, Cin, Hin, Win = x.shape
         w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
@@ -233,11 +237,15 @@ class FusedConvFn(torch.autograd.Function):
         ctx.w_dim = w.dim()
         ctx.params = (w, b, gn_w, gn_b)           # to reach pre-assigned flat-buffer gradients (see _direct_grad)
         ctx.save_for_backward(x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb)
+        if pass_input:
+            return y, x
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb = ctx.saved_tensors
+        if dskip is not None:
+            dskip = to_cl(dskip)
         cfg = ctx.cfg
         dy = to_cl(dy)
         N, Cin, Hin, Win = x.shape
@@ -302,16 +310,19 @@ class FusedConvFn(torch.autograd.Function):
                     dgb = torch.empty_like(dgw)
                 ws = workspace(query("favae_gn_workspace", N, Hin * Win, Cin), dev)
                 call("favae_gn_act_bwd", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), N, Hin * Win, Cin,
-                     cfg.groups, act, None, ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,
+                     cfg.groups, act, ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,
                      ptr(ws), ws.numel())
+                dskip = None                                  # consumed by the kernel (dx = GN-backward + dskip)
             else:
                 dx = da
+        if dskip is not None:
+            dx = dskip if dx is None else dx + dskip
         dres = dy if ctx.has_res else None
-        return dx, dw, db, dgw, dgb, dres, None
+        return dx, dw, db, dgw, dgb, dres, None, None
 
 
-def fused_conv(x, w, b=None, gn_w=None, gn_b=None, resid=None, cfg=None):
-    return FusedConvFn.apply(x, w, b, gn_w, gn_b, resid, cfg)
+def fused_conv(x, w, b=None, gn_w=None, gn_b=None, resid=None, cfg=None, pass_input=False):
+    return FusedConvFn.apply(x, w, b, gn_w, gn_b, resid, cfg, pass_input)
 
 
 # ---------------------------------------------------------------------------------------------------------------

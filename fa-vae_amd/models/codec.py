@@ -75,9 +75,12 @@ class _NormActConvBlock(nn.Module):
             self.shortcut = nn.Conv2d(in_c, out_c, kernel_size=1, stride=1, padding=0)
         self._cfg = _cfg_gn(num_groups)
 
-    def _body(self, x, resid):
+    def _conv1(self, x, pass_input=False):
         b = self.block
-        h = K.fused_conv(x, b[2].weight, b[2].bias, b[0].weight, b[0].bias, None, self._cfg)
+        return K.fused_conv(x, b[2].weight, b[2].bias, b[0].weight, b[0].bias, None, self._cfg, pass_input)
+
+    def _conv2(self, h, resid):
+        b = self.block
         return K.fused_conv(h, b[6].weight, b[6].bias, b[3].weight, b[3].bias, resid, self._cfg)
 
 
@@ -86,8 +89,11 @@ class ResnetBlock(_NormActConvBlock):
         super().__init__(in_c, out_c, dropout)
 
     def forward(self, x):
-        skip = K.fused_conv(x, self.shortcut.weight, self.shortcut.bias, cfg=_C1) if self.has_shortcut else x
-        return self._body(x, skip)                                # x + h, add fused in the second conv's epilogue
+        # the skip path reads the alias of x returned by the first conv: its gradient is then added inside that conv's
+        # GroupNorm-backward kernel (ops.FusedConvFn, pass_input) instead of by an autograd accumulation kernel
+        h, xa = self._conv1(x, pass_input=True)
+        skip = K.fused_conv(xa, self.shortcut.weight, self.shortcut.bias, cfg=_C1) if self.has_shortcut else xa
+        return self._conv2(h, skip)                               # x + h, add fused in the second conv's epilogue
 
 
 class NonResnetBlock(_NormActConvBlock):
@@ -97,7 +103,7 @@ class NonResnetBlock(_NormActConvBlock):
         super().__init__(in_c, out_c, dropout, num_groups)
 
     def forward(self, x):
-        return self._body(x, None)
+        return self._conv2(self._conv1(x), None)
 
 
 class AttnBlock(nn.Module):
@@ -109,9 +115,9 @@ class AttnBlock(nn.Module):
 
     def forward(self, x):
         a = self.attn
-        qkv = K.fused_conv(x, a.in_proj_weight, a.in_proj_bias, self.norm.weight, self.norm.bias, None, self._cfg_in)
+        qkv, xa = K.fused_conv(x, a.in_proj_weight, a.in_proj_bias, self.norm.weight, self.norm.bias, None, self._cfg_in, True)
         o = K.AttnCoreFn.apply(qkv)
-        return K.fused_conv(o, a.out_proj.weight, a.out_proj.bias, resid=x, cfg=_C1)
+        return K.fused_conv(o, a.out_proj.weight, a.out_proj.bias, resid=xa, cfg=_C1)
 
 
 class TransEncoderBlock(nn.Module):
