@@ -62,17 +62,42 @@ __global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs a) {
     }
     __syncthreads();
     // ---- butterflies ------------------------------------------------------------------------------------------
-    for (int s = 1; s <= a.logL; ++s) {
-        const int half = 1 << (s - 1);
-        const int tstep = L >> s;
+    // Two radix-2 stages (s, s+1) are applied per pass on groups of four points held in registers -- the same butterflies in
+    // the same order as stage-by-stage radix-2 (bit-identical results), with half the LDS traffic and half the barriers.
+    auto bfly = [](const float2 w, float2& x0, float2& x1) {
+        const float2 t = make_float2(w.x * x1.x - w.y * x1.y, w.x * x1.y + w.y * x1.x);
+        x1 = make_float2(x0.x - t.x, x0.y - t.y);
+        x0 = make_float2(x0.x + t.x, x0.y + t.y);
+    };
+    int s = 1;
+    if (a.logL & 1) {                                          // odd number of stages: one plain radix-2 stage first
         for (int b = bl; b < L / 2; b += BL) {
+            const int p0 = b << 1;
+            float2 x0 = data[p0 * IC + ic], x1 = data[(p0 + 1) * IC + ic];
+            bfly(tw[0], x0, x1);
+            data[p0 * IC + ic] = x0;
+            data[(p0 + 1) * IC + ic] = x1;
+        }
+        __syncthreads();
+        s = 2;
+    }
+    for (; s + 1 <= a.logL; s += 2) {
+        const int half = 1 << (s - 1);
+        const int t1 = L >> s, t2 = L >> (s + 1);
+        for (int b = bl; b < L / 4; b += BL) {
             const int grp = b >> (s - 1), j = b & (half - 1);
-            const int p0 = (grp << s) + j, p1 = p0 + half;
-            const float2 w = tw[j * tstep];
-            const float2 x0 = data[p0 * IC + ic], x1 = data[p1 * IC + ic];
-            const float2 t = make_float2(w.x * x1.x - w.y * x1.y, w.x * x1.y + w.y * x1.x);
-            data[p0 * IC + ic] = make_float2(x0.x + t.x, x0.y + t.y);
-            data[p1 * IC + ic] = make_float2(x0.x - t.x, x0.y - t.y);
+            const int p0 = (grp << (s + 1)) + j;
+            float2 x0 = data[p0 * IC + ic], x1 = data[(p0 + half) * IC + ic];
+            float2 x2 = data[(p0 + 2 * half) * IC + ic], x3 = data[(p0 + 3 * half) * IC + ic];
+            const float2 w1 = tw[j * t1];
+            bfly(w1, x0, x1);                                  // stage s
+            bfly(w1, x2, x3);
+            bfly(tw[j * t2], x0, x2);                          // stage s + 1
+            bfly(tw[(j + half) * t2], x1, x3);
+            data[p0 * IC + ic] = x0;
+            data[(p0 + half) * IC + ic] = x1;
+            data[(p0 + 2 * half) * IC + ic] = x2;
+            data[(p0 + 3 * half) * IC + ic] = x3;
         }
         __syncthreads();
     }
