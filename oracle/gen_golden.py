@@ -87,6 +87,14 @@ def check(name, a, b, tol=2e-5):
     assert r < tol, f"oracle != reference for {name}: maxrel {r}"
 
 
+def check_adam(name, a, b, lr):
+    """post-Adam parameters: the first Adam step is -lr*sign(g) (m/sqrt(v) = +-1), so an element whose gradient is at noise
+    level may legitimately differ by 2*lr between two fp32 implementations; nothing may differ by more."""
+    d = float((a.detach().double() - b.detach().double()).abs().max())
+    report.append((name + " [abs, bound 2*lr]", d))
+    assert d <= 2.02 * lr, f"oracle != reference for {name}: max abs {d} > 2*lr"
+
+
 # =============================================================================================
 # G1: blocks
 # =============================================================================================
@@ -414,6 +422,105 @@ def gen_cfg1_full():
     np.savez_compressed(os.path.join(OUT, "cfg1_256.npz"), **out)
 
 
+DISC_KEYS = ["discriminator.features.0.weight", "discriminator.features.0.bias", "discriminator.features.2.weight",
+             "discriminator.features.3.weight", "discriminator.features.3.bias", "discriminator.features.8.weight",
+             "discriminator.features.9.weight", "discriminator.head.weight", "discriminator.head.bias"]
+
+
+def gen_gan():
+    """Discriminator training (BASELINE config 5 wiring, perceptual term off): one full train() iteration of the reference
+    modules -- stage 0 with the hinge generator term and the adaptive weight (favae_scripts/train_favae.py:32-39,75-106,
+    the five lines of compute_adaptive_weight are restated here because the script itself needs tensorboard/torchvision),
+    opt_g step, stage 1 (models/vqgan_fcm.py:138-147) with hinge_d, opt_d step."""
+    tag = "gan_96"
+    mk = dict(codebook_size=512, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
+              use_l2_quantizer=True, kernel_size=9, dsl_init_sigma=3.0, use_same_conv_gauss=True, num_groups=32, device="cpu")
+    ok = dict(codebook_size=512, variant="same_conv_gauss", kernel_size=9, num_groups=32)
+    B, H, W, seed = 2, 96, 96, 4321
+    lr, disc_w = 4.5e-6 * 2, 0.75
+    out = {}
+    model = VQGANFCM(**mk)
+    P = fill_module(model, "")
+    cfg = O.OracleConfig(**ok)
+    x = O.det_input(B, H, W, seed)
+    g_params = list(model.encoder.parameters()) + list(model.decoder.parameters()) + list(model.quantizer.parameters())
+    if hasattr(model, "sigmas"):
+        opt_g = torch.optim.Adam([{"params": g_params}, {"params": model.sigmas, "lr": 2.0e-7}], lr=lr, betas=(0.5, 0.9))
+    else:
+        opt_g = torch.optim.Adam(g_params, lr=lr, betas=(0.5, 0.9))
+    opt_d = torch.optim.Adam(model.discriminator.parameters(), lr=lr, betas=(0.5, 0.9))
+    # ---- stage 0 (reference) ----
+    opt_g.zero_grad()
+    res = run_reference_step(model, x, dsl_w=0.01, ffl_w=1.0, cw=1.0)
+    loss_recon = res["loss_l1"]
+    loss_disc = hinge_g_loss(res["logits_fake"])
+    last_layer = model.decoder.final[2].weight
+    grad_disc = torch.autograd.grad(loss_disc, last_layer, retain_graph=True)[0]
+    grad_recon = torch.autograd.grad(loss_recon, last_layer, retain_graph=True)[0]
+    weight_d = torch.clamp(torch.norm(grad_recon) / (torch.norm(grad_disc) + 1e-4), 0.0, 1e4).item()
+    loss_g = res["loss_g"] + weight_d * disc_w * loss_disc
+    loss_g.sum().backward()
+    named = dict(model.named_parameters())
+    g_grads = {k: named[k].grad.clone() for k in GRAD_KEYS if k in named and named[k].grad is not None}
+    opt_g.step()
+    # ---- stage 1 (reference) ----
+    opt_d.zero_grad()
+    logits_real, logits_fake = model(x, stage=1)
+    loss_d = hinge_d_loss(logits_real, logits_fake)
+    loss_d.backward()
+    d_grads = {k: named[k].grad.clone() for k in DISC_KEYS}
+    opt_d.step()
+    # ---- oracle ----
+    tr = O.OracleTrainer(cfg, O.StepConfig(codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, lr=lr, train_disc=True,
+                                           disc_weight=disc_w), state={k: v.clone() for k, v in P.items()})
+    ro = tr.step(x)
+    check(f"{tag}/x_recon", ro["out"]["x_recon"], res["x_recon"], tol=1e-4)
+    check(f"{tag}/logits_fake", ro["out"]["logits_fake"], res["logits_fake"], tol=1e-4)
+    check(f"{tag}/loss_disc", ro["loss_disc"], loss_disc, tol=1e-4)
+    check(f"{tag}/weight_d", torch.tensor(ro["weight_d"]), torch.tensor(weight_d), tol=2e-3)
+    check(f"{tag}/loss_g", ro["loss_g"], loss_g, tol=1e-4)
+    check(f"{tag}/loss_d", ro["loss_d"], loss_d, tol=1e-4)
+    check(f"{tag}/logits_real", ro["logits_real"], logits_real, tol=1e-4)
+    check(f"{tag}/logits_fake_d", ro["logits_fake_d"], logits_fake, tol=1e-4)
+    p = tag + "."
+    summarize(p, res, model, out, x)
+    out[p + "indices"] = npy(ro["out"]["indices"])
+    out[p + "weight_d"] = np.float64(weight_d)
+    out[p + "loss_disc"] = npy(loss_disc.reshape(-1))
+    out[p + "loss_g_total"] = npy(loss_g.reshape(-1))
+    out[p + "loss_d"] = npy(loss_d.reshape(-1))
+    for nm, t in (("logits_fake", res["logits_fake"]), ("logits_real", logits_real), ("logits_fake_d", logits_fake)):
+        out[p + nm] = npy(t)
+    for k, g in g_grads.items():
+        out[p + "g." + k + ".sum"] = np.float64(g.double().sum().item())
+        out[p + "g." + k + ".abs"] = np.float64(g.double().abs().sum().item())
+        out[p + "g." + k + ".head"] = npy(g.reshape(-1)[:16])
+        check(f"{tag}/g.{k}", ro["grads"][k], g, tol=2e-3)
+    for k, g in d_grads.items():
+        out[p + "dg." + k + ".sum"] = np.float64(g.double().sum().item())
+        out[p + "dg." + k + ".abs"] = np.float64(g.double().abs().sum().item())
+        out[p + "dg." + k + ".head"] = npy(g.reshape(-1)[:16])
+        check(f"{tag}/dg.{k}", ro["dgrads"][k], g, tol=2e-3)
+        out[p + "adam." + k + ".head"] = npy(named[k].reshape(-1)[:16])
+        check_adam(f"{tag}/adam.{k}", tr.P[k], named[k], lr)
+    for k in ("encoder.conv_in.weight", "decoder.final.2.weight"):
+        out[p + "adam." + k + ".head"] = npy(named[k].reshape(-1)[:16])
+        check_adam(f"{tag}/adam.{k}", tr.P[k], named[k], lr)
+    # side effects of the iteration: two EMA codebook updates, three BatchNorm running-stat updates
+    out[p + "embed_after_sum"] = np.float64(model.quantizer._codebook.embed.double().sum().item())
+    out[p + "embed_after_abs"] = np.float64(model.quantizer._codebook.embed.double().abs().sum().item())
+    out[p + "cluster_after"] = npy(model.quantizer._codebook.cluster_size)
+    check(f"{tag}/embed_after", tr.P["quantizer._codebook.embed"], model.quantizer._codebook.embed)
+    out[p + "bn_running_mean"] = npy(model.discriminator.features[3].running_mean)
+    out[p + "bn_running_var"] = npy(model.discriminator.features[3].running_var)
+    out[p + "bn_batches"] = np.int64(int(model.discriminator.features[3].num_batches_tracked))
+    check(f"{tag}/bn_running_mean", tr.P["discriminator.features.3.running_mean"], model.discriminator.features[3].running_mean)
+    check(f"{tag}/bn_running_var", tr.P["discriminator.features.3.running_var"], model.discriminator.features[3].running_var)
+    out[p + "shape"] = np.array([B, H, W, seed], np.int64)
+    out[p + "hyper"] = np.array([lr, disc_w], np.float64)
+    np.savez_compressed(os.path.join(OUT, "gan_96.npz"), **out)
+
+
 def gen_hinge():
     out = {}
     a = (3 * (2 * O._hash_uniform(2 * 30 * 30, 1).reshape(2, 1, 30, 30) - 1)).float()
@@ -426,7 +533,7 @@ def gen_hinge():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["blocks", "blur", "vq", "hinge", "models", "cfg1"]
+    which = sys.argv[1:] or ["blocks", "blur", "vq", "hinge", "models", "cfg1", "gan"]
     if "blocks" in which:
         gen_blocks()
     if "blur" in which:
@@ -439,6 +546,8 @@ if __name__ == "__main__":
         gen_models()
     if "cfg1" in which:
         gen_cfg1_full()
+    if "gan" in which:
+        gen_gan()
     print("oracle-vs-reference max relative differences:")
     for name, r in report:
         print(f"  {name:55s} {r:.3e}")
