@@ -120,9 +120,74 @@ int diff_sum(const float* a, const float* b, int64_t n, float scale, float* loss
     return FAVAE_OK;
 }
 
+// hinge GAN terms (losses/hinge.py:5-14) as means of one logits tensor: MODE 0: -x (generator), 1: relu(1 - x) (real),
+// 2: relu(1 + x) (fake).  Forward: fp64 block partials -> finish_kernel; backward: d/dx * g * scale.
+__device__ __forceinline__ float hinge_val(float x, int mode) {
+    return mode == 0 ? -x : (mode == 1 ? fmaxf(1.f - x, 0.f) : fmaxf(1.f + x, 0.f));
+}
+__global__ __launch_bounds__(256) void hinge_reduce_kernel(const float* x, long n, int mode, double* part) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += (double)hinge_val(x[i], mode);
+    const double tot = block_sum_d256(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void hinge_bwd_kernel(const float* x, const float* g, float scale, long n, int mode, float* dx) {
+    const float gs = g[0] * scale;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i];
+        const float d = mode == 0 ? -1.f : (mode == 1 ? (1.f - v > 0.f ? -1.f : 0.f) : (1.f + v > 0.f ? 1.f : 0.f));
+        dx[i] = d * gs;
+    }
+}
+
+// dx = da * act'(x) for an activation applied without normalisation (first LeakyReLU of the discriminator)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* da, const float* x, int act, long n, float* dx) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i];
+        float d = 1.f;
+        if (act == FAVAE_ACT_SILU) {
+            const float sg = 1.f / (1.f + __expf(-v));
+            d = sg * (1.f + v * (1.f - sg));
+        } else if (act == FAVAE_ACT_LEAKY02) {
+            d = v > 0.f ? 1.f : 0.2f;
+        }
+        dx[i] = da[i] * d;
+    }
+}
+
 }  // namespace
 
 extern "C" int favae_abi_version(void) { return 4; }
+
+extern "C" int favae_hinge_mean(const float* x, int64_t n, int mode, float* loss, void* ws, size_t ws_bytes,
+                                favae_stream_t stream) {
+    FAVAE_REQUIRE(x && loss && ws && n > 0 && mode >= 0 && mode <= 2);
+    if (ws_bytes < RED_BLOCKS * sizeof(double)) return FAVAE_ERR_WORKSPACE;
+    long nb = (n + 255) / 256;
+    nb = nb > RED_BLOCKS ? RED_BLOCKS : nb;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(hinge_reduce_kernel, dim3((int)nb), dim3(256), 0, s, x, (long)n, mode, (double*)ws);
+    FAVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, (int)nb, 1.0 / (double)n, loss);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_hinge_mean_bwd(const float* x, const float* g, int64_t n, int mode, float* dx, favae_stream_t stream) {
+    FAVAE_REQUIRE(x && g && dx && n > 0 && mode >= 0 && mode <= 2);
+    hipLaunchKernelGGL(hinge_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, g, (float)(1.0 / (double)n),
+                       (long)n, mode, dx);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_act_bwd(const float* da, const float* x, int act, int64_t n, float* dx, favae_stream_t stream) {
+    FAVAE_REQUIRE(da && x && dx && n > 0);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, da, x, act, (long)n, dx);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
 
 extern "C" size_t favae_reduce_workspace(int64_t n) { (void)n; return RED_BLOCKS * sizeof(double); }
 

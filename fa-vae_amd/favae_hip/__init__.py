@@ -63,6 +63,9 @@ SIGNATURES = {
     "favae_vq_segment_sum": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _S]),
     "favae_vq_ema_update": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _S]),
     "favae_vq_ste": (c_int, [_P, _P, _P, c_int64, _S]),
+    "favae_hinge_mean": (c_int, [_P, c_int64, c_int, _P, _P, c_size_t, _S]),
+    "favae_hinge_mean_bwd": (c_int, [_P, _P, c_int64, c_int, _P, _S]),
+    "favae_act_bwd": (c_int, [_P, _P, c_int, c_int64, _P, _S]),
     "favae_reduce_workspace": (c_size_t, [c_int64]),
     "favae_absdiff_sum": (c_int, [_P, _P, c_int64, c_float, _P, _P, c_size_t, _S]),
     "favae_sqdiff_sum": (c_int, [_P, _P, c_int64, c_float, _P, _P, c_size_t, _S]),

@@ -152,11 +152,28 @@ def absmax(t):
     return out
 
 
+_DIRECT_GRAD = True
+
+
+class no_direct_grad:
+    """Context manager: gradients are returned to autograd instead of being accumulated straight into the flat gradient
+    buffer -- needed by torch.autograd.grad() calls (the adaptive weight of train_favae.py:32-39), which must neither touch
+    .grad nor receive None."""
+
+    def __enter__(self):
+        global _DIRECT_GRAD
+        self.prev, _DIRECT_GRAD = _DIRECT_GRAD, False
+
+    def __exit__(self, *a):
+        global _DIRECT_GRAD
+        _DIRECT_GRAD = self.prev
+
+
 def _direct_grad(p):
     """Gradient target for parameter `p` when its .grad is a pre-zeroed view of a flat gradient buffer owned by
     favae_step.TrainStep (marked `_favae_flat`): the reduction kernels then ACCUMULATE into it and autograd is handed
     None, which removes one AccumulateGrad add kernel per parameter.  None -> ordinary autograd path."""
-    if p is None or not getattr(p, "_favae_flat", False) or p.grad is None:
+    if not _DIRECT_GRAD or p is None or not getattr(p, "_favae_flat", False) or p.grad is None:
         return None
     g = p.grad
     if g.dim() == 4:
@@ -166,12 +183,16 @@ def _direct_grad(p):
 
 class ConvCfg:
     """Static description of one fused conv site."""
-    __slots__ = ("kh", "kw", "stride", "pad", "pad_br", "upsample", "act", "groups", "eps")
+    __slots__ = ("kh", "kw", "stride", "pad", "pad_br", "upsample", "act", "groups", "eps", "norm")
 
-    def __init__(self, kh, kw, stride=1, pad=0, pad_br=None, upsample=False, act=ACT_SILU, groups=32, eps=1e-5):
+    def __init__(self, kh, kw, stride=1, pad=0, pad_br=None, upsample=False, act=ACT_SILU, groups=32, eps=1e-5, norm="group"):
+        """norm: how the fused input transform act(affine(x)) gets its affine --
+        "group": GroupNorm(groups) of x, statistics per image (gn_w/gn_b = its weight/bias);
+        "batch": BatchNorm2d batch statistics over (N,H,W) (gn_w/gn_b = its weight/bias; bn_batch_stats() supplies `stats`);
+        "act":   no normalisation, the activation alone (gn_w/gn_b = None)."""
         self.kh, self.kw, self.stride, self.pad = kh, kw, stride, pad
         self.pad_br = pad if pad_br is None else pad_br
-        self.upsample, self.act, self.groups, self.eps = upsample, act, groups, eps
+        self.upsample, self.act, self.groups, self.eps, self.norm = upsample, act, groups, eps, norm
 
     def out_hw(self, H, W):
         if self.upsample:
@@ -211,7 +232,7 @@ class FusedConvFn(torch.autograd.Function):
     and is added inside the GroupNorm-backward kernel (dx_add) instead of by a separate autograd accumulation kernel."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gn_w, gn_b, resid, cfg, pass_input=False):
+    def forward(ctx, x, w, b, gn_w, gn_b, resid, cfg, pass_input=False, stats=None):
         x = to_cl(x)
         N, Cin, Hin, Win = x.shape
         w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
@@ -220,19 +241,31 @@ class FusedConvFn(torch.autograd.Function):
         Ho, Wo = cfg.out_hw(Hin, Win)
         dev = x.device
         mean = rstd = scale = shift = xb = None
-        if gn_w is not None:
+        per_image = 1
+        if cfg.norm == "batch":                   # BatchNorm batch statistics, computed by bn_batch_stats() (running stats there)
+            mean, rstd, scale, shift, xb = stats
+            per_image = 0
+        elif cfg.norm == "act":                   # activation only: identity affine shared by all images
+            scale = torch.ones((1, Cin), dtype=torch.float32, device=dev)
+            shift = torch.zeros((1, Cin), dtype=torch.float32, device=dev)
+            xb = absmax(x) if _fp16_planes() else None           # |act(x)| <= |x| for SiLU / LeakyReLU
+            per_image = 0
+        elif gn_w is not None:
             mean, rstd, scale, shift, xb = gn_stats(x, gn_w, gn_b, cfg.groups, cfg.eps, with_bound=True)
         if resid is not None:
             resid = to_cl(resid)
         y = new_cl(N, Cout, Ho, Wo, dev)
         d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad,
-                           GATHER_UPSAMPLE2 if cfg.upsample else GATHER_PLAIN, cfg.act if gn_w is not None else ACT_NONE, 1)
+                           GATHER_UPSAMPLE2 if cfg.upsample else GATHER_PLAIN, cfg.act if scale is not None else ACT_NONE,
+                           per_image)
         if xb is None and query("favae_conv_wants_split_weights", byref(d), 0) == 2:
             xb = absmax(x)
         _conv_launch(d, x, wk, b, resid, scale, shift, y, xb)
         ctx.cfg = cfg
         ctx.has_b = b is not None
         ctx.has_gn = gn_w is not None
+        ctx.has_xform = scale is not None
+        ctx.per_image = per_image
         ctx.has_res = resid is not None
         ctx.w_dim = w.dim()
         ctx.params = (w, b, gn_w, gn_b)           # to reach pre-assigned flat-buffer gradients (see _direct_grad)
@@ -254,7 +287,7 @@ class FusedConvFn(torch.autograd.Function):
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = dw = db = dgw = dgb = None
         gather = GATHER_UPSAMPLE2 if cfg.upsample else GATHER_PLAIN
-        act = cfg.act if ctx.has_gn else ACT_NONE
+        act = cfg.act if ctx.has_xform else ACT_NONE
         p_w, p_b, p_gw, p_gb = ctx.params
         # range of dy for the fp16 split scheme: read off the bias-gradient pass when there is one
         want_range = xb is not None and _fp16_planes()
@@ -270,7 +303,7 @@ class FusedConvFn(torch.autograd.Function):
         elif want_range:
             call("favae_absmax", ptr(dy), dy.numel(), ptr(dyb))
         if need_w:
-            d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad, gather, act, 1)
+            d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad, gather, act, ctx.per_image)
             ws = workspace(query("favae_conv_wgrad_workspace", byref(d)), dev)
             tgt = _direct_grad(p_w)
             if tgt is None:
@@ -284,6 +317,8 @@ class FusedConvFn(torch.autograd.Function):
                 call("favae_conv_wgrad", byref(d), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(tgt), 1,
                      ptr(ws), ws.numel())
         if need_x or ctx.has_gn:
+            if ctx.has_gn and mean is None:
+                raise RuntimeError("gradient through a normalisation with frozen (running) statistics is not implemented")
             wt = torch.empty((Cin, cfg.kh, cfg.kw, Cout), dtype=torch.float32, device=dev)
             call("favae_weight_flip", ptr(wk), ptr(wt), Cout, cfg.kh, cfg.kw, Cin)
             if cfg.stride == 1:
@@ -308,21 +343,70 @@ class FusedConvFn(torch.autograd.Function):
                 if not direct:
                     dgw = torch.empty((Cin,), dtype=torch.float32, device=dev)
                     dgb = torch.empty_like(dgw)
-                ws = workspace(query("favae_gn_workspace", N, Hin * Win, Cin), dev)
-                call("favae_gn_act_bwd", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), N, Hin * Win, Cin,
-                     cfg.groups, act, ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,
+                # BatchNorm = GroupNorm with one channel per group over the batch folded into the pixel dimension
+                gN, gHW, gG = (1, N * Hin * Win, Cin) if cfg.norm == "batch" else (N, Hin * Win, cfg.groups)
+                ws = workspace(query("favae_gn_workspace", gN, gHW, Cin), dev)
+                call("favae_gn_act_bwd", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin,
+                     gG, act, ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,
                      ptr(ws), ws.numel())
                 dskip = None                                  # consumed by the kernel (dx = GN-backward + dskip)
+            elif ctx.has_xform:                               # activation without normalisation
+                dx = new_cl(N, Cin, Hin, Win, dev)
+                call("favae_act_bwd", ptr(da), ptr(x), act, da.numel(), ptr(dx))
             else:
                 dx = da
         if dskip is not None:
             dx = dskip if dx is None else dx + dskip
         dres = dy if ctx.has_res else None
-        return dx, dw, db, dgw, dgb, dres, None, None
+        return dx, dw, db, dgw, dgb, dres, None, None, None
 
 
-def fused_conv(x, w, b=None, gn_w=None, gn_b=None, resid=None, cfg=None, pass_input=False):
-    return FusedConvFn.apply(x, w, b, gn_w, gn_b, resid, cfg, pass_input)
+def fused_conv(x, w, b=None, gn_w=None, gn_b=None, resid=None, cfg=None, pass_input=False, stats=None):
+    return FusedConvFn.apply(x, w, b, gn_w, gn_b, resid, cfg, pass_input, stats)
+
+
+@torch.no_grad()
+def bn_batch_stats(x, bn, training):
+    """Statistics of nn.BatchNorm2d `bn` for the fused conv that consumes act(bn(x)) (cfg.norm == "batch"): batch statistics
+    (+ running-stat update exactly like nn.BatchNorm2d: momentum, unbiased variance) in training mode, running statistics
+    otherwise.  Returns (mean, rstd, scale, shift, bound); mean/rstd are None for frozen statistics."""
+    x = to_cl(x)
+    N, C, H, W = x.shape
+    dev = x.device
+    if training or not bn.track_running_stats:
+        xv = x.permute(0, 2, 3, 1).reshape(1, N * H, W, C).permute(0, 3, 1, 2)       # (1,C,N*H,W) view of the NHWC memory
+        mean, rstd, scale, shift, bound = gn_stats(xv, bn.weight, bn.bias, C, bn.eps, with_bound=True)
+        if training and bn.track_running_stats:
+            call("favae_bn_update_running", ptr(mean), ptr(rstd), C, N * H * W, bn.eps, bn.momentum, ptr(bn.running_mean),
+                 ptr(bn.running_var))
+            bn.num_batches_tracked += 1
+        return mean, rstd, scale, shift, bound
+    inv = torch.rsqrt(bn.running_var + bn.eps)
+    scale = (bn.weight * inv).reshape(1, C).contiguous()
+    shift = (bn.bias - bn.running_mean * bn.weight * inv).reshape(1, C).contiguous()
+    bound = absmax(x) * scale.abs().max() + shift.abs().max() if _fp16_planes() else None
+    return None, None, scale, shift, bound
+
+
+class HingeMeanFn(torch.autograd.Function):
+    """mean_i h(x_i): mode 0: -x (hinge_g_loss), 1: relu(1-x), 2: relu(1+x)   (losses/hinge.py:5-14)."""
+
+    @staticmethod
+    def forward(ctx, x, mode):
+        x = x.contiguous()
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        ws = workspace(query("favae_reduce_workspace", x.numel()), x.device)
+        call("favae_hinge_mean", ptr(x), x.numel(), mode, ptr(out), ptr(ws), ws.numel())
+        ctx.mode = mode
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        call("favae_hinge_mean_bwd", ptr(x), ptr(g.contiguous()), x.numel(), ctx.mode, ptr(dx))
+        return dx, None
 
 
 # ---------------------------------------------------------------------------------------------------------------

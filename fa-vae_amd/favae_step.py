@@ -1,6 +1,8 @@
-"""One FA-VAE training step (stage 0) on the MI355X-native kernels -- restates the hot loop of the reference's
-train() (favae_scripts/train_favae.py:68-106) for the BASELINE configurations (LPIPS and discriminator *training* off,
-FFL + 4-level DSL on), with the optimizer of :292-301 (Adam, betas (0.5, 0.9), lr = base_lr * batch * world).
+"""One FA-VAE training iteration on the MI355X-native kernels -- restates the hot loop of the reference's train()
+(favae_scripts/train_favae.py:68-116): stage 0 (encoder + decoder + quantizer: L1 + commit + FFL + 4-level DSL, optionally
+the hinge generator term with the adaptive weight of :32-39) and, with train_disc, stage 1 (discriminator, hinge loss), with
+the optimizers of :292-305 (Adam, betas (0.5, 0.9), lr = base_lr * batch * world).  The perceptual (LPIPS) term is not part
+of the accelerated path (no VGG weights offline): perceptual_weight must be 0.
 
 MI355X-first choices:
   * all trainable parameters, their gradients and both Adam moments live in four flat fp32 buffers; parameters are
@@ -15,15 +17,36 @@ import torch.distributed as dist
 
 from favae_hip import ops as K
 from focal_frequency_loss import FocalFrequencyLoss
+from losses.hinge import hinge_d_loss, hinge_g_loss
 from losses.vqgan_losses import recon_ffl_features_loss, recon_ffl_loss
+
+
+def _flatten(params, dev):
+    """parameters, gradients and Adam moments of `params` as views into four flat fp32 buffers"""
+    total = sum(p.numel() for p in params)
+    pflat = torch.empty(total, dtype=torch.float32, device=dev)
+    gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+    mflat = torch.zeros(total, dtype=torch.float32, device=dev)
+    vflat = torch.zeros(total, dtype=torch.float32, device=dev)
+    off = 0
+    for p in params:
+        n = p.numel()
+        view = pflat[off:off + n].as_strided(p.shape, p.stride())
+        view.copy_(p.data)
+        p.data = view
+        p.grad = gflat[off:off + n].as_strided(p.shape, p.stride())
+        p._favae_flat = True          # ops._direct_grad: reductions accumulate straight into this (zeroed) view
+        off += n
+    return pflat, gflat, mflat, vflat
 
 
 class TrainStep:
     def __init__(self, model, lr, betas=(0.5, 0.9), eps=1e-8, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01,
-                 sigma_lr=2.0e-7, distributed=False):
+                 sigma_lr=2.0e-7, distributed=False, train_disc=False, disc_weight=0.75):
         self.model = model
         self.lr, self.betas, self.eps, self.sigma_lr = lr, betas, eps, sigma_lr
         self.cw = codebook_weight
+        self.train_disc, self.disc_weight = train_disc, disc_weight
         self.ffl = FocalFrequencyLoss(loss_weight=ffl_weight, alpha=1.0) if ffl_weight > 0 else None
         self.dsl = FocalFrequencyLoss(loss_weight=dsl_weight, alpha=1.0) if dsl_weight > 0 else None
         self.distributed = distributed and dist.is_available() and dist.is_initialized()
@@ -36,19 +59,10 @@ class TrainStep:
         self.n_main = sum(p.numel() for p in main)
         total = self.n_main + sum(p.numel() for p in extra)
         dev = main[0].device
-        self.pflat = torch.empty(total, dtype=torch.float32, device=dev)
-        self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.mflat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.vflat = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            view = self.pflat[off:off + n].as_strided(p.shape, p.stride())
-            view.copy_(p.data)
-            p.data = view
-            p.grad = self.gflat[off:off + n].as_strided(p.shape, p.stride())
-            p._favae_flat = True          # ops._direct_grad: reductions accumulate straight into this (zeroed) view
-            off += n
+        self.pflat, self.gflat, self.mflat, self.vflat = _flatten(self.params, dev)
+        if train_disc:                 # opt_d (train_favae.py:304-305)
+            self.dparams = list(model.discriminator.parameters())
+            self.dpflat, self.dgflat, self.dmflat, self.dvflat = _flatten(self.dparams, dev)
 
     def losses(self, x):
         """Forward + loss assembly of train() :75-102 (perceptual / adversarial terms off)."""
@@ -63,9 +77,36 @@ class TrainStep:
         if self.dsl is not None:
             out["loss_dsl"], out["loss_dsl_levels"] = recon_ffl_features_loss(self.dsl, enc_feats, dec_feats, x.device)
             loss_g = loss_g + out["loss_dsl"]
+        if self.train_disc:                                  # train_favae.py:82-88 (loss_recon = L1: perceptual term off)
+            out["loss_disc"] = hinge_g_loss(_logits_fake)
+            out["weight_d"] = self.adaptive_weight(out["loss_l1"], out["loss_disc"])
+            loss_g = loss_g + out["weight_d"] * self.disc_weight * out["loss_disc"]
+        out["logits_fake"] = _logits_fake
         out["loss_g"] = loss_g
         out["x_recon"] = x_recon
         return out
+
+    def adaptive_weight(self, loss_recon, loss_disc):
+        """compute_adaptive_weight (train_favae.py:32-39): ratio of the gradient norms at decoder.final[2].weight, clamped to
+        [0, 1e4] and detached.  Kept as a device scalar (the reference syncs with .item() here)."""
+        last = self.model.decoder.final[2].weight
+        with K.no_direct_grad():
+            grad_disc = torch.autograd.grad(loss_disc, last, retain_graph=True)[0]
+            grad_recon = torch.autograd.grad(loss_recon, last, retain_graph=True)[0]
+        w = torch.norm(grad_recon) / (torch.norm(grad_disc) + 1e-4)
+        return torch.clamp(w, 0.0, 1e4).detach()
+
+    def disc_step(self, x):
+        """Stage 1 (train_favae.py:108-116): discriminator update on (x, x_recon.detach()); model(x, stage=1) recomputes the
+        reconstruction under no_grad in train mode (second EMA codebook update of the iteration, as in the reference)."""
+        self.dgflat.zero_()                                  # opt_d.zero_grad(): also drops what stage 0 left here
+        logits_real, logits_fake = self.model(K.to_cl(x), stage=1)
+        loss_d = hinge_d_loss(logits_real, logits_fake)
+        loss_d.backward()
+        if self.distributed:
+            dist.all_reduce(self.dgflat)
+        K.adam_step(self.dpflat, self.dgflat, self.dmflat, self.dvflat, self.t, self.lr, self.betas, self.eps, 1.0 / self.world)
+        return {"loss_d": loss_d, "logits_real": logits_real, "logits_fake_d": logits_fake}
 
     def step(self, x):
         self.model.train()
@@ -81,4 +122,6 @@ class TrainStep:
         if self.pflat.numel() > nm:
             K.adam_step(self.pflat[nm:], self.gflat[nm:], self.mflat[nm:], self.vflat[nm:], self.t, self.sigma_lr, self.betas,
                         self.eps, gs)
+        if self.train_disc:
+            out.update(self.disc_step(x))
         return out

@@ -1,13 +1,12 @@
-"""Hinge GAN losses (reference losses/hinge.py:5-34) -- tiny reductions, kept as torch ops on the GPU."""
-import torch
-import torch.nn.functional as F
+"""Hinge GAN losses (reference losses/hinge.py:5-34) on the HIP reduction kernels (favae_hinge_mean*)."""
+from favae_hip import ops as K
 
 
 def hinge_g_loss(logits_fake):
-    return -torch.mean(logits_fake)
+    return K.HingeMeanFn.apply(logits_fake, 0)                     # -mean(logits_fake)
 
 
 def hinge_d_loss(logits_real, logits_fake):
-    loss_real = torch.mean(F.relu(1.0 - logits_real))
-    loss_fake = torch.mean(F.relu(1.0 + logits_fake))
+    loss_real = K.HingeMeanFn.apply(logits_real, 1)                # mean(relu(1 - real))
+    loss_fake = K.HingeMeanFn.apply(logits_fake, 2)                # mean(relu(1 + fake))
     return 0.5 * (loss_real + loss_fake)

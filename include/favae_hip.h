@@ -188,6 +188,17 @@ int favae_vq_segment_sum(const float* zn, const int64_t* idx, int T, int d, int 
 int favae_vq_ema_update(float* embed, float* cluster_size, const float* en, const float* bins, const float* embed_sum,
                         int C, int d, float decay, favae_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Discriminator training terms (BASELINE config 5): hinge losses (losses/hinge.py:5-14) and the backward of an
+ * activation applied without normalisation (first LeakyReLU of models/discriminator.py:198-201).
+ * ---------------------------------------------------------------------------------------------------------- */
+/* loss = mean_i h(x_i): mode 0: -x (hinge_g_loss), 1: relu(1 - x) (real half of hinge_d_loss), 2: relu(1 + x) (fake half).
+ * ws: favae_reduce_workspace().  Backward: dx_i = g * h'(x_i) / n  (g: device scalar). */
+int favae_hinge_mean(const float* x, int64_t n, int mode, float* loss, void* ws, size_t ws_bytes, favae_stream_t stream);
+int favae_hinge_mean_bwd(const float* x, const float* g, int64_t n, int mode, float* dx, favae_stream_t stream);
+/* dx = da * act'(x), act as in favae_conv_desc */
+int favae_act_bwd(const float* da, const float* x, int act, int64_t n, float* dx, favae_stream_t stream);
+
 /* straight-through value exactly as the reference forms it: out = x + (q - x)   (models/l2_quantize.py:554) */
 int favae_vq_ste(const float* x, const float* q, float* out, int64_t n, favae_stream_t stream);
 

@@ -432,11 +432,11 @@ def gen_gan():
     modules -- stage 0 with the hinge generator term and the adaptive weight (favae_scripts/train_favae.py:32-39,75-106,
     the five lines of compute_adaptive_weight are restated here because the script itself needs tensorboard/torchvision),
     opt_g step, stage 1 (models/vqgan_fcm.py:138-147) with hinge_d, opt_d step."""
-    tag = "gan_96"
+    tag = "gan_128"
     mk = dict(codebook_size=512, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
               use_l2_quantizer=True, kernel_size=9, dsl_init_sigma=3.0, use_same_conv_gauss=True, num_groups=32, device="cpu")
     ok = dict(codebook_size=512, variant="same_conv_gauss", kernel_size=9, num_groups=32)
-    B, H, W, seed = 2, 96, 96, 4321
+    B, H, W, seed = 2, 128, 128, int(os.environ.get("FAVAE_GAN_SEED", "4321"))
     lr, disc_w = 4.5e-6 * 2, 0.75
     out = {}
     model = VQGANFCM(**mk)
@@ -500,7 +500,7 @@ def gen_gan():
         out[p + "dg." + k + ".sum"] = np.float64(g.double().sum().item())
         out[p + "dg." + k + ".abs"] = np.float64(g.double().abs().sum().item())
         out[p + "dg." + k + ".head"] = npy(g.reshape(-1)[:16])
-        check(f"{tag}/dg.{k}", ro["dgrads"][k], g, tol=2e-3)
+        check(f"{tag}/dg.{k}", ro["dgrads"][k], g, tol=1e-4)     # larger = a LeakyReLU input within rounding of zero: pick another seed
         out[p + "adam." + k + ".head"] = npy(named[k].reshape(-1)[:16])
         check_adam(f"{tag}/adam.{k}", tr.P[k], named[k], lr)
     for k in ("encoder.conv_in.weight", "decoder.final.2.weight"):
@@ -518,7 +518,7 @@ def gen_gan():
     check(f"{tag}/bn_running_var", tr.P["discriminator.features.3.running_var"], model.discriminator.features[3].running_var)
     out[p + "shape"] = np.array([B, H, W, seed], np.int64)
     out[p + "hyper"] = np.array([lr, disc_w], np.float64)
-    np.savez_compressed(os.path.join(OUT, "gan_96.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "gan_128.npz"), **out)
 
 
 def gen_hinge():

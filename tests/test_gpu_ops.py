@@ -390,3 +390,25 @@ def test_layout_roundtrip(K):
     assert torch.equal(y.cpu(), x.cpu()) and y.is_contiguous(memory_format=torch.channels_last)
     z = K.to_nchw(y)
     assert z.is_contiguous() and torch.equal(z.cpu(), x.cpu())
+
+
+def test_hinge_terms(K, golden_dir):
+    """hinge_g / hinge_d (losses/hinge.py) on the HIP reduction kernels: golden values of the reference + gradients vs torch."""
+    from losses.hinge import hinge_d_loss, hinge_g_loss
+    g = np.load(os.path.join(golden_dir, "hinge.npz"))
+    real = torch.from_numpy(g["real"]).requires_grad_(True)
+    fake = torch.from_numpy(g["fake"]).requires_grad_(True)
+    ld = 0.5 * (F.relu(1 - real).mean() + F.relu(1 + fake).mean())
+    lg = -fake.mean()
+    gr = torch.autograd.grad(ld, (real, fake))
+    gg = torch.autograd.grad(lg, fake)[0]
+    rd = real.detach().to(dev()).requires_grad_(True)
+    fd = fake.detach().to(dev()).requires_grad_(True)
+    ldd = hinge_d_loss(rd, fd)
+    lgd = hinge_g_loss(fd)
+    check(ldd, torch.from_numpy(g["d"]), 1e-6, "hinge_d vs reference golden")
+    check(lgd, torch.from_numpy(g["g"]), 1e-6, "hinge_g vs reference golden")
+    grd = torch.autograd.grad(ldd, (rd, fd))
+    check(grd[0], gr[0], 1e-6, "d hinge_d / d real")
+    check(grd[1], gr[1], 1e-6, "d hinge_d / d fake")
+    check(torch.autograd.grad(lgd, fd)[0], gg, 1e-6, "d hinge_g / d fake")

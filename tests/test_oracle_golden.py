@@ -229,48 +229,52 @@ def test_cfg1_full_256(golden_dir):
 GAN_CFG = dict(codebook_size=512, variant="same_conv_gauss", kernel_size=9, num_groups=32)
 
 
-def check_gan_golden(g, res, P, lr, close_fn=close, grad_tol=5e-3):
+GAN_TOLS_ORACLE = dict(stage0=1e-4, weight_d=2e-3, loss_g=1e-4, grads=5e-3, logits_fake_d=1e-4, dgrad_head=5e-3, dgrad_abs=5e-3,
+                       bn=1e-4)
+
+
+def check_gan_golden(g, res, P, lr, close_fn=close, tols=GAN_TOLS_ORACLE):
     """Shared by the CPU (oracle) and GPU (HIP path) tests: one full train() iteration with discriminator training against the
-    outputs captured from the reference modules (tests/golden/gan_96.npz, oracle/gen_golden.py::gen_gan).
+    outputs captured from the reference modules (tests/golden/gan_128.npz, oracle/gen_golden.py::gen_gan).
     res: loss_disc, weight_d, loss_g, loss_d, logits_fake (stage 0), logits_real, logits_fake_d (stage 1), grads, dgrads;
-    P: name -> parameter/buffer after the iteration."""
-    p = "gan_96."
-    close_fn(res["loss_disc"].reshape(-1), g[p + "loss_disc"], rtol=1e-4, name="loss_disc")
-    close_fn(torch.as_tensor(float(res["weight_d"])), g[p + "weight_d"], rtol=2e-3, name="weight_d")
-    close_fn(res["loss_g"].reshape(-1), g[p + "loss_g_total"], rtol=1e-4, name="loss_g")
-    close_fn(res["loss_d"].reshape(-1), g[p + "loss_d"], rtol=1e-4, name="loss_d")
-    close_fn(res["logits_fake"], g[p + "logits_fake"], rtol=1e-4, name="logits_fake")
-    close_fn(res["logits_real"], g[p + "logits_real"], rtol=1e-4, name="logits_real")
-    close_fn(res["logits_fake_d"], g[p + "logits_fake_d"], rtol=1e-4, name="logits_fake_d")
+    P: name -> parameter/buffer after the iteration.  tols: see GAN_TOLS_ORACLE / the GPU test for why they differ."""
+    p = "gan_128."
+    close_fn(res["loss_disc"].reshape(-1), g[p + "loss_disc"], rtol=tols["stage0"], name="loss_disc")
+    close_fn(torch.as_tensor(float(res["weight_d"])), g[p + "weight_d"], rtol=tols["weight_d"], name="weight_d")
+    close_fn(res["loss_g"].reshape(-1), g[p + "loss_g_total"], rtol=tols["loss_g"], name="loss_g")
+    close_fn(res["logits_fake"], g[p + "logits_fake"], rtol=tols["stage0"], name="logits_fake")
+    close_fn(res["logits_real"], g[p + "logits_real"], rtol=tols["stage0"], name="logits_real")
+    close_fn(res["loss_d"].reshape(-1), g[p + "loss_d"], rtol=tols["stage0"], name="loss_d")
+    close_fn(res["logits_fake_d"], g[p + "logits_fake_d"], rtol=tols["logits_fake_d"], name="logits_fake_d")
     n = 0
     for k, gr in res["grads"].items():
         if p + "g." + k + ".head" in g.files:
-            close_fn(gr.reshape(-1)[:16], g[p + "g." + k + ".head"], rtol=grad_tol, name="g." + k)
+            close_fn(gr.reshape(-1)[:16], g[p + "g." + k + ".head"], rtol=tols["grads"], name="g." + k)
             n += 1
     assert n >= 8
     for k, gr in res["dgrads"].items():
         if p + "dg." + k + ".head" in g.files:
-            close_fn(gr.reshape(-1)[:16], g[p + "dg." + k + ".head"], rtol=grad_tol, name="dg." + k)
-            close_fn(gr.double().abs().sum(), g[p + "dg." + k + ".abs"], rtol=grad_tol, name="dgabs." + k)
+            close_fn(gr.reshape(-1)[:16], g[p + "dg." + k + ".head"], rtol=tols["dgrad_head"], name="dg." + k)
+            close_fn(gr.double().abs().sum(), g[p + "dg." + k + ".abs"], rtol=tols["dgrad_abs"], name="dgabs." + k)
             # first Adam step = -lr*sign(g): a noise-level gradient may flip sign between fp32 implementations
             d = float((P[k].detach().reshape(-1)[:16].double().cpu() - T(g[p + "adam." + k + ".head"]).double()).abs().max())
             assert d <= 2.02 * lr, f"adam.{k}: {d}"
             n += 1
     assert n >= 17
     close_fn(P["quantizer._codebook.embed"].double().abs().sum(), g[p + "embed_after_abs"], rtol=1e-5, name="embed after 2 EMA updates")
-    close_fn(P["discriminator.features.3.running_mean"], g[p + "bn_running_mean"], rtol=1e-4, name="bn mean after 3 updates")
-    close_fn(P["discriminator.features.3.running_var"], g[p + "bn_running_var"], rtol=1e-4, name="bn var after 3 updates")
+    close_fn(P["discriminator.features.3.running_mean"], g[p + "bn_running_mean"], rtol=tols["bn"], name="bn mean after 3 updates")
+    close_fn(P["discriminator.features.3.running_var"], g[p + "bn_running_var"], rtol=tols["bn"], name="bn var after 3 updates")
 
 
 def test_gan_iteration(golden_dir):
     """Config-5 wiring (hinge generator term, adaptive weight, stage-1 discriminator update), perceptual term off."""
-    g = np.load(os.path.join(golden_dir, "gan_96.npz"))
-    B, H, W, seed = [int(v) for v in g["gan_96.shape"]]
-    lr, disc_w = [float(v) for v in g["gan_96.hyper"]]
+    g = np.load(os.path.join(golden_dir, "gan_128.npz"))
+    B, H, W, seed = [int(v) for v in g["gan_128.shape"]]
+    lr, disc_w = [float(v) for v in g["gan_128.hyper"]]
     cfg = O.OracleConfig(**GAN_CFG)
     tr = O.OracleTrainer(cfg, O.StepConfig(codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, lr=lr, train_disc=True,
                                            disc_weight=disc_w))
     r = tr.step(O.det_input(B, H, W, seed))
-    assert np.array_equal(r["out"]["indices"].numpy(), g["gan_96.indices"])
+    assert np.array_equal(r["out"]["indices"].numpy(), g["gan_128.indices"])
     r["logits_fake"] = r["out"]["logits_fake"]
     check_gan_golden(g, r, tr.P, lr)
