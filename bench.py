@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--codebook", type=int, default=16384)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gan", action="store_true",
+                    help="also train the discriminator (BASELINE config-5 wiring: hinge terms, adaptive weight, stage 1; perceptual "
+                         "term off) -- not the headline workload, reported under config.workload")
     ap.add_argument("--cpu-batch", type=int, default=8, help="images in the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -157,7 +160,7 @@ def main():
                      use_l2_quantizer=True, sync_codebook=use_dist, commitment_weight=1.0, kernel_size=9, dsl_init_sigma=3.0,
                      device=dev, use_gauss_resblock=True).to(dev)
     lr = 4.5e-6 * args.batch * world               # train_favae.py:250-251
-    ts = TrainStep(model, lr=lr, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, distributed=use_dist)
+    ts = TrainStep(model, lr=lr, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, distributed=use_dist, train_disc=args.gan)
     xs = [O.det_input(args.batch, args.res, args.res, 1234 + 17 * rank + i).to(dev) for i in range(2)]
 
     hook = ConvEventHook(torch)
@@ -201,7 +204,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: FA-VAE f=16 CelebA-HQ config, codebook %d, embed_dim 256, residual FCM + "
                                    "non-pairwise DSL (k=9, sigma0=3), FFL 1.0 + DSL 0.01, %dx%d, batch %d per GPU, stage-0 step "
-                                   "(LPIPS/disc training off, disc forward on)" % (args.codebook, args.res, args.res, args.batch),
+                                   "(LPIPS/disc training off, disc forward on)" % (args.codebook, args.res, args.res, args.batch)
+                                   + (" + discriminator training (hinge, adaptive weight, stage 1)" if args.gan else ""),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss_g_last": loss},
         }
         if conv:
