@@ -103,6 +103,7 @@ class TrainStep:
         logits_real, logits_fake = self.model(K.to_cl(x), stage=1)
         loss_d = hinge_d_loss(logits_real, logits_fake)
         loss_d.backward()
+        K.sync_side_stream()
         if self.distributed:
             dist.all_reduce(self.dgflat)
         K.adam_step(self.dpflat, self.dgflat, self.dmflat, self.dvflat, self.t, self.lr, self.betas, self.eps, 1.0 / self.world)
@@ -113,6 +114,7 @@ class TrainStep:
         self.gflat.zero_()
         out = self.losses(x)
         out["loss_g"].sum().backward()
+        K.sync_side_stream()                                 # weight gradients run on a second stream (ops._SIDE)
         if self.distributed:
             dist.all_reduce(self.gflat)                      # RCCL over xGMI; averaged inside the Adam kernel
         self.t += 1
