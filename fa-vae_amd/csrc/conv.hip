@@ -1037,6 +1037,57 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     return FAVAE_OK;
 }
 
+namespace {
+// weight_flip_kernel + split_w_kernel in one pass: the flipped weights of the data-gradient convolution go straight into
+// pre-split records.  The range of the flipped tensor is the range of w: `amax_src` is the header of the forward's record
+// buffer (no second maximum reduction).  Cout % 4 == 0.
+template <int NP>
+__global__ __launch_bounds__(256) void weight_flip_split_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
+                                                                int Cout, int KH, int KW, int Cin,
+                                                                const float* __restrict__ amax_src) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int kh = tap / KW, kw = tap % KW;
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        reinterpret_cast<float*>(out)[0] = amax_src ? amax_src[0] : 0.f;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * KH * KW + tap) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+    const float Sw = (NP == 2 && amax_src) ? sp::pow2_scale(amax_src) : 1.f;
+    const int tapf = (KH - 1 - kh) * KW + (KW - 1 - kw);
+    // 32 ci x 8 co-quads = 256 records per tile: thread -> (ci = tid / 8, quad = tid % 8)
+    const int r = threadIdx.x >> 3, qd = threadIdx.x & 7;
+    const int ci = ci0 + r, co = co0 + 4 * qd;
+    if (ci < Cin && co < Cout) {
+        const float4 v = make_float4(tile[4 * qd][r], tile[4 * qd + 1][r], tile[4 * qd + 2][r], tile[4 * qd + 3][r]);
+        uint2 p[NP];
+        sp::Scheme<NP>::split4(v, Sw, p);
+        unsigned* o = reinterpret_cast<unsigned*>(out + sp::WHDR) + ((((size_t)ci * KH * KW + tapf) * Cout + co) / 4) * (2 * NP);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { o[2 * k] = p[k].x; o[2 * k + 1] = p[k].y; }
+    }
+}
+}  // namespace
+
+extern "C" int favae_weight_flip_split(const float* w, void* out, int Cout, int KH, int KW, int Cin, int planes,
+                                       const float* absmax_src, favae_stream_t stream) {
+    FAVAE_REQUIRE(w && out && Cout > 0 && KH > 0 && KW > 0 && Cin > 0 && Cout % 4 == 0 && (planes == 3 || (planes == 2 && absmax_src)));
+    FAVAE_REQUIRE((((uintptr_t)out) & 15) == 0);
+    dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), KH * KW);
+    if (planes == 2)
+        hipLaunchKernelGGL((weight_flip_split_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, Cout, KH, KW,
+                           Cin, absmax_src);
+    else
+        hipLaunchKernelGGL((weight_flip_split_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, Cout, KH, KW,
+                           Cin, absmax_src);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
 extern "C" int favae_weight_flip(const float* w, float* wt, int Cout, int KH, int KW, int Cin, favae_stream_t stream) {
     FAVAE_REQUIRE(w && wt && Cout > 0 && KH > 0 && KW > 0 && Cin > 0);
     dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), KH * KW);

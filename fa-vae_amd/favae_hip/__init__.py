@@ -40,6 +40,7 @@ SIGNATURES = {
     "favae_conv_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "favae_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _S]),
     "favae_weight_flip": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
+    "favae_weight_flip_split": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _S]),
     "favae_colsum_workspace": (c_size_t, [c_int64, c_int]),
     "favae_colsum": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, c_size_t, _S]),
     "favae_upsample2x_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),

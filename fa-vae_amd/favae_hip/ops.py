@@ -225,15 +225,29 @@ class ConvCfg:
         return Ho, Wo
 
 
-def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None):
+def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=None):
     """conv forward / data gradient.  When the library runs this shape on the split-precision matrix path the weights are
     pre-split once per call (instead of once per tile in the K loop); the fp16 scheme (2 planes) also needs the operand
-    range: `x_bound` = device scalar >= max|T(x)| (computed here for an un-transformed operand when not supplied)."""
+    range: `x_bound` = device scalar >= max|T(x)| (computed here for an un-transformed operand when not supplied).
+    flip_of = (w, Cout, KH, KW, Cin, w_absmax): the weights of this (data-gradient) conv are the flip of the OHWI tensor w;
+    w_ohwi may then be None -- records are written by one flip+split kernel that reuses the forward's max|w|.
+    Returns the device float holding max|w| when pre-split records were made (fp16 scheme), else None."""
     planes = query("favae_conv_wants_split_weights", byref(d), 0 if scale is None else 1)
+    w_amax = None
     if planes:
-        n = w_ohwi.numel()
-        wsp = torch.empty(query("favae_split_weights_bytes", n, planes), dtype=torch.uint8, device=w_ohwi.device)
-        call("favae_split_weights", ptr(w_ohwi), ptr(wsp), n, planes)
+        if flip_of is not None and (planes == 3 or flip_of[5] is not None) and os.environ.get("FAVAE_FLIP_SPLIT", "1") != "0":
+            w, co, kh, kw, ci, w_amax = flip_of
+            n = w.numel()
+            wsp = torch.empty(query("favae_split_weights_bytes", n, planes), dtype=torch.uint8, device=w.device)
+            call("favae_weight_flip_split", ptr(w), ptr(wsp), co, kh, kw, ci, planes, ptr(w_amax))
+        else:
+            if w_ohwi is None:
+                w_ohwi = _flipped(flip_of)
+            n = w_ohwi.numel()
+            wsp = torch.empty(query("favae_split_weights_bytes", n, planes), dtype=torch.uint8, device=w_ohwi.device)
+            call("favae_split_weights", ptr(w_ohwi), ptr(wsp), n, planes)
+            if planes == 2:
+                w_amax = wsp[:4].view(torch.float32)          # header of the record buffer (keeps the buffer alive while saved)
         if planes == 2 and x_bound is None:
             if scale is not None:
                 raise RuntimeError("a transformed conv operand needs its range bound (gn_stats(with_bound=True))")
@@ -241,7 +255,18 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None):
         call("favae_conv_fwd_split", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
              ptr(shift), ptr(y))
     else:
+        if w_ohwi is None:
+            w_ohwi = _flipped(flip_of)
         call("favae_conv_fwd", byref(d), ptr(x), ptr(w_ohwi), ptr(b), ptr(resid), ptr(scale), ptr(shift), ptr(y))
+    return w_amax
+
+
+def _flipped(flip_of):
+    """wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci] as an fp32 tensor (convs that do not take pre-split records)"""
+    w, co, kh, kw, ci, _ = flip_of
+    wt = torch.empty((ci, kh, kw, co), dtype=torch.float32, device=w.device)
+    call("favae_weight_flip", ptr(w), ptr(wt), co, kh, kw, ci)
+    return wt
 
 
 class FusedConvFn(torch.autograd.Function):
@@ -283,7 +308,7 @@ class FusedConvFn(torch.autograd.Function):
                            per_image)
         if xb is None and query("favae_conv_wants_split_weights", byref(d), 0) == 2:
             xb = absmax(x)
-        _conv_launch(d, x, wk, b, resid, scale, shift, y, xb)
+        w_amax = _conv_launch(d, x, wk, b, resid, scale, shift, y, xb)
         ctx.cfg = cfg
         ctx.has_b = b is not None
         ctx.has_gn = gn_w is not None
@@ -292,14 +317,14 @@ class FusedConvFn(torch.autograd.Function):
         ctx.has_res = resid is not None
         ctx.w_dim = w.dim()
         ctx.params = (w, b, gn_w, gn_b)           # to reach pre-assigned flat-buffer gradients (see _direct_grad)
-        ctx.save_for_backward(x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb)
+        ctx.save_for_backward(x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb, w_amax)
         if pass_input:
             return y, x
         return y
 
     @staticmethod
     def backward(ctx, dy, dskip=None):
-        x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb = ctx.saved_tensors
+        x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb, w_amax = ctx.saved_tensors
         if dskip is not None:
             dskip = to_cl(dskip)
         cfg = ctx.cfg
@@ -365,8 +390,6 @@ class FusedConvFn(torch.autograd.Function):
         if need_x or ctx.has_gn:
             if ctx.has_gn and mean is None:
                 raise RuntimeError("gradient through a normalisation with frozen (running) statistics is not implemented")
-            wt = torch.empty((Cin, cfg.kh, cfg.kw, Cout), dtype=torch.float32, device=dev)
-            call("favae_weight_flip", ptr(wk), ptr(wt), Cout, cfg.kh, cfg.kw, Cin)
             if cfg.stride == 1:
                 Hv, Wv = (2 * Hin, 2 * Win) if cfg.upsample else (Hin, Win)
                 g2, pad2 = GATHER_PLAIN, cfg.kh - 1 - cfg.pad
@@ -377,7 +400,7 @@ class FusedConvFn(torch.autograd.Function):
                 raise RuntimeError("unsupported conv geometry for the data gradient")
             da = new_cl(N, Cin, Hv, Wv, dev)
             d2 = make_conv_desc(N, Ho, Wo, Cout, Hv, Wv, Cin, cfg.kh, cfg.kw, 1, pad2, g2, ACT_NONE, 1)
-            _conv_launch(d2, dy, wt, None, None, None, None, da, dyb)
+            _conv_launch(d2, dy, None, None, None, None, None, da, dyb, flip_of=(wk, Cout, cfg.kh, cfg.kw, Cin, w_amax))
             if late_wgrad is not None:
                 late_wgrad()
             if cfg.upsample:

@@ -95,6 +95,11 @@ int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const float* dy, 
 
 /* wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]  (weights of the data-gradient convolution) */
 int favae_weight_flip(const float* w, float* wt, int Cout, int KH, int KW, int Cin, favae_stream_t stream);
+/* the same, written directly as pre-split records for favae_conv_fwd_split (favae_split_weights_bytes(Cout*KH*KW*Cin, planes)
+ * bytes).  absmax_src: device float holding max|w| -- the first float of the forward's record buffer -- so that the data
+ * gradient needs neither a flipped fp32 copy nor a second maximum reduction (required for planes == 2).  Cout % 4 == 0. */
+int favae_weight_flip_split(const float* w, void* out, int Cout, int KH, int KW, int Cin, int planes, const float* absmax_src,
+                            favae_stream_t stream);
 
 /* out[c] (+)= sum_m a[m][c]  (bias gradient; M rows of C) ; deterministic two-stage.  `accumulate` != 0 adds to `out`
  * (gradients written straight into a pre-zeroed flat gradient buffer, as favae_conv_wgrad / favae_gn_act_bwd do). */
