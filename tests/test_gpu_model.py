@@ -336,3 +336,47 @@ def test_gan_trainstep_runs_two_iterations():
         for k in ("loss_g", "loss_disc", "loss_d", "weight_d"):
             assert torch.isfinite(torch.as_tensor(out[k])).all(), k
     assert float((model.discriminator.head.weight - w0).abs().max()) > 0
+
+
+def test_train_step_is_deterministic():
+    """Two runs of the same two training steps (fresh models, same inputs) give bit-identical parameters, codebook and losses:
+    every reduction is ordered (split-K slabs, fp64 block partials, counting-sort segment sums, order-independent maxima) and
+    the second HIP stream only changes WHEN the weight gradients are computed, not what they are."""
+    from models.vqgan_fcm import VQGANFCM
+    from favae_step import TrainStep
+    mk, ok = MODEL_KW["cfg1"]
+    cfg = O.OracleConfig(**ok)
+    state = O.det_state(cfg, with_disc=True)
+
+    def run():
+        model = VQGANFCM(**mk, device=DEV)
+        model.load_state_dict(state, strict=True)
+        model = model.to(DEV)
+        ts = TrainStep(model, lr=1e-4)
+        losses = []
+        for s in range(2):
+            out = ts.step(O.det_input(2, 128, 128, 70 + s).to(DEV))
+            losses.append(float(out["loss_g"].reshape(-1)[0]))
+        torch.cuda.synchronize()
+        return ts.pflat.clone(), model.quantizer._codebook.embed.clone(), losses
+
+    p1, e1, l1 = run()
+    p2, e2, l2 = run()
+    assert l1 == l2
+    assert torch.equal(p1, p2), f"{int((p1 != p2).sum())} parameters differ"
+    assert torch.equal(e1, e2)
+
+
+def test_zero_and_nonfinite_operands():
+    """fp16 split scheme edge cases: an all-zero operand (max = 0 -> scale 1) gives exact zeros; a NaN input propagates."""
+    from favae_hip import ops as K
+    x = torch.zeros(1, 128, 16, 16, device=DEV, requires_grad=True)
+    w = (torch.randn(128, 128, 3, 3, device=DEV) * 0.05).requires_grad_(True)
+    y = K.fused_conv(x, w, None, None, None, None, K.ConvCfg(3, 3, 1, 1))
+    assert float(y.abs().max()) == 0.0
+    gx, gw = torch.autograd.grad(y, (x, w), torch.zeros_like(y))
+    assert float(gx.abs().max()) == 0.0 and float(gw.abs().max()) == 0.0
+    xn = torch.randn(1, 128, 16, 16, device=DEV)
+    xn[0, 5, 3, 3] = float("nan")
+    yn = K.fused_conv(xn, w.detach(), None, None, None, None, K.ConvCfg(3, 3, 1, 1))
+    assert torch.isnan(yn).any()
