@@ -89,6 +89,11 @@ struct ConvArgs {
     unsigned x_bytes, w_bytes, aff_bytes;   // operand sizes for the buffer-addressed kernels
     const float* x_amax;                    // split-precision fp16 scheme: device-side bound of |transformed x| ...
     const float* w_amax;                    // ... and of |w| (header of the pre-split weight buffer)
+    // conv_fwd_sp_kernel only: separate left padding and sub-grid addressing (favae_conv_desc lat_*): pixel (n, h, w) of the
+    // input / output lives at ((n * img + h * step * row + w * step + off) * C) of its tensor (dense: step 1, row = W, off 0)
+    int pad_w;
+    int in_step, in_row, in_img, in_off;
+    int out_step, out_row, out_img, out_off;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -301,6 +306,8 @@ struct WgradArgs {
     unsigned x_bytes, aff_bytes;
     const float* x_amax;                    // split-precision fp16 scheme: device-side bounds of |transformed x| and |dy|
     const float* dy_amax;
+    int pad_w;                              // conv_wgrad_sp_kernel only: left padding, dy on a sub-grid (see ConvArgs)
+    int dy_step, dy_row, dy_img, dy_off;
 };
 
 template <int BCO, int BCI, int WAVES_O, int WAVES_I>
@@ -614,8 +621,14 @@ __global__ void upsample2x_bwd_kernel(const float* du, float* dx, int N, int H, 
 bool desc_ok(const favae_conv_desc* d) {
     return d && d->N > 0 && d->Hin > 0 && d->Win > 0 && d->Cin > 0 && d->Hout > 0 && d->Wout > 0 && d->Cout > 0 &&
            d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0 && d->gather >= 0 && d->gather <= 2 && d->act >= 0 &&
-           d->act <= 2 && (long)d->N * d->Hout * d->Wout < (1L << 31);
+           d->act <= 2 && (long)d->N * d->Hout * d->Wout < (1L << 31) &&
+           (d->lat_step == 0 || d->lat_step == 1 || (d->lat_step == 2 && (d->lat_side == 1 || d->lat_side == 2) &&
+                                                      (unsigned)d->lat_oh < 2u && (unsigned)d->lat_ow < 2u)) &&
+           d->pad + d->pad_dw >= 0 && d->w_rec_offset >= 0 && d->w_rec_offset % 16 == 0;
 }
+
+// descriptors only conv_fwd_sp_kernel / conv_wgrad_sp_kernel implement
+bool desc_special(const favae_conv_desc* d) { return d->lat_step == 2 || d->pad_dw != 0; }
 
 int wgrad_splitk(const favae_conv_desc* d, int tiles, int* chunk) {
     const long M = (long)d->N * d->Hout * d->Wout;
@@ -668,7 +681,7 @@ static bool thin_enabled() {
     return v == 1;
 }
 static int thin_kind(const favae_conv_desc* d, bool has_affine) {
-    if (!desc_ok(d) || force_generic() || !thin_enabled()) return 0;
+    if (!desc_ok(d) || force_generic() || !thin_enabled() || desc_special(d)) return 0;
     if (!(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->gather == FAVAE_GATHER_PLAIN && d->Hout == d->Hin &&
           d->Wout == d->Win))
         return 0;
@@ -806,7 +819,17 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     }
     ConvArgs a;
     a.x_amax = x_amax; a.w_amax = w;
-    a.x = x; a.w = w6 ? (const float*)((const char*)w + sp::WHDR) : w; a.bias = bias; a.resid = resid; a.scale = scale; a.shift = shift; a.y = y;
+    a.x = x; a.w = w6 ? (const float*)((const char*)w + sp::WHDR + d->w_rec_offset) : w;
+    const bool special = desc_special(d);
+    const int st = d->lat_step == 2 ? 2 : 1;
+    a.pad_w = d->pad + d->pad_dw;
+    a.in_step = 1; a.in_row = d->Win; a.in_img = d->Hin * d->Win; a.in_off = 0;
+    a.out_step = 1; a.out_row = d->Wout; a.out_img = d->Hout * d->Wout; a.out_off = 0;
+    if (st == 2 && d->lat_side == 2) {
+        a.in_step = 2; a.in_row = 2 * d->Win; a.in_img = 4 * d->Hin * d->Win; a.in_off = d->lat_oh * a.in_row + d->lat_ow;
+    } else if (st == 2) {
+        a.out_step = 2; a.out_row = 2 * d->Wout; a.out_img = 4 * d->Hout * d->Wout; a.out_off = d->lat_oh * a.out_row + d->lat_ow;
+    } a.bias = bias; a.resid = resid; a.scale = scale; a.shift = shift; a.y = y;
     a.N = d->N; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->Cin; a.Hout = d->Hout; a.Wout = d->Wout; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.gather = d->gather; a.act = d->act;
     a.aff_stride = d->affine_per_image ? d->Cin : 0;
@@ -824,11 +847,12 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         else if (bn == 64) hipLaunchKernelGGL((conv_fwd_fast_kernel<64, 2, 2, G>), grid, blk, 0, s, a);            \
         else hipLaunchKernelGGL((conv_fwd_fast_kernel<32, 4, 1, G>), grid, blk, 0, s, a);                          \
     } while (0)
-    const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, wb = (size_t)d->Cout * d->KH * d->KW * d->Cin * 4;
+    const size_t xb = (size_t)d->N * a.in_img * d->Cin * 4, wb = (size_t)d->Cout * d->KH * d->KW * d->Cin * 4;
     const size_t ab = (size_t)(d->affine_per_image ? d->N : 1) * d->Cin * 4;
     const int xf = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_LEAKY02 ? 3 : 1)) : 0;
     const bool buf_ok = !force_generic() && !force_nobuf() && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) &&
-                        (d->gather == FAVAE_GATHER_PLAIN || xf == 0);
+                        (size_t)d->N * a.out_img * d->Cout * 4 < ((size_t)1 << 32) && (d->gather == FAVAE_GATHER_PLAIN || xf == 0);
+    if (special && !(buf_ok && use_b6() && bn == 128 && w6 && d->gather == FAVAE_GATHER_PLAIN)) return FAVAE_ERR_UNSUPPORTED;
     a.x_bytes = (unsigned)xb; a.aff_bytes = (unsigned)ab;
     a.w_bytes = (unsigned)(wplanes == 3 ? wb / 16 * sp::Scheme<3>::WREC : (wplanes == 2 ? wb / 16 * sp::Scheme<2>::WREC : wb));
 #define FAVAE_LAUNCH_BUF(G, X)                                                                                     \
@@ -837,7 +861,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         else if (bn == 64) hipLaunchKernelGGL((conv_fwd_buf_kernel<64, 2, 2, G, X>), grid, blk, 0, s, a);          \
         else hipLaunchKernelGGL((conv_fwd_buf_kernel<32, 4, 1, G, X>), grid, blk, 0, s, a);                        \
     } while (0)
-    const bool halo_ok = buf_ok && use_b6() && w6 && use_halo() && bn == 128 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
+    const bool halo_ok = !special && buf_ok && use_b6() && w6 && use_halo() && bn == 128 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
                          d->pad == 1 && d->gather == FAVAE_GATHER_PLAIN && d->Hout == d->Hin && d->Wout == d->Win &&
                          d->Hin % 8 == 0 && d->Win % 16 == 0;
     if (halo_ok) {
@@ -954,6 +978,13 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     WgradArgs a;
     a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.part = (float*)ws;
     a.x_amax = x_absmax; a.dy_amax = dy_absmax;
+    const bool special = desc_special(d);
+    a.pad_w = d->pad + d->pad_dw;
+    a.dy_step = 1; a.dy_row = d->Wout; a.dy_img = d->Hout * d->Wout; a.dy_off = 0;
+    if (d->lat_step == 2) {
+        if (d->lat_side != 1) return FAVAE_ERR_UNSUPPORTED;          // weight gradients: only the conv OUTPUT may be a sub-grid
+        a.dy_step = 2; a.dy_row = 2 * d->Wout; a.dy_img = 4 * d->Hout * d->Wout; a.dy_off = d->lat_oh * a.dy_row + d->lat_ow;
+    }
     a.N = d->N; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->Cin; a.Hout = d->Hout; a.Wout = d->Wout; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.gather = d->gather; a.act = d->act;
     a.aff_stride = d->affine_per_image ? d->Cin : 0;
@@ -980,13 +1011,16 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     const bool buf_ok = !force_generic() && !force_nobuf() && a.vec_i && a.vec_o && (d->gather == FAVAE_GATHER_PLAIN || ups_b6) &&
                         d->stride == 1 && d->Wout % 16 == 0 && xb < (1u << 31) && yb < (1u << 31) && xf != 3;
     a.x_bytes = (unsigned)xb; a.aff_bytes = (unsigned)ab;
+    if (special && !(buf_ok && use_b6() && bco == 128 && bci == 128 && d->gather == FAVAE_GATHER_PLAIN &&
+                     (size_t)d->N * a.dy_img * d->Cout * 4 < ((size_t)1 << 32)))
+        return FAVAE_ERR_UNSUPPORTED;
 #define FAVAE_LAUNCH_WBUF(X)                                                                                       \
     do {                                                                                                           \
         if (bco == 128 && bci == 128) hipLaunchKernelGGL((conv_wgrad_buf_kernel<128, 128, 2, 2, X>), grid, dim3(256), 0, s, a); \
         else if (bco == 32) hipLaunchKernelGGL((conv_wgrad_buf_kernel<32, 128, 1, 4, X>), grid, dim3(256), 0, s, a);            \
         else hipLaunchKernelGGL((conv_wgrad_buf_kernel<128, 32, 4, 1, X>), grid, dim3(256), 0, s, a);                           \
     } while (0)
-    const bool row3 = buf_ok && use_b6() && use_row3() && bco == 128 && bci == 128 && d->gather == FAVAE_GATHER_PLAIN &&
+    const bool row3 = !special && buf_ok && use_b6() && use_row3() && bco == 128 && bci == 128 && d->gather == FAVAE_GATHER_PLAIN &&
                       d->KH == 3 && d->KW == 3 && d->pad == 1;
     if (row3) {
         // three taps per workgroup: grid.x = tiles * 3 filter rows; split-K sized for the smaller grid
@@ -1035,6 +1069,86 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, dw, n, a.splitk, accumulate);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
+}
+
+namespace {
+// Upsample phase weights (include/favae_hip.h): tap sets of the 3x3 kernel that land on the same low-resolution pixel
+__device__ __forceinline__ void phase_taps(int par, int a, int& k0, int& k1) {      // taps k0..k1 (inclusive)
+    if (par == 0) { k0 = a == 0 ? 0 : 1; k1 = a == 0 ? 0 : 2; }
+    else { k0 = a == 0 ? 0 : 2; k1 = a == 0 ? 1 : 2; }
+}
+__global__ __launch_bounds__(256) void upsample_weights_kernel(const float* __restrict__ w, float* __restrict__ weff, int Cout,
+                                                               int Cin) {
+    const size_t n = (size_t)4 * Cout * 4 * Cin;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int ci = (int)(i % Cin);
+        size_t t = i / Cin;
+        const int b = (int)(t & 1), a = (int)((t >> 1) & 1);
+        t >>= 2;
+        const int co = (int)(t % Cout), ph = (int)(t / Cout);
+        int h0, h1, w0, w1;
+        phase_taps(ph >> 1, a, h0, h1);
+        phase_taps(ph & 1, b, w0, w1);
+        float s = 0.f;
+        for (int kh = h0; kh <= h1; ++kh)
+            for (int kw = w0; kw <= w1; ++kw) s += w[(((size_t)co * 3 + kh) * 3 + kw) * Cin + ci];
+        weff[i] = s;
+    }
+}
+__global__ __launch_bounds__(256) void upsample_wgrad_fold_kernel(const float* __restrict__ dweff, float* __restrict__ dw, int Cout,
+                                                                  int Cin, int accumulate) {
+    const size_t n = (size_t)Cout * 9 * Cin;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int ci = (int)(i % Cin);
+        size_t t = i / Cin;
+        const int kw = (int)(t % 3), kh = (int)((t / 3) % 3), co = (int)(t / 9);
+        float s = 0.f;
+        for (int py = 0; py < 2; ++py)
+            for (int a = 0; a < 2; ++a) {
+                int h0, h1;
+                phase_taps(py, a, h0, h1);
+                if (kh < h0 || kh > h1) continue;
+                for (int px = 0; px < 2; ++px)
+                    for (int b = 0; b < 2; ++b) {
+                        int w0, w1;
+                        phase_taps(px, b, w0, w1);
+                        if (kw < w0 || kw > w1) continue;
+                        s += dweff[((((size_t)(py * 2 + px) * Cout + co) * 2 + a) * 2 + b) * Cin + ci];
+                    }
+            }
+        dw[i] = accumulate ? dw[i] + s : s;
+    }
+}
+}  // namespace
+
+extern "C" int favae_upsample_weights(const float* w, float* weff, int Cout, int Cin, favae_stream_t stream) {
+    FAVAE_REQUIRE(w && weff && Cout > 0 && Cin > 0);
+    const size_t n = (size_t)16 * Cout * Cin;
+    hipLaunchKernelGGL(upsample_weights_kernel, dim3((unsigned)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256))), dim3(256), 0,
+                       (hipStream_t)stream, w, weff, Cout, Cin);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_upsample_wgrad_fold(const float* dweff, float* dw, int Cout, int Cin, int accumulate, favae_stream_t stream) {
+    FAVAE_REQUIRE(dweff && dw && Cout > 0 && Cin > 0);
+    const size_t n = (size_t)9 * Cout * Cin;
+    hipLaunchKernelGGL(upsample_wgrad_fold_kernel, dim3((unsigned)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256))), dim3(256), 0,
+                       (hipStream_t)stream, dweff, dw, Cout, Cin, accumulate);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+extern "C" int favae_conv_subpixel_ok(int N, int H, int W, int Cin, int Cout) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("FAVAE_CONV_SUBPIXEL"); off = (e && e[0] == '0') ? 1 : 0; }
+    if (off || N <= 0 || H <= 0 || W <= 0) return 0;
+    favae_conv_desc d{};
+    d.N = N; d.Hin = H; d.Win = W; d.Cin = Cin; d.Hout = H; d.Wout = W; d.Cout = Cout; d.KH = 2; d.KW = 2; d.stride = 1; d.pad = 1;
+    d.lat_step = 2; d.lat_side = 1;
+    // forward / data-gradient phases (im2col split kernel) and the per-tap split weight gradient (128 x 128 tiles, W % 16 == 0)
+    return sp_fwd_eligible(&d, false) && Cout % 16 == 0 && Cin > 64 && W % 16 == 0 && Cin % 4 == 0 && Cout % 4 == 0 &&
+           (size_t)N * 4 * H * W * (Cout > Cin ? Cout : Cin) * 4 < ((size_t)1 << 31);
 }
 
 namespace {

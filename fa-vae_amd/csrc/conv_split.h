@@ -184,8 +184,10 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_sp_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             int sh, sw;
-            const bool ok = r_ok[j] && gather_src_t<GATHER>(a.stride, a.pad, a.Hin, a.Win, r_oh[j], r_ow[j], kh, kw, sh, sw);
-            voa[j] = ok ? (unsigned)((((r_n[j] * a.Hin + sh) * a.Win + sw) * a.Cin + c4) * 4) : FAVAE_OOB;
+            // separate left padding: shift the column by the difference (pad_w == pad for every ordinary conv)
+            const bool ok = r_ok[j] && gather_src_t<GATHER>(a.stride, a.pad, a.Hin, a.Win, r_oh[j], r_ow[j], kh, kw + (a.pad - a.pad_w), sh, sw);
+            voa[j] = ok ? (unsigned)(((r_n[j] * a.in_img + sh * a.in_step * a.in_row + sw * a.in_step + a.in_off) * a.Cin + c4) * 4)
+                        : FAVAE_OOB;
             if (XFORM) vos[j] = ok ? (unsigned)((r_n[j] * a.aff_stride + c4) * 4) : FAVAE_OOB;
         }
     };
@@ -275,7 +277,13 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_sp_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < a.M) {
-                    const size_t o = (size_t)row * a.Cout + col;
+                    size_t o = (size_t)row * a.Cout + col;
+                    if (a.out_step != 1) {                      // output on a sub-grid of a larger tensor
+                        const int hw = a.Hout * a.Wout;
+                        const int on = row / hw, rr = row - on * hw;
+                        const int oh = rr / a.Wout, ow = rr - oh * a.Wout;
+                        o = ((size_t)on * a.out_img + (size_t)oh * a.out_step * a.out_row + ow * a.out_step + a.out_off) * a.Cout + col;
+                    }
                     float v = acc[i][j][r];
                     if constexpr (NP == 2) v = v * un_a * un_w;
                     v += bv;
@@ -320,7 +328,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_sp_kernel(WgradArgs a) {
     const float So = NP == 2 ? sp::pow2_scale(a.dy_amax) : 1.f, Si = NP == 2 ? sp::pow2_scale(a.x_amax) : 1.f;
 
     const auto rx = make_rsrc(a.x, a.x_bytes);
-    const auto rdy = make_rsrc(a.dy, (unsigned)p_end * (unsigned)a.Cout * 4u);
+    // dense dy: rows >= p_end read as zeros through the descriptor's range check; dy on a sub-grid (a.dy_step == 2, dispatcher
+    // guarantees whole 16-pixel steps): the range is the whole tensor
+    const auto rdy = make_rsrc(a.dy, a.dy_step == 1 ? (unsigned)p_end * (unsigned)a.Cout * 4u
+                                                    : (unsigned)a.N * (unsigned)a.dy_img * (unsigned)a.Cout * 4u);
     const auto rsc_d = make_rsrc(XFORM ? a.scale : a.x, XFORM ? a.aff_bytes : 0u);
     const auto rsh_d = make_rsrc(XFORM ? a.shift : a.x, XFORM ? a.aff_bytes : 0u);
 
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_sp_kernel(WgradArgs a) {
         s_c[j] = (i & 31) * 4;
         o_ok[j] = co0 + s_c[j] < a.Cout;
         i_ok[j] = ci0 + s_c[j] < a.Cin;
-        voo[j] = o_ok[j] ? (unsigned)((s_p[j] * a.Cout + co0 + s_c[j]) * 4) : FAVAE_OOB;
+        voo[j] = o_ok[j] ? (unsigned)((s_p[j] * a.dy_step * a.Cout + co0 + s_c[j]) * 4) : FAVAE_OOB;
         vos[j] = (unsigned)((ci0 + s_c[j]) * 4);
     }
     int s_n, s_oh, s_ow;
@@ -351,7 +362,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_sp_kernel(WgradArgs a) {
 
     float4 ro[2], ri[2], rsc[2], rsh[2];
     auto load_tiles = [&]() {
-        const unsigned so = (unsigned)ld_pb * (unsigned)a.Cout * 4u;
+        const unsigned so = a.dy_step == 1
+                                ? (unsigned)ld_pb * (unsigned)a.Cout * 4u
+                                : (unsigned)(s_n * a.dy_img + s_oh * a.dy_step * a.dy_row + s_ow * a.dy_step + a.dy_off) * (unsigned)a.Cout * 4u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) ro[j] = bload(rdy, voo[j], so);
         const int vh = s_oh + kh - a.pad;
@@ -361,7 +374,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_sp_kernel(WgradArgs a) {
         const unsigned ss = (unsigned)(s_n * a.aff_stride) * 4u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int vw = s_ow + s_p[j] + kw - a.pad;
+            const int vw = s_ow + s_p[j] + kw - a.pad_w;
             const int iw = UPS ? vw >> 1 : vw;
             const bool ok = row_ok && i_ok[j] && (unsigned)vw < (unsigned)(UPS ? 2 * a.Win : a.Win) && ld_pb + s_p[j] < p_end;
             const unsigned vx = ok ? (unsigned)((iw * a.Cin + ci0 + s_c[j]) * 4) : FAVAE_OOB;

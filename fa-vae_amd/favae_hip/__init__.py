@@ -24,7 +24,8 @@ _ERR = {1: "bad argument", 2: "kernel launch failed", 3: "unsupported shape", 4:
 
 class ConvDesc(Structure):
     _fields_ = [(n, c_int32) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "KH", "KW", "stride", "pad",
-                                       "gather", "act", "affine_per_image")]
+                                       "gather", "act", "affine_per_image", "lat_step", "lat_side", "lat_oh", "lat_ow",
+                                       "pad_dw", "w_rec_offset")]
 
 
 # name -> (restype, argtypes); mirrors include/favae_hip.h one to one (tests/test_abi.py checks the symbol list)
@@ -41,6 +42,9 @@ SIGNATURES = {
     "favae_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _S]),
     "favae_weight_flip": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     "favae_weight_flip_split": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _S]),
+    "favae_upsample_weights": (c_int, [_P, _P, c_int, c_int, _S]),
+    "favae_upsample_wgrad_fold": (c_int, [_P, _P, c_int, c_int, c_int, _S]),
+    "favae_conv_subpixel_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "favae_colsum_workspace": (c_size_t, [c_int64, c_int]),
     "favae_colsum": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, c_size_t, _S]),
     "favae_upsample2x_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
@@ -145,5 +149,6 @@ def workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
 
 
 def make_conv_desc(N, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, gather=GATHER_PLAIN, act=ACT_NONE,
-                   affine_per_image=1):
-    return ConvDesc(N, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, gather, act, affine_per_image)
+                   affine_per_image=1, lattice=(0, 0, 0, 0), pad_dw=0, w_rec_offset=0):
+    return ConvDesc(N, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, gather, act, affine_per_image, lattice[0], lattice[1],
+                    lattice[2], lattice[3], pad_dw, w_rec_offset)

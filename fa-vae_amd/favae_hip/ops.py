@@ -432,7 +432,113 @@ class FusedConvFn(torch.autograd.Function):
         return dx, dw, db, dgw, dgb, dres, None, None, None
 
 
+def _phase_desc(N, H, W, Cin, Cout, ph, rec_off=0, dgrad=False):
+    """One of the four phase convs of an Upsample (include/favae_hip.h, favae_conv_desc.lat_*): output parity (py, px)."""
+    py, px = ph >> 1, ph & 1
+    if not dgrad:      # forward / weight gradient: dense low-resolution x -> every second pixel of y (offset py, px)
+        return make_conv_desc(N, H, W, Cin, H, W, Cout, 2, 2, 1, 1 - py, GATHER_PLAIN, ACT_NONE, 1, lattice=(2, 1, py, px),
+                              pad_dw=py - px, w_rec_offset=rec_off)
+    # data gradient: every second pixel of dy (Cout channels) -> dense dx (Cin channels), flipped 2x2 weights
+    return make_conv_desc(N, H, W, Cout, H, W, Cin, 2, 2, 1, py, GATHER_PLAIN, ACT_NONE, 1, lattice=(2, 2, py, px), pad_dw=px - py)
+
+
+class UpsampleConvFn(torch.autograd.Function):
+    """y = conv3x3(nearest_x2(x), w) + b  (Upsample, models/codec.py:11-18) as four phase-wise 2x2 convolutions of the
+    low-resolution input with summed weights: 16 instead of 36 multiply-adds per low-resolution pixel in the forward pass, the
+    data gradient (which lands directly on the low-resolution grid: no 2x2 gather of a full-resolution gradient) and the
+    weight gradient.  The weights are summed in fp32 before the products instead of after: rounding-level differences only."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = to_cl(x)
+        N, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        dev = x.device
+        wk = weight_ohwi(w)
+        weff = torch.empty((16 * Cout * Cin,), dtype=torch.float32, device=dev)
+        call("favae_upsample_weights", ptr(wk), ptr(weff), Cout, Cin)
+        planes = query("favae_conv_wants_split_weights", byref(_phase_desc(N, H, W, Cin, Cout, 0)), 0)
+        wsp = torch.empty(query("favae_split_weights_bytes", weff.numel(), planes), dtype=torch.uint8, device=dev)
+        call("favae_split_weights", ptr(weff), ptr(wsp), weff.numel(), planes)
+        rec = (Cout * 4 * Cin // 4) * (16 if planes == 2 else 24)
+        xb = absmax(x) if planes == 2 else None
+        y = new_cl(N, Cout, 2 * H, 2 * W, dev)
+        for ph in range(4):
+            call("favae_conv_fwd_split", byref(_phase_desc(N, H, W, Cin, Cout, ph, ph * rec)), ptr(x), ptr(wsp), planes, ptr(xb),
+                 ptr(b), None, None, None, ptr(y))
+        ctx.planes, ctx.has_b, ctx.params = planes, b is not None, (w, b)
+        ctx.save_for_backward(x, weff, xb, wsp[:4].view(torch.float32) if planes == 2 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weff, xb, w_amax = ctx.saved_tensors
+        dy = to_cl(dy)
+        N, Cin, H, W = x.shape
+        Cout = dy.shape[1]
+        dev = x.device
+        planes = ctx.planes
+        p_w, p_b = ctx.params
+        dx = dw = db = None
+        dyb = torch.empty((1,), dtype=torch.float32, device=dev) if planes == 2 else None
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            M = N * 4 * H * W
+            ws = workspace(query("favae_colsum_workspace", M, Cout), dev)
+            tgt = _direct_grad(p_b)
+            if tgt is None:
+                db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+            call("favae_colsum", ptr(dy), ptr(db if tgt is None else tgt), M, Cout, 0 if tgt is None else 1, ptr(dyb), ptr(ws),
+                 ws.numel())
+        elif dyb is not None:
+            call("favae_absmax", ptr(dy), dy.numel(), ptr(dyb))
+        late = None
+        if ctx.needs_input_grad[1]:
+            tgt = _direct_grad(p_w)
+            dweff = torch.empty((16 * Cout * Cin,), dtype=torch.float32, device=dev)
+            d0 = _phase_desc(N, H, W, Cin, Cout, 0)
+            wss = workspace(query("favae_conv_wgrad_workspace", byref(d0)), dev)
+            dwk = None if tgt is not None else torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=dev)
+
+            def wgrad():
+                for ph in range(4):
+                    call("favae_conv_wgrad", byref(_phase_desc(N, H, W, Cin, Cout, ph)), ptr(x), ptr(dy), None, None, ptr(xb),
+                         ptr(dyb), dweff.data_ptr() + ph * 4 * Cout * 4 * Cin, 0, ptr(wss), wss.numel())
+                call("favae_upsample_wgrad_fold", ptr(dweff), ptr(tgt if tgt is not None else dwk), Cout, Cin,
+                     1 if tgt is not None else 0)
+            if tgt is not None and _SIDE["on"]:
+                def late():
+                    side = _side_stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        wgrad()
+                    for t in (x, dy, xb, dyb, wss, dweff):
+                        if t is not None:
+                            t.record_stream(side)
+                    if not _SIDE["used"]:
+                        _SIDE["used"] = True
+                        torch.autograd.Variable._execution_engine.queue_callback(sync_side_stream)
+            else:
+                wgrad()
+                if dwk is not None:
+                    dw = dwk.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[0]:
+            dx = new_cl(N, Cin, H, W, dev)
+            nph = Cout * 4 * Cin
+            for ph in range(4):
+                wfl = torch.empty(query("favae_split_weights_bytes", nph, planes), dtype=torch.uint8, device=dev)
+                call("favae_weight_flip_split", weff.data_ptr() + ph * nph * 4, ptr(wfl), Cout, 2, 2, Cin, planes, ptr(w_amax))
+                call("favae_conv_fwd_split", byref(_phase_desc(N, H, W, Cin, Cout, ph, dgrad=True)), ptr(dy), ptr(wfl), planes,
+                     ptr(dyb), None, ptr(dx) if ph else None, None, None, ptr(dx))
+        if late is not None:
+            late()
+        return dx, dw, db
+
+
 def fused_conv(x, w, b=None, gn_w=None, gn_b=None, resid=None, cfg=None, pass_input=False, stats=None):
+    if (cfg.upsample and gn_w is None and resid is None and not pass_input and cfg.kh == 3 and cfg.kw == 3 and cfg.stride == 1
+            and cfg.pad == 1 and w.dim() == 4
+            and query("favae_conv_subpixel_ok", x.shape[0], x.shape[2], x.shape[3], x.shape[1], w.shape[0])):
+        return UpsampleConvFn.apply(x, w, b)
     return FusedConvFn.apply(x, w, b, gn_w, gn_b, resid, cfg, pass_input, stats)
 
 

@@ -54,6 +54,14 @@ typedef struct {
                                        (transposed conv = data gradient of a stride-2 conv) */
     int32_t act;                    /* activation applied after the affine input transform: 0 none | 1 SiLU | 2 LeakyReLU(0.2) */
     int32_t affine_per_image;       /* 1: scale/shift are [N][Cin] (GroupNorm); 0: [Cin] shared by the batch (BatchNorm) */
+    /* Sub-grid addressing for the phase decomposition of the Upsample convs (all zero = an ordinary conv).  nearest x2 followed
+     * by a 3x3 conv equals, for each output parity (py,px), a 2x2 conv of the low-resolution input with summed weights
+     * (favae_upsample_weights): 16 instead of 36 multiply-adds per low-resolution pixel.  lat_step = 2 puts ONE side of the
+     * conv on every second pixel (offset lat_oh, lat_ow) of a tensor of twice the stated height/width: lat_side = 1 the output
+     * (also resid, and dy in favae_conv_wgrad), lat_side = 2 the input.  Only the split-precision kernels implement it. */
+    int32_t lat_step, lat_side, lat_oh, lat_ow;
+    int32_t pad_dw;                 /* left zero padding = pad + pad_dw (top padding = pad) */
+    int32_t w_rec_offset;           /* favae_conv_fwd_split: byte offset of this conv's records behind the header of wsplit */
 } favae_conv_desc;
 
 #define FAVAE_GATHER_PLAIN 0
@@ -100,6 +108,14 @@ int favae_weight_flip(const float* w, float* wt, int Cout, int KH, int KW, int C
  * gradient needs neither a flipped fp32 copy nor a second maximum reduction (required for planes == 2).  Cout % 4 == 0. */
 int favae_weight_flip_split(const float* w, void* out, int Cout, int KH, int KW, int Cin, int planes, const float* absmax_src,
                             favae_stream_t stream);
+
+/* Upsample (nearest x2 + 3x3 conv, models/codec.py:11-18) as four phase convs: weff[py*2+px][co][a][b][ci] (a,b in {0,1}) =
+ * sum of the w[co][kh][kw][ci] whose tap lands on the same low-resolution pixel (rows: py=0: {0},{1,2}; py=1: {0,1},{2}).
+ * favae_upsample_wgrad_fold is the adjoint: dw[co][kh][kw][ci] (+)= sum of the dweff entries that contain that tap. */
+int favae_upsample_weights(const float* w, float* weff, int Cout, int Cin, favae_stream_t stream);
+int favae_upsample_wgrad_fold(const float* dweff, float* dw, int Cout, int Cin, int accumulate, favae_stream_t stream);
+/* 1 if the four phase convs of an Upsample with these sizes run on the split-precision kernels (else use gather = 1) */
+int favae_conv_subpixel_ok(int N, int H, int W, int Cin, int Cout);
 
 /* out[c] (+)= sum_m a[m][c]  (bias gradient; M rows of C) ; deterministic two-stage.  `accumulate` != 0 adds to `out`
  * (gradients written straight into a pre-zeroed flat gradient buffer, as favae_conv_wgrad / favae_gn_act_bwd do). */

@@ -62,6 +62,10 @@ CONV_CASES = [
     (2, 128, 10, 12, 128, 3, 2, 0, 1, False, None, False),     # Downsample at 128 ch: implicit-GEMM split kernel, dilated dgrad
     (2, 128, 8, 8, 128, 3, 1, 1, 1, True, None, False),        # Upsample at 128 ch: upsample gather fwd + wgrad
     (2, 128, 6, 10, 384, 1, 1, 0, 0, False, 32, False),        # 1x1 with GN+SiLU, 3 Cout tiles
+    # Upsample as four phase-wise 2x2 convs (W % 16 == 0, >= 128 channels); the W = 8 case above keeps the gather kernel
+    (2, 128, 8, 16, 128, 3, 1, 1, 1, True, None, False),
+    (1, 256, 16, 16, 128, 3, 1, 1, 1, True, None, False),
+    (1, 128, 5, 32, 256, 3, 1, 1, 1, True, None, False),
     # thin-channel kernels (RGB ends of the codec): ragged rows, 64-wide, residual, plain thin output
     (1, 3, 5, 19, 128, 3, 1, 1, 1, False, None, True),
     (2, 3, 33, 70, 64, 3, 1, 1, 1, False, None, False),
