@@ -1202,6 +1202,62 @@ extern "C" int favae_weight_flip_split(const float* w, void* out, int Cout, int 
     return FAVAE_OK;
 }
 
+namespace {
+// Data gradient of the stride-2 Downsample conv (3x3, zero padding on the bottom/right only: y[o] = sum_k x[2o + k] w[k]) by
+// output parity instead of a x2 zero-dilated input: dx[2u] = dy[u] w[0] + dy[u-1] w[2], dx[2u+1] = dy[u] w[1] per axis, i.e.
+// four convs over dy with 2x2 / 2x1 / 1x2 / 1x1 kernels -- 9 instead of 36 taps per 2x2 block of dx.  This kernel writes the
+// four weight sets as pre-split records, one after the other: wph[ci][a][b][co] = w[co][kh(py,a)][kw(px,b)][ci] with
+// kh(even,0) = 2, kh(even,1) = 0, kh(odd,0) = 1.  One thread per record (4 consecutive co).
+template <int NP>
+__global__ __launch_bounds__(256) void downsample_dgrad_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
+                                                                       int Cout, int Cin, const float* __restrict__ amax_src) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(out)[0] = amax_src ? amax_src[0] : 0.f;
+    const float Sw = (NP == 2 && amax_src) ? sp::pow2_scale(amax_src) : 1.f;
+    const size_t q = Cout / 4, per_tap = (size_t)Cin * q;          // records per (phase tap)
+    const size_t total = 9 * per_tap;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        // phase order and sizes: (even,even) 2x2 | (even,odd) 2x1 | (odd,even) 1x2 | (odd,odd) 1x1 ; record layout [ci][a][b][co/4]
+        size_t r = i;
+        int ph = 0, kh_n = 2, kw_n = 2;
+        const size_t sz[4] = {4 * per_tap, 2 * per_tap, 2 * per_tap, per_tap};
+        while (r >= sz[ph]) { r -= sz[ph]; ++ph; }
+        kh_n = ph < 2 ? 2 : 1;
+        kw_n = (ph & 1) ? 1 : 2;
+        const int cq = (int)(r % q);
+        size_t t = r / q;
+        const int b = (int)(t % kw_n); t /= kw_n;
+        const int a = (int)(t % kh_n);
+        const int ci = (int)(t / kh_n);
+        const int kh = kh_n == 2 ? (a == 0 ? 2 : 0) : 1;
+        const int kw = kw_n == 2 ? (b == 0 ? 2 : 0) : 1;
+        const float* src = w + (((size_t)(4 * cq) * 3 + kh) * 3 + kw) * Cin + ci;
+        const size_t cs = (size_t)9 * Cin;                      // stride between output channels of w
+        const float4 v = make_float4(src[0], src[cs], src[2 * cs], src[3 * cs]);
+        uint2 p[NP];
+        sp::Scheme<NP>::split4(v, Sw, p);
+        unsigned* o = reinterpret_cast<unsigned*>(out + sp::WHDR) + i * (2 * NP);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { o[2 * k] = p[k].x; o[2 * k + 1] = p[k].y; }
+    }
+}
+}  // namespace
+
+extern "C" int favae_downsample_dgrad_weights(const float* w, void* out, int Cout, int Cin, int planes, const float* absmax_src,
+                                              favae_stream_t stream) {
+    FAVAE_REQUIRE(w && out && Cout > 0 && Cin > 0 && Cout % 4 == 0 && (planes == 3 || (planes == 2 && absmax_src)));
+    FAVAE_REQUIRE((((uintptr_t)out) & 15) == 0);
+    const size_t total = (size_t)9 * Cin * (Cout / 4);
+    const unsigned blocks = (unsigned)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
+    if (planes == 2)
+        hipLaunchKernelGGL((downsample_dgrad_weights_kernel<2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
+                           Cout, Cin, absmax_src);
+    else
+        hipLaunchKernelGGL((downsample_dgrad_weights_kernel<3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
+                           Cout, Cin, absmax_src);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
 extern "C" int favae_weight_flip(const float* w, float* wt, int Cout, int KH, int KW, int Cin, favae_stream_t stream) {
     FAVAE_REQUIRE(w && wt && Cout > 0 && KH > 0 && KW > 0 && Cin > 0);
     dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), KH * KW);

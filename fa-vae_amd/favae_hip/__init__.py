@@ -42,6 +42,7 @@ SIGNATURES = {
     "favae_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _S]),
     "favae_weight_flip": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     "favae_weight_flip_split": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _S]),
+    "favae_downsample_dgrad_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P, _S]),
     "favae_upsample_weights": (c_int, [_P, _P, c_int, c_int, _S]),
     "favae_upsample_wgrad_fold": (c_int, [_P, _P, c_int, c_int, c_int, _S]),
     "favae_conv_subpixel_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),

@@ -154,6 +154,7 @@ def absmax(t):
 
 
 _DIRECT_GRAD = True
+_SUBPIXEL_DGRAD = os.environ.get("FAVAE_SUBPIXEL_DGRAD", "1") != "0"     # Downsample data gradient by output parity (A/B switch)
 
 # ---- second HIP stream for the weight gradients ----------------------------------------------------------------------------
 # In a conv's backward the weight gradient (matrix-pipe bound, accumulated straight into the flat gradient buffer) is
@@ -390,7 +391,31 @@ class FusedConvFn(torch.autograd.Function):
         if need_x or ctx.has_gn:
             if ctx.has_gn and mean is None:
                 raise RuntimeError("gradient through a normalisation with frozen (running) statistics is not implemented")
-            if cfg.stride == 1:
+            phased = None
+            if (cfg.stride == 2 and not cfg.upsample and cfg.kh == 3 and cfg.kw == 3 and cfg.pad == 0 and cfg.pad_br == 1
+                    and Hin % 2 == 0 and Win % 2 == 0 and Cout % 16 == 0 and _SUBPIXEL_DGRAD):
+                # Downsample: data gradient by output parity (favae_downsample_dgrad_weights) instead of a zero-dilated input
+                d00 = make_conv_desc(N, Ho, Wo, Cout, Ho, Wo, Cin, 2, 2, 1, 1, GATHER_PLAIN, ACT_NONE, 1, lattice=(2, 1, 0, 0))
+                planes = query("favae_conv_wants_split_weights", byref(d00), 0)
+                if planes == 3 or (planes == 2 and w_amax is not None):
+                    phased = planes
+            if phased:
+                planes = phased
+                da = new_cl(N, Cin, Hin, Win, dev)
+                wph = torch.empty(query("favae_split_weights_bytes", 9 * Cin * Cout, planes), dtype=torch.uint8, device=dev)
+                call("favae_downsample_dgrad_weights", ptr(wk), ptr(wph), Cout, Cin, planes, ptr(w_amax))
+                rec = (Cin * Cout // 4) * (16 if planes == 2 else 24)
+                if planes == 2 and dyb is None:
+                    dyb = absmax(dy)
+                for ph, (khn, kwn, off) in enumerate(((2, 2, 0), (2, 1, 4), (1, 2, 6), (1, 1, 8))):
+                    ph_pad, pw_pad = khn - 1, kwn - 1
+                    dph = make_conv_desc(N, Ho, Wo, Cout, Ho, Wo, Cin, khn, kwn, 1, ph_pad, GATHER_PLAIN, ACT_NONE, 1,
+                                         lattice=(2, 1, ph >> 1, ph & 1), pad_dw=pw_pad - ph_pad, w_rec_offset=off * rec)
+                    call("favae_conv_fwd_split", byref(dph), ptr(dy), ptr(wph), planes, ptr(dyb), None, None, None, None, ptr(da))
+                if late_wgrad is not None:
+                    late_wgrad()
+                    late_wgrad = None
+            elif cfg.stride == 1:
                 Hv, Wv = (2 * Hin, 2 * Win) if cfg.upsample else (Hin, Win)
                 g2, pad2 = GATHER_PLAIN, cfg.kh - 1 - cfg.pad
             elif cfg.stride == 2 and not cfg.upsample:
@@ -398,9 +423,10 @@ class FusedConvFn(torch.autograd.Function):
                 g2, pad2 = GATHER_DILATE2, cfg.kh - 1 - cfg.pad
             else:
                 raise RuntimeError("unsupported conv geometry for the data gradient")
-            da = new_cl(N, Cin, Hv, Wv, dev)
-            d2 = make_conv_desc(N, Ho, Wo, Cout, Hv, Wv, Cin, cfg.kh, cfg.kw, 1, pad2, g2, ACT_NONE, 1)
-            _conv_launch(d2, dy, None, None, None, None, None, da, dyb, flip_of=(wk, Cout, cfg.kh, cfg.kw, Cin, w_amax))
+            if not phased:
+                da = new_cl(N, Cin, Hv, Wv, dev)
+                d2 = make_conv_desc(N, Ho, Wo, Cout, Hv, Wv, Cin, cfg.kh, cfg.kw, 1, pad2, g2, ACT_NONE, 1)
+                _conv_launch(d2, dy, None, None, None, None, None, da, dyb, flip_of=(wk, Cout, cfg.kh, cfg.kw, Cin, w_amax))
             if late_wgrad is not None:
                 late_wgrad()
             if cfg.upsample:

@@ -109,6 +109,14 @@ int favae_weight_flip(const float* w, float* wt, int Cout, int KH, int KW, int C
 int favae_weight_flip_split(const float* w, void* out, int Cout, int KH, int KW, int Cin, int planes, const float* absmax_src,
                             favae_stream_t stream);
 
+/* Data gradient of the Downsample conv (3x3, stride 2, padding bottom/right only, models/codec.py:21-31) by output parity:
+ * dx[2u] = dy[u] w[0] + dy[u-1] w[2], dx[2u+1] = dy[u] w[1] along each axis -> four convs over dy with 2x2, 2x1, 1x2 and 1x1
+ * kernels whose outputs interleave (favae_conv_desc.lat_side = 1), 9 instead of 36 taps per 2x2 block of dx.  Writes the four
+ * weight sets [Cin][a][b][Cout] as pre-split records one after the other behind one header (record offsets: 0, 4, 6, 8 times
+ * Cin*Cout/4 records); out: favae_split_weights_bytes(9*Cin*Cout, planes) bytes; absmax_src as in favae_weight_flip_split. */
+int favae_downsample_dgrad_weights(const float* w, void* out, int Cout, int Cin, int planes, const float* absmax_src,
+                                   favae_stream_t stream);
+
 /* Upsample (nearest x2 + 3x3 conv, models/codec.py:11-18) as four phase convs: weff[py*2+px][co][a][b][ci] (a,b in {0,1}) =
  * sum of the w[co][kh][kw][ci] whose tap lands on the same low-resolution pixel (rows: py=0: {0},{1,2}; py=1: {0,1},{2}).
  * favae_upsample_wgrad_fold is the adjoint: dw[co][kh][kw][ci] (+)= sum of the dweff entries that contain that tap. */
