@@ -59,7 +59,9 @@ CONV_CASES = [
     (2, 128, 16, 32, 128, 3, 1, 1, 1, False, 32, True),        # halo fwd (GN+SiLU) + halo dgrad + row3 wgrad + residual
     (1, 128, 24, 16, 256, 3, 1, 1, 1, False, None, False),     # halo, plain operand (range from favae_absmax), 2 Cout tiles
     (1, 144, 8, 16, 160, 3, 1, 1, 1, False, 16, False),        # halo with ragged channel tiles
-    (2, 128, 10, 12, 128, 3, 2, 0, 1, False, None, False),     # Downsample at 128 ch: implicit-GEMM split kernel, dilated dgrad
+    (2, 128, 10, 12, 128, 3, 2, 0, 1, False, None, False),     # Downsample at 128 ch: split kernel, data gradient by output parity
+    (1, 128, 9, 14, 128, 3, 2, 0, 1, False, None, False),      # odd height: the zero-dilated data-gradient path at 128 ch
+    (1, 256, 16, 32, 128, 3, 2, 0, 1, False, None, False),     # parity path, Cin != Cout, two Cin tiles in the data gradient
     (2, 128, 8, 8, 128, 3, 1, 1, 1, True, None, False),        # Upsample at 128 ch: upsample gather fwd + wgrad
     (2, 128, 6, 10, 384, 1, 1, 0, 0, False, 32, False),        # 1x1 with GN+SiLU, 3 Cout tiles
     # Upsample as four phase-wise 2x2 convs (W % 16 == 0, >= 128 channels); the W = 8 case above keeps the gather kernel
