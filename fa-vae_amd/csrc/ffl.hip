@@ -10,7 +10,14 @@
 // IC = 32 consecutive inner elements (256-byte contiguous complex segments -> coalesced), holds the L x IC complex tile
 // in LDS, and runs an in-LDS radix-2 DIT FFT (bit-reversed load, log2 L butterfly stages, twiddles from an LDS table).
 // HBM traffic per transform pass = one read + one write of the tile; the planes never leave LDS inside a pass.
+//
+// The input is real, so the spectrum is Hermitian, F[v][W-k] = conj F[-v][k]: only the W/2+1 bins k <= W/2 of the W-axis
+// transform are stored ([N][H][W/2+1][C]); the H-axis pass, the weighting and the inverse H-axis pass run on that half, the
+// loss counts the bins 0 < k < W/2 twice (|F| and the weight w are symmetric), and the inverse W-axis pass rebuilds the mirrored
+// bins as conjugates while loading (after the inverse H-axis transform every row is still Hermitian in k).  Half the bytes in
+// four of the five passes; the value and the gradient are those of the full-spectrum formulation.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -23,12 +30,13 @@ struct FftArgs {
     const float* gscale;   // device scalar multiplied into the real output (bwd)
     long outer, inner;
     int L, logL, IC, C;
+    int Lin, Lout;         // bins present in the input / written to the output along L (L, or L/2+1 for the half spectrum)
     long plane_outer_div;  // outer index -> n : n = outer / plane_outer_div
     float scale;           // 1/sqrt(L)
     int inverse;
 };
 
-enum { IN_COMPLEX = 0, IN_DIFF = 1 };
+enum { IN_COMPLEX = 0, IN_DIFF = 1, IN_HALF = 2 };   // IN_HALF: bins l > L/2 are the conjugates of bins L - l
 enum { OUT_COMPLEX = 0, OUT_COMPLEX_MAX = 1, OUT_REAL = 2 };
 
 template <int IN, int OUT>
@@ -49,13 +57,21 @@ __global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs a) {
     // ---- load (bit-reversed along L) ------------------------------------------------------------------------
     const int ic = tid % IC, bl = tid / IC, BL = 256 / IC;
     const bool ic_ok = i0 + ic < a.inner;
-    const size_t base = (size_t)o * L * a.inner + i0 + ic;
+    const size_t base = (size_t)o * L * a.inner + i0 + ic;            // full-length lines (real input, real output)
+    const size_t base_in = (size_t)o * a.Lin * a.inner + i0 + ic;
+    const size_t base_out = (size_t)o * a.Lout * a.inner + i0 + ic;
     for (int l = bl; l < L; l += BL) {
         float2 v = make_float2(0.f, 0.f);
         if (ic_ok) {
-            const size_t idx = base + (size_t)l * a.inner;
-            if (IN == IN_DIFF) v.x = a.in0[idx] - a.in1[idx];
-            else v = reinterpret_cast<const float2*>(a.in0)[idx];
+            if (IN == IN_DIFF) {
+                const size_t idx = base + (size_t)l * a.inner;
+                v.x = a.in0[idx] - a.in1[idx];
+            } else if (IN == IN_HALF && l >= a.Lin) {
+                v = reinterpret_cast<const float2*>(a.in0)[base_in + (size_t)(L - l) * a.inner];
+                v.y = -v.y;
+            } else {
+                v = reinterpret_cast<const float2*>(a.in0)[base_in + (size_t)l * a.inner];
+            }
         }
         const int r = (int)(__brev((unsigned)l) >> (32 - a.logL));
         data[(a.logL ? r : 0) * IC + ic] = v;
@@ -105,16 +121,16 @@ __global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs a) {
     if (!ic_ok) return;
     float mx = 0.f;
     const float gs = (OUT == OUT_REAL) ? a.gscale[0] * a.scale : a.scale;
-    for (int l = bl; l < L; l += BL) {
+    for (int l = bl; l < (OUT == OUT_REAL ? L : a.Lout); l += BL) {
         float2 v = data[l * IC + ic];
-        const size_t idx = base + (size_t)l * a.inner;
         if (OUT == OUT_REAL) {
+            const size_t idx = base + (size_t)l * a.inner;
             const float r = v.x * gs;
             a.out[idx] = r;
             if (a.out2) a.out2[idx] = -r;
         } else {
             v.x *= gs; v.y *= gs;
-            reinterpret_cast<float2*>(a.out)[idx] = v;
+            reinterpret_cast<float2*>(a.out)[base_out + (size_t)l * a.inner] = v;
             if (OUT == OUT_COMPLEX_MAX) mx = fmaxf(mx, v.x * v.x + v.y * v.y);
         }
     }
@@ -126,8 +142,9 @@ __global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs a) {
 }
 
 // spec <- coef * w * F (in place), per-block partial of sum(w*d) in double
+// half spectrum [N][H][Wh][C]: bins 0 < k < W/2 stand for two bins of the full spectrum
 __global__ __launch_bounds__(256) void ffl_weight_kernel(float* spec, const unsigned* planemax, double* part, long per_img,
-                                                         int C, long total, float coef) {
+                                                         int C, long total, float coef, int Wh, int W) {
     __shared__ double red[4];
     double acc = 0.0;
     float2* s2 = reinterpret_cast<float2*>(spec);
@@ -139,7 +156,8 @@ __global__ __launch_bounds__(256) void ffl_weight_kernel(float* spec, const unsi
         const float mx = sqrtf(__uint_as_float(planemax[n * C + c]));
         float w = (mx > 0.f) ? sqrtf(d) / mx : 0.f;                   // 0/0 -> NaN -> 0 upstream
         w = fminf(fmaxf(w, 0.f), 1.f);
-        acc += (double)(w * d);
+        const int k = (int)((i / C) % Wh);
+        acc += (double)(w * d) * ((Wh == W || k == 0 || 2 * k == W) ? 1.0 : 2.0);
         const float g = coef * w;
         s2[i] = make_float2(g * f.x, g * f.y);
     }
@@ -153,6 +171,13 @@ __global__ __launch_bounds__(256) void ffl_finish_kernel(const double* part, int
     for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
     const double tot = block_sum_d256(acc, red);
     if (threadIdx.x == 0) loss[0] = (float)(tot * scale);
+}
+
+// FAVAE_FFL_FULL=1 keeps all W bins (A/B switch; default: the W/2+1 bins of the Hermitian half)
+int stored_bins(int W) {
+    static int full = -1;
+    if (full < 0) { const char* e = getenv("FAVAE_FFL_FULL"); full = (e && e[0] == '1') ? 1 : 0; }
+    return full ? W : W / 2 + 1;
 }
 
 int ilog2(int v) {
@@ -169,6 +194,8 @@ template <int IN, int OUT>
 int launch_fft(FftArgs& a, hipStream_t s) {
     a.IC = pick_ic(a.L);
     a.logL = ilog2(a.L);
+    if (a.Lin <= 0) a.Lin = a.L;
+    if (a.Lout <= 0) a.Lout = a.L;
     a.scale = 1.0f / sqrtf((float)a.L);
     const size_t shm = fft_shm(a.L, a.IC);
     static bool attr = false;
@@ -186,10 +213,14 @@ int launch_fft(FftArgs& a, hipStream_t s) {
 
 }  // namespace
 
+extern "C" size_t favae_ffl_spec_floats(int N, int H, int W, int C) {
+    return (size_t)N * H * stored_bins(W) * C * 2;
+}
+
 extern "C" size_t favae_ffl_workspace(int N, int H, int W, int C) {
     // fwd: planemax (N*C u32) + WEIGHT_BLOCKS doubles ; bwd: complex scratch
     const size_t fwd = (size_t)N * C * sizeof(unsigned) + 256 + WEIGHT_BLOCKS * sizeof(double);
-    const size_t bwd = (size_t)N * H * W * C * 2 * sizeof(float);
+    const size_t bwd = (size_t)N * H * stored_bins(W) * C * 2 * sizeof(float);
     return fwd > bwd ? fwd : bwd;
 }
 
@@ -204,22 +235,23 @@ extern "C" int favae_ffl_fwd(const float* pred, const float* target, int N, int 
     if (hipMemsetAsync(planemax, 0, (size_t)N * C * sizeof(unsigned), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
     FftArgs a{};
     a.C = C;
-    // pass 1: along W, real difference in
+    const int Wh = stored_bins(W);
+    // pass 1: along W, real difference in, bins 0..W/2 out
     a.in0 = pred; a.in1 = target; a.out = spec; a.out2 = nullptr; a.planemax = planemax; a.gscale = nullptr;
-    a.outer = (long)N * H; a.inner = C; a.L = W; a.plane_outer_div = H; a.inverse = 0;
+    a.outer = (long)N * H; a.inner = C; a.L = W; a.Lin = W; a.Lout = Wh; a.plane_outer_div = H; a.inverse = 0;
     int rc = launch_fft<IN_DIFF, OUT_COMPLEX>(a, s);
     if (rc) return rc;
-    // pass 2: along H, in place, with plane max of |F|^2
+    // pass 2: along H on the half spectrum, in place, with plane max of |F|^2 (= the maximum over the full spectrum)
     a.in0 = spec; a.in1 = nullptr; a.out = spec;
-    a.outer = N; a.inner = (long)W * C; a.L = H; a.plane_outer_div = 1;
+    a.outer = N; a.inner = (long)Wh * C; a.L = H; a.Lin = H; a.Lout = H; a.plane_outer_div = 1;
     rc = launch_fft<IN_COMPLEX, OUT_COMPLEX_MAX>(a, s);
     if (rc) return rc;
-    const long total = (long)N * H * W * C;
-    const double M = (double)total;
+    const long total = (long)N * H * Wh * C;                 // stored bins
+    const double M = (double)N * H * W * C;                  // elements of the mean (full spectrum)
     int blocks = (int)((total + 255) / 256);
     if (blocks > WEIGHT_BLOCKS) blocks = WEIGHT_BLOCKS;
-    hipLaunchKernelGGL(ffl_weight_kernel, dim3(blocks), dim3(256), 0, s, spec, (const unsigned*)planemax, part, (long)H * W * C,
-                       C, total, (float)(2.0 * (double)loss_weight / M));
+    hipLaunchKernelGGL(ffl_weight_kernel, dim3(blocks), dim3(256), 0, s, spec, (const unsigned*)planemax, part, (long)H * Wh * C,
+                       C, total, (float)(2.0 * (double)loss_weight / M), Wh, W);
     FAVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(ffl_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)part, blocks, (double)loss_weight / M, loss);
     FAVAE_CHECK_LAUNCH();
@@ -234,11 +266,12 @@ extern "C" int favae_ffl_bwd(const float* spec, const float* gloss, int N, int H
     hipStream_t s = (hipStream_t)stream;
     FftArgs a{};
     a.C = C;
+    const int Wh = stored_bins(W);
     a.in0 = spec; a.in1 = nullptr; a.out = (float*)ws; a.out2 = nullptr; a.planemax = nullptr; a.gscale = nullptr;
-    a.outer = N; a.inner = (long)W * C; a.L = H; a.plane_outer_div = 1; a.inverse = 1;
+    a.outer = N; a.inner = (long)Wh * C; a.L = H; a.Lin = H; a.Lout = H; a.plane_outer_div = 1; a.inverse = 1;
     int rc = launch_fft<IN_COMPLEX, OUT_COMPLEX>(a, s);
     if (rc) return rc;
     a.in0 = (const float*)ws; a.out = gpred; a.out2 = gtarget; a.gscale = gloss;
-    a.outer = (long)N * H; a.inner = C; a.L = W; a.plane_outer_div = H;
-    return launch_fft<IN_COMPLEX, OUT_REAL>(a, s);
+    a.outer = (long)N * H; a.inner = C; a.L = W; a.Lin = Wh; a.Lout = W; a.plane_outer_div = H;
+    return launch_fft<IN_HALF, OUT_REAL>(a, s);
 }

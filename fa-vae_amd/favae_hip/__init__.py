@@ -60,6 +60,7 @@ SIGNATURES = {
     "favae_blur_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _S]),
     "favae_blur_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "favae_blur_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _S]),
+    "favae_ffl_spec_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "favae_ffl_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "favae_ffl_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_size_t, _S]),
     "favae_ffl_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _S]),

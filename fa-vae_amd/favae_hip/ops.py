@@ -702,7 +702,7 @@ class FFLFn(torch.autograd.Function):
             raise RuntimeError("FFL: shape mismatch")
         N, C, H, W = pred.shape
         dev = pred.device
-        spec = torch.empty((N, H, W, C, 2), dtype=torch.float32, device=dev)
+        spec = torch.empty((query("favae_ffl_spec_floats", N, H, W, C),), dtype=torch.float32, device=dev)   # half (Hermitian) spectrum
         loss = torch.empty((1,), dtype=torch.float32, device=dev)
         ws = workspace(query("favae_ffl_workspace", N, H, W, C), dev)
         call("favae_ffl_fwd", ptr(pred), ptr(target), N, H, W, C, float(loss_weight), ptr(loss), ptr(spec), ptr(ws), ws.numel())

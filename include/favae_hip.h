@@ -189,9 +189,11 @@ int favae_blur_bwd(const float* x, const float* dy, const float* sigma, int ksiz
  * (pip 0.3.0; call sites favae_scripts/train_favae.py:313,318,326, losses/vqgan_losses.py:14,25-26).
  * H and W must be powers of two <= 1024.
  *   loss = loss_weight * mean( w * |F|^2 ),  F = fft2_ortho(pred - target),  w = clamp(|F| / max_plane|F|, 0, 1), NaN -> 0
- * `spec` (N*H*W*C*2 floats) receives (2*loss_weight/M) * w * F, from which favae_ffl_bwd forms
+ * `spec` (N*H*(W/2+1)*C*2 floats: the input is real, only the bins k <= W/2 of the Hermitian spectrum are kept; the loss counts
+ * the others through their mirror images) receives (2*loss_weight/M) * w * F, from which favae_ffl_bwd forms
  *   dL/dpred = gloss * Re ifft2_ortho(spec),  dL/dtarget = -dL/dpred.
  * ---------------------------------------------------------------------------------------------------------- */
+size_t favae_ffl_spec_floats(int N, int H, int W, int C);     /* floats `spec` must hold */
 size_t favae_ffl_workspace(int N, int H, int W, int C);
 int favae_ffl_fwd(const float* pred, const float* target, int N, int H, int W, int C, float loss_weight, float* loss,
                   float* spec, void* ws, size_t ws_bytes, favae_stream_t stream);
