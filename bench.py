@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--gan", action="store_true",
                     help="also train the discriminator (BASELINE config-5 wiring: hinge terms, adaptive weight, stage 1; perceptual "
                          "term off) -- not the headline workload, reported under config.workload")
+    ap.add_argument("--lpips", action="store_true",
+                    help="add the perceptual term lpips(x, x_recon) (train_favae.py:77-79) on deterministic stand-in VGG16/lin "
+                         "weights (vgg16_lpips.pt is not available offline: timing only) -- not the headline workload")
     ap.add_argument("--cpu-batch", type=int, default=8, help="images in the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -63,7 +66,7 @@ class ConvEventHook:
         """kernel instantiation a favae_conv_fwd_split call dispatches to (mirrors conv_fwd_impl in csrc/conv.hip)"""
         if name != "favae_conv_fwd_split" or d.Cin % 16 or d.Cout <= 64:
             return None                                    # narrow tiles / fp32-MFMA fallbacks: not the dominant family
-        xf = 0 if not has_affine else {0: 1, 1: 2, 2: 3}[d.act]
+        xf = 0 if not has_affine else {0: 1, 1: 2, 2: 3, 3: 3}[d.act]
         halo = (d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1 and d.gather == 0 and d.Hout == d.Hin and
                 d.Wout == d.Win and d.Hin % 8 == 0 and d.Win % 16 == 0)
         if halo:
@@ -160,7 +163,14 @@ def main():
                      use_l2_quantizer=True, sync_codebook=use_dist, commitment_weight=1.0, kernel_size=9, dsl_init_sigma=3.0,
                      device=dev, use_gauss_resblock=True).to(dev)
     lr = 4.5e-6 * args.batch * world               # train_favae.py:250-251
-    ts = TrainStep(model, lr=lr, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, distributed=use_dist, train_disc=args.gan)
+    lpips = None
+    if args.lpips:
+        from losses.lpips import LPIPS
+        lpips = LPIPS(pretrained=False)
+        lpips.load_state_dict(O.lpips_det_state(), strict=True)
+        lpips = lpips.to(dev).eval()               # train_favae.py:308
+    ts = TrainStep(model, lr=lr, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, distributed=use_dist, train_disc=args.gan,
+                   lpips=lpips, perceptual_weight=1.0)
     xs = [O.det_input(args.batch, args.res, args.res, 1234 + 17 * rank + i).to(dev) for i in range(2)]
 
     hook = ConvEventHook(torch)
@@ -220,7 +230,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: FA-VAE f=16 CelebA-HQ config, codebook %d, embed_dim 256, residual FCM + "
                                    "non-pairwise DSL (k=9, sigma0=3), FFL 1.0 + DSL 0.01, %dx%d, batch %d per GPU, stage-0 step "
                                    "(LPIPS/disc training off, disc forward on)" % (args.codebook, args.res, args.res, args.batch)
-                                   + (" + discriminator training (hinge, adaptive weight, stage 1)" if args.gan else ""),
+                                   + (" + discriminator training (hinge, adaptive weight, stage 1)" if args.gan else "")
+                                   + (" + LPIPS perceptual term (stand-in weights)" if args.lpips else ""),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss_g_last": loss},
         }
         if conv:

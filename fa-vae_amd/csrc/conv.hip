@@ -99,6 +99,7 @@ struct ConvArgs {
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == FAVAE_ACT_SILU) return silu_f(v);
     if (act == FAVAE_ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
+    if (act == FAVAE_ACT_RELU) return v > 0.f ? v : 0.f;
     return v;
 }
 
@@ -621,7 +622,7 @@ __global__ void upsample2x_bwd_kernel(const float* du, float* dx, int N, int H, 
 bool desc_ok(const favae_conv_desc* d) {
     return d && d->N > 0 && d->Hin > 0 && d->Win > 0 && d->Cin > 0 && d->Hout > 0 && d->Wout > 0 && d->Cout > 0 &&
            d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0 && d->gather >= 0 && d->gather <= 2 && d->act >= 0 &&
-           d->act <= 2 && (long)d->N * d->Hout * d->Wout < (1L << 31) &&
+           d->act <= 3 && (long)d->N * d->Hout * d->Wout < (1L << 31) &&
            (d->lat_step == 0 || d->lat_step == 1 || (d->lat_step == 2 && (d->lat_side == 1 || d->lat_side == 2) &&
                                                       (unsigned)d->lat_oh < 2u && (unsigned)d->lat_ow < 2u)) &&
            d->pad + d->pad_dw >= 0 && d->w_rec_offset >= 0 && d->w_rec_offset % 16 == 0;
@@ -790,12 +791,13 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     const bool w6 = wplanes != 0;                            // pre-split weights: records start behind the header
     if (!w6) {
         const int tk = thin_kind(d, scale != nullptr);
-        const int xf0 = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_LEAKY02 ? 3 : 1)) : 0;
+        const int xf0 = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_NONE ? 1 : 3)) : 0;
         if (tk && al16(x) && al16(y) && al16(resid) && al16(scale) && al16(shift)) {
             ThinArgs t{};
             t.x = x; t.w = w; t.bias = bias; t.resid = resid; t.scale = scale; t.shift = shift; t.y = y;
             t.N = d->N; t.H = d->Hin; t.W = d->Win;
             t.aff_stride = d->affine_per_image ? d->Cin : 0;
+            t.act = d->act;
             hipStream_t s = (hipStream_t)stream;
             if (tk == 1) {
                 t.Cw = d->Cout; t.xb = 64;
@@ -849,7 +851,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     } while (0)
     const size_t xb = (size_t)d->N * a.in_img * d->Cin * 4, wb = (size_t)d->Cout * d->KH * d->KW * d->Cin * 4;
     const size_t ab = (size_t)(d->affine_per_image ? d->N : 1) * d->Cin * 4;
-    const int xf = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_LEAKY02 ? 3 : 1)) : 0;
+    const int xf = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_NONE ? 1 : 3)) : 0;
     const bool buf_ok = !force_generic() && !force_nobuf() && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) &&
                         (size_t)d->N * a.out_img * d->Cout * 4 < ((size_t)1 << 32) && (d->gather == FAVAE_GATHER_PLAIN || xf == 0);
     if (special && !(buf_ok && use_b6() && bn == 128 && w6 && d->gather == FAVAE_GATHER_PLAIN)) return FAVAE_ERR_UNSUPPORTED;
@@ -940,12 +942,13 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     if (ws_bytes < favae_conv_wgrad_workspace(d)) return FAVAE_ERR_WORKSPACE;
     {
         const int tk = thin_kind(d, scale != nullptr);
-        const int xf0 = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_LEAKY02 ? 3 : 1)) : 0;
+        const int xf0 = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_NONE ? 1 : 3)) : 0;
         if (tk && xf0 != 3 && al16(x) && al16(dy) && al16(scale) && al16(shift) && al16(ws)) {
             ThinArgs t{};
             t.x = x; t.dy = dy; t.scale = scale; t.shift = shift; t.part = (float*)ws;
             t.N = d->N; t.H = d->Hin; t.W = d->Win;
             t.aff_stride = d->affine_per_image ? d->Cin : 0;
+            t.act = d->act;
             hipStream_t s = (hipStream_t)stream;
             int blocks;
             if (tk == 1) {
@@ -1006,7 +1009,7 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     } while (0)
     const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, yb = (size_t)d->N * d->Hout * d->Wout * d->Cout * 4;
     const size_t ab = (size_t)(d->affine_per_image ? d->N : 1) * d->Cin * 4;
-    const int xf = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_LEAKY02 ? 3 : 1)) : 0;
+    const int xf = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_NONE ? 1 : 3)) : 0;
     const bool ups_b6 = d->gather == FAVAE_GATHER_UPSAMPLE2 && xf == 0 && use_b6() && bco == 128 && bci == 128;
     const bool buf_ok = !force_generic() && !force_nobuf() && a.vec_i && a.vec_o && (d->gather == FAVAE_GATHER_PLAIN || ups_b6) &&
                         d->stride == 1 && d->Wout % 16 == 0 && xb < (1u << 31) && yb < (1u << 31) && xf != 3;

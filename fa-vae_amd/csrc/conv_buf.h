@@ -23,22 +23,24 @@ __device__ __forceinline__ auto make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
 }
 
-// XFORM: 0 none | 1 affine | 2 affine + SiLU | 3 affine + LeakyReLU(0.2)
+// XFORM: 0 none | 1 affine | 2 affine + SiLU | 3 affine + LeakyReLU(0.2) or ReLU (act = FAVAE_ACT_RELU: slope 0)
+__device__ __forceinline__ float leaky_slope(int act) { return act == FAVAE_ACT_RELU ? 0.0f : 0.2f; }
+
 template <int XFORM>
-__device__ __forceinline__ float xform1(float v, float sc, float sh) {
+__device__ __forceinline__ float xform1(float v, float sc, float sh, int act) {
     if (XFORM == 0) return v;
     v = fmaf(v, sc, sh);
     if (XFORM == 2) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-    if (XFORM == 3) v = v > 0.f ? v : 0.2f * v;
+    if (XFORM == 3) v = v > 0.f ? v : leaky_slope(act) * v;
     return v;
 }
 
 template <int XFORM>
-__device__ __forceinline__ float4 xform4_t(float4 v, float4 sc, float4 sh) {
-    v.x = xform1<XFORM>(v.x, sc.x, sh.x);
-    v.y = xform1<XFORM>(v.y, sc.y, sh.y);
-    v.z = xform1<XFORM>(v.z, sc.z, sh.z);
-    v.w = xform1<XFORM>(v.w, sc.w, sh.w);
+__device__ __forceinline__ float4 xform4_t(float4 v, float4 sc, float4 sh, int act) {
+    v.x = xform1<XFORM>(v.x, sc.x, sh.x, act);
+    v.y = xform1<XFORM>(v.y, sc.y, sh.y, act);
+    v.z = xform1<XFORM>(v.z, sc.z, sh.z, act);
+    v.w = xform1<XFORM>(v.w, sc.w, sh.w, act);
     return v;
 }
 
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_fwd_buf_kernel(ConvArgs a) {
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            *reinterpret_cast<float4*>(a_st[j] + buf * BM * LDK) = xform4_t<XFORM>(ra[j], rsc[j], rsh[j]);
+            *reinterpret_cast<float4*>(a_st[j] + buf * BM * LDK) = xform4_t<XFORM>(ra[j], rsc[j], rsh[j], a.act);
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
             const int row = (tid >> 2) + 64 * j;
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_buf_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < I_LD; ++j)
             if (i_p[j] < BKP)
-                *reinterpret_cast<float4*>(&Is[(buf * BKP + i_p[j]) * BCI + i_c[j]]) = xform4_t<XFORM>(ri[j], rsc[j], rsh[j]);
+                *reinterpret_cast<float4*>(&Is[(buf * BKP + i_p[j]) * BCI + i_c[j]]) = xform4_t<XFORM>(ri[j], rsc[j], rsh[j], a.act);
     };
 
     f32x16 acc[MI][NI];

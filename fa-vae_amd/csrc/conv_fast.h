@@ -27,13 +27,14 @@ __device__ __forceinline__ bool gather_src_t(int stride, int pad, int Hin, int W
 
 __device__ __forceinline__ float silu_fast(float y) { return y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
 
-__device__ __forceinline__ float4 xform4(float4 v, float4 sc, float4 sh, int xform) {
+__device__ __forceinline__ float4 xform4(float4 v, float4 sc, float4 sh, int xform, int act) {
     v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
     if (xform == 2) {
         v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w);
     } else if (xform == 3) {
-        v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
-        v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
+        const float sl = act == FAVAE_ACT_RELU ? 0.0f : 0.2f;
+        v.x = v.x > 0.f ? v.x : sl * v.x; v.y = v.y > 0.f ? v.y : sl * v.y;
+        v.z = v.z > 0.f ? v.z : sl * v.z; v.w = v.w > 0.f ? v.w : sl * v.w;
     }
     return v;
 }
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void conv_fwd_fast_kernel(ConvArgs a) {
     const int c4 = (tid & 3) * 4;
     const int taps = a.KH * a.KW;
     // xform: 0 none, 1 affine, 2 affine+SiLU, 3 affine+LeakyReLU  (wave-uniform)
-    const int xform = a.scale ? (a.act == FAVAE_ACT_SILU ? 2 : (a.act == FAVAE_ACT_LEAKY02 ? 3 : 1)) : 0;
+    const int xform = a.scale ? (a.act == FAVAE_ACT_SILU ? 2 : (a.act == FAVAE_ACT_NONE ? 1 : 3)) : 0;
 
     int r_n[2], r_oh[2], r_ow[2];
     bool r_ok[2];
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void conv_fwd_fast_kernel(ConvArgs a) {
         for (int j = 0; j < 2; ++j) {
             float4 v = ra[j];
             if (xform) {
-                const float4 t = xform4(v, rsc[j], rsh[j], xform);
+                const float4 t = xform4(v, rsc[j], rsh[j], xform, a.act);
                 v = rav[j] ? t : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             *reinterpret_cast<float4*>(&As[(buf * BM + (tid >> 2) + 64 * j) * LDK + c4]) = v;
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradArgs a) {
     const int p_begin = z * a.chunk;
     const int p_end = min(a.M, p_begin + a.chunk);
     const int T = (p_end > p_begin) ? (p_end - p_begin + BKP - 1) / BKP : 0;
-    const int xform = a.scale ? (a.act == FAVAE_ACT_SILU ? 2 : (a.act == FAVAE_ACT_LEAKY02 ? 3 : 1)) : 0;
+    const int xform = a.scale ? (a.act == FAVAE_ACT_SILU ? 2 : (a.act == FAVAE_ACT_NONE ? 1 : 3)) : 0;
 
     // fixed (pixel slot, channel quad) of this thread for both tiles; pixel coordinates advance by BKP per step
     int o_p[O_LD], o_c[O_LD];
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradArgs a) {
         for (int j = 0; j < I_LD; ++j) {
             float4 v = ri[j];
             if (xform) {
-                const float4 tt = xform4(v, rsc[j], rsh[j], xform);
+                const float4 tt = xform4(v, rsc[j], rsh[j], xform, a.act);
                 v = riv[j] ? tt : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             if (i_p[j] < BKP) *reinterpret_cast<float4*>(&Is[(buf * BKP + i_p[j]) * BCI + i_c[j]]) = v;

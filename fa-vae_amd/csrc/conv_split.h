@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_sp_kernel(ConvArgs a) {
         for (int j = 0; j < R; ++j) {
             const int row = (tid >> 2) + RSTEP * j;
             uint2 p[NP];
-            S::split4(xform4_t<XFORM>(ra[j], rsc[j], rsh[j]), Sa, p);
+            S::split4(xform4_t<XFORM>(ra[j], rsc[j], rsh[j], a.act), Sa, p);
             sp::store_planes<NP>(As + (buf * BM + row) * S::ROWB + q4 * 8, 32, p);
             if constexpr (WS) {
                 sp::store_planes<NP>(Bs + (buf * BN + row) * S::ROWB + q4 * 8, 32, rbp[j]);
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_sp_kernel(WgradArgs a) {
             const int off = buf * OPB + s_p[j] * sp::RSB + s_c[j] * 2;
             S::split4(ro[j], So, p);
             sp::store_planes<NP>(Os + off, sp::PLB, p);
-            S::split4(xform4_t<XFORM>(ri[j], rsc[j], rsh[j]), Si, p);
+            S::split4(xform4_t<XFORM>(ri[j], rsc[j], rsh[j], a.act), Si, p);
             sp::store_planes<NP>(Is + off, sp::PLB, p);
         }
     };
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP == 2 ? 6
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && tid >= HROWS * 4 - 512) continue;
             uint2 p[NP];
-            float4 t = xform4_t<XFORM>(rh[j], rsc, rsh);
+            float4 t = xform4_t<XFORM>(rh[j], rsc, rsh, a.act);
             if (XFORM && !hok[j]) t = make_float4(0.f, 0.f, 0.f, 0.f);
             S::split4(t, Sa, p);
             sp::store_planes<NP>(Hs + buf * HALO_B + hoff[j] + q4 * 8, 32, p);
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_sp_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && !two) continue;
-            S::split4(xform4_t<XFORM>(ri[j], rsc[j], rsh[j]), Si, p);
+            S::split4(xform4_t<XFORM>(ri[j], rsc[j], rsh[j], a.act), Si, p);
             sp::store_planes<NP>(Is + buf * IB + (spx + 16 * j) * sp::RSB + sq * 2, IPL, p);
         }
     };

@@ -30,13 +30,14 @@ struct ThinArgs {
     int N, H, W, Cw;      // Cw = wide channel count
     int aff_stride;       // Cw if the affine is per image, 0 otherwise
     int xb;               // pixels of one row per workgroup
+    int act;              // FAVAE_ACT_* of the fused input transform (thin_out)
 };
 
 
 template <int XFORM>
-__device__ __forceinline__ float4 thin_xform(float4 v, float4 sc, float4 sh, bool ok) {
+__device__ __forceinline__ float4 thin_xform(float4 v, float4 sc, float4 sh, bool ok, int act) {
     if (XFORM == 0) return v;                                   // out-of-image loads already returned zeros
-    v = xform4_t<XFORM>(v, sc, sh);
+    v = xform4_t<XFORM>(v, sc, sh, act);
     return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void thin_out_kernel(ThinArgs a) {
             const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xc < (unsigned)a.W;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + yy) * a.W + xc) * a.Cw + 4 * q);
-            c[r] = thin_xform<XFORM>(v, sc, sh, ok);
+            c[r] = thin_xform<XFORM>(v, sc, sh, ok, a.act);
         }
     };
     auto pixel = [&](int xx, const float4 (&L)[3], const float4 (&M)[3], const float4 (&R)[3]) {

@@ -151,6 +151,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* da, const flo
             d = sg * (1.f + v * (1.f - sg));
         } else if (act == FAVAE_ACT_LEAKY02) {
             d = v > 0.f ? 1.f : 0.2f;
+        } else if (act == FAVAE_ACT_RELU) {
+            d = v > 0.f ? 1.f : 0.f;
         }
         dx[i] = da[i] * d;
     }
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* da, const flo
 
 }  // namespace
 
-extern "C" int favae_abi_version(void) { return 4; }
+extern "C" int favae_abi_version(void) { return 5; }
 
 extern "C" int favae_hinge_mean(const float* x, int64_t n, int mode, float* loss, void* ws, size_t ws_bytes,
                                 favae_stream_t stream) {

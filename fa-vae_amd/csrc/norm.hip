@@ -20,6 +20,7 @@ __device__ __forceinline__ float act_grad(float y, int act) {
         return s * (1.0f + y * (1.0f - s));
     }
     if (act == FAVAE_ACT_LEAKY02) return y > 0.f ? 1.0f : 0.2f;
+    if (act == FAVAE_ACT_RELU) return y > 0.f ? 1.0f : 0.0f;
     return 1.0f;
 }
 

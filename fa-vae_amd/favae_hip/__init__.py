@@ -14,10 +14,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfavae_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
-ACT_NONE, ACT_SILU, ACT_LEAKY02 = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_LEAKY02, ACT_RELU = 0, 1, 2, 3
 
 _ERR = {1: "bad argument", 2: "kernel launch failed", 3: "unsupported shape", 4: "workspace too small"}
 
@@ -73,6 +73,12 @@ SIGNATURES = {
     "favae_hinge_mean": (c_int, [_P, c_int64, c_int, _P, _P, c_size_t, _S]),
     "favae_hinge_mean_bwd": (c_int, [_P, _P, c_int64, c_int, _P, _S]),
     "favae_act_bwd": (c_int, [_P, _P, c_int, c_int64, _P, _S]),
+    "favae_lpips_level_workspace": (c_size_t, [c_int]),
+    "favae_lpips_level": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_size_t, _S]),
+    "favae_lpips_level_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _S]),
+    "favae_maxpool2": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
+    "favae_maxpool2_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _S]),
+    "favae_channel_affine": (c_int, [_P, _P, _P, c_int64, c_int, _P, _S]),
     "favae_reduce_workspace": (c_size_t, [c_int64]),
     "favae_absdiff_sum": (c_int, [_P, _P, c_int64, c_float, _P, _P, c_size_t, _S]),
     "favae_sqdiff_sum": (c_int, [_P, _P, c_int64, c_float, _P, _P, c_size_t, _S]),

@@ -11,7 +11,7 @@ from ctypes import byref
 
 import torch
 
-from . import (ACT_LEAKY02, ACT_NONE, ACT_SILU, GATHER_DILATE2, GATHER_PLAIN, GATHER_UPSAMPLE2, call, make_conv_desc,
+from . import (ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SILU, GATHER_DILATE2, GATHER_PLAIN, GATHER_UPSAMPLE2, call, make_conv_desc,
                ptr, query, workspace)
 
 CL = torch.channels_last
@@ -610,6 +610,81 @@ class HingeMeanFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         call("favae_hinge_mean_bwd", ptr(x), ptr(g.contiguous()), x.numel(), ctx.mode, ptr(dx))
         return dx, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LPIPS pieces (losses/lpips.py:17-110): ScalingLayer, 2x2 max pooling, one level of the distance
+# ---------------------------------------------------------------------------------------------------------------
+class ChannelAffineFn(torch.autograd.Function):
+    """(x - shift_c) / scale_c   (ScalingLayer.forward, losses/lpips.py:61-62); shift/scale are buffers (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, shift, scale):
+        x = to_cl(x)
+        y = torch.empty_like(x)
+        call("favae_channel_affine", ptr(x), ptr(shift), ptr(scale), x.numel(), x.shape[1], ptr(y))
+        ctx.save_for_backward(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        g = to_cl(g)
+        dx = torch.empty_like(g)
+        call("favae_channel_affine", ptr(g), None, ptr(scale), g.numel(), g.shape[1], ptr(dx))
+        return dx, None, None
+
+
+class MaxPool2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(kernel_size=2, stride=2) (torchvision vgg16 features[4,9,16,23] as sliced by losses/lpips.py:88-96)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = to_cl(x)
+        N, C, H, W = x.shape
+        y = new_cl(N, C, H // 2, W // 2, x.device)
+        call("favae_maxpool2", ptr(x), N, H, W, C, ptr(y))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        N, C, H, W = x.shape
+        g = to_cl(g)
+        dx = new_cl(N, C, H, W, x.device)
+        call("favae_maxpool2_bwd", ptr(x), ptr(g), N, H, W, C, ptr(dx))
+        return dx
+
+
+class LpipsLevelFn(torch.autograd.Function):
+    """val[n] (+)= mean_hw sum_c w_c (a^ - b^)^2 of one VGG level (losses/lpips.py:44-48).  a, b: PRE-activation features of
+    lpips()'s first / second argument (the ReLU is applied here); `val` is the running (N,) sum over levels (None for the
+    first level) -- its gradient passes through unchanged.  Gradient flows to b only (the step's lpips(x, x_recon))."""
+
+    @staticmethod
+    def forward(ctx, a, b, w, val):
+        a, b = to_cl(a), to_cl(b)
+        N, C, H, W = b.shape
+        out = torch.empty((N,), dtype=torch.float32, device=b.device) if val is None else val.clone()
+        wv = w.reshape(-1).contiguous()
+        ws = workspace(query("favae_lpips_level_workspace", N), b.device)
+        call("favae_lpips_level", ptr(a), ptr(b), ptr(wv), N, H * W, C, ptr(out), 0 if val is None else 1, ptr(ws), ws.numel())
+        ctx.save_for_backward(a, b, wv)
+        ctx.has_val = val is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, wv = ctx.saved_tensors
+        N, C, H, W = b.shape
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            raise RuntimeError("LPIPS: only the second image argument carries a gradient (train_favae.py:77 lpips(x, x_recon))")
+        db = None
+        if ctx.needs_input_grad[1]:
+            db = new_cl(N, C, H, W, b.device)
+            call("favae_lpips_level_bwd", ptr(a), ptr(b), ptr(wv), ptr(g.contiguous()), N, H * W, C, ptr(db))
+        return None, db, None, (g if ctx.has_val else None)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -1,8 +1,8 @@
 """One FA-VAE training iteration on the MI355X-native kernels -- restates the hot loop of the reference's train()
 (favae_scripts/train_favae.py:68-116): stage 0 (encoder + decoder + quantizer: L1 + commit + FFL + 4-level DSL, optionally
 the hinge generator term with the adaptive weight of :32-39) and, with train_disc, stage 1 (discriminator, hinge loss), with
-the optimizers of :292-305 (Adam, betas (0.5, 0.9), lr = base_lr * batch * world).  The perceptual (LPIPS) term is not part
-of the accelerated path (no VGG weights offline): perceptual_weight must be 0.
+the optimizers of :292-305 (Adam, betas (0.5, 0.9), lr = base_lr * batch * world).  The perceptual term
+`perceptual_weight * lpips(x, x_recon).mean()` (:77-79) is on when an LPIPS module (losses/lpips.py) is passed.
 
 MI355X-first choices:
   * all trainable parameters, their gradients and both Adam moments live in four flat fp32 buffers; parameters are
@@ -42,8 +42,10 @@ def _flatten(params, dev):
 
 class TrainStep:
     def __init__(self, model, lr, betas=(0.5, 0.9), eps=1e-8, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01,
-                 sigma_lr=2.0e-7, distributed=False, train_disc=False, disc_weight=0.75):
+                 sigma_lr=2.0e-7, distributed=False, train_disc=False, disc_weight=0.75, lpips=None, perceptual_weight=1.0):
         self.model = model
+        self.lpips = lpips                                   # losses.lpips.LPIPS in eval mode (train_favae.py:308) or None
+        self.pw = perceptual_weight if lpips is not None else 0.0
         self.lr, self.betas, self.eps, self.sigma_lr = lr, betas, eps, sigma_lr
         self.cw = codebook_weight
         self.train_disc, self.disc_weight = train_disc, disc_weight
@@ -65,21 +67,26 @@ class TrainStep:
             self.dpflat, self.dgflat, self.dmflat, self.dvflat = _flatten(self.dparams, dev)
 
     def losses(self, x):
-        """Forward + loss assembly of train() :75-102 (perceptual / adversarial terms off)."""
+        """Forward + loss assembly of train() :75-102."""
         m = self.model
         x = K.to_cl(x)
         x_recon, loss_q, _logits_fake, _z, enc_feats, dec_feats = m(x, stage=0)
         out = {"loss_l1": K.l1_loss(x, x_recon), "loss_quant": loss_q}
-        loss_g = out["loss_l1"] + self.cw * loss_q
+        loss_recon = out["loss_l1"]
+        if self.pw > 0:                                      # train_favae.py:77-79
+            out["loss_perceptual"] = self.lpips(x, x_recon).mean()
+            loss_recon = loss_recon + self.pw * out["loss_perceptual"]
+        out["loss_recon"] = loss_recon
+        loss_g = loss_recon + self.cw * loss_q
         if self.ffl is not None:
             out["loss_ffl"] = recon_ffl_loss(self.ffl, x, x_recon)
             loss_g = loss_g + out["loss_ffl"]
         if self.dsl is not None:
             out["loss_dsl"], out["loss_dsl_levels"] = recon_ffl_features_loss(self.dsl, enc_feats, dec_feats, x.device)
             loss_g = loss_g + out["loss_dsl"]
-        if self.train_disc:                                  # train_favae.py:82-88 (loss_recon = L1: perceptual term off)
+        if self.train_disc:                                  # train_favae.py:82-88
             out["loss_disc"] = hinge_g_loss(_logits_fake)
-            out["weight_d"] = self.adaptive_weight(out["loss_l1"], out["loss_disc"])
+            out["weight_d"] = self.adaptive_weight(loss_recon, out["loss_disc"])
             loss_g = loss_g + out["weight_d"] * self.disc_weight * out["loss_disc"]
         out["logits_fake"] = _logits_fake
         out["loss_g"] = loss_g

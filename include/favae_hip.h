@@ -70,6 +70,7 @@ typedef struct {
 #define FAVAE_ACT_NONE 0
 #define FAVAE_ACT_SILU 1
 #define FAVAE_ACT_LEAKY02 2
+#define FAVAE_ACT_RELU 3      /* VGG16 feature stack of LPIPS (losses/lpips.py:74-110) */
 
 /* y = conv(T(x), w) + bias + resid, T(x) = act(x*scale+shift) (scale==NULL -> T = identity).  bias, resid, scale,
  * shift may be NULL.  The data gradient of a stride-1 conv is this same call on dy with favae_weight_flip()'d weights. */
@@ -229,6 +230,27 @@ int favae_hinge_mean(const float* x, int64_t n, int mode, float* loss, void* ws,
 int favae_hinge_mean_bwd(const float* x, const float* g, int64_t n, int mode, float* dx, favae_stream_t stream);
 /* dx = da * act'(x), act as in favae_conv_desc */
 int favae_act_bwd(const float* da, const float* x, int act, int64_t n, float* dx, favae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * LPIPS perceptual distance (losses/lpips.py:17-110; `lpips(x, x_recon)` of favae_scripts/train_favae.py:77).  The VGG16
+ * 3x3 convs run through favae_conv_fwd* with act = FAVAE_ACT_RELU applied on the operand load, so feature tensors hold
+ * PRE-activation values; the entry points below apply the ReLU themselves.  NHWC fp32.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* One level of LPIPS.forward (losses/lpips.py:44-48): val[n] (+)= mean_hw sum_c w_c (a^ - b^)^2 with
+ * a^ = relu(a) / max(|relu(a)|_2, 1e-12) over channels (F.normalize).  C in {64,128,256,512}; w = the level's 1x1 `lin`
+ * weights [C]; ws: favae_lpips_level_workspace(N).  Backward: db = d val[n]/d b * g[n]  (b = pre-activation features of the
+ * image that carries the gradient, i.e. the SECOND argument of lpips(); a gets no gradient in the training step). */
+size_t favae_lpips_level_workspace(int N);
+int favae_lpips_level(const float* a, const float* b, const float* w, int N, int HW, int C, float* val, int accumulate, void* ws,
+                      size_t ws_bytes, favae_stream_t stream);
+int favae_lpips_level_bwd(const float* a, const float* b, const float* w, const float* g, int N, int HW, int C, float* db,
+                          favae_stream_t stream);
+/* nn.MaxPool2d(2, 2) of torchvision's vgg16 features (losses/lpips.py:88-96): H, W even, C % 4 == 0; first maximum in
+ * scan order wins, NaN propagates (aten).  Backward routes dy to that element and writes zeros elsewhere (dx fully written). */
+int favae_maxpool2(const float* x, int N, int H, int W, int C, float* y, favae_stream_t stream);
+int favae_maxpool2_bwd(const float* x, const float* dy, int N, int H, int W, int C, float* dx, favae_stream_t stream);
+/* ScalingLayer (losses/lpips.py:55-62): y = (x - shift[c]) / scale[c], c = i mod C; shift == NULL: y = x / scale[c] (its gradient) */
+int favae_channel_affine(const float* x, const float* shift, const float* scale, int64_t n, int C, float* y, favae_stream_t stream);
 
 /* straight-through value exactly as the reference forms it: out = x + (q - x)   (models/l2_quantize.py:554) */
 int favae_vq_ste(const float* x, const float* q, float* out, int64_t n, favae_stream_t stream);

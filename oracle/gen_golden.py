@@ -531,9 +531,69 @@ def gen_hinge():
     np.savez_compressed(os.path.join(OUT, "hinge.npz"), **out)
 
 
+def gen_lpips_head():
+    """LPIPS.forward / ScalingLayer / NetLinLayer of the reference (losses/lpips.py:40-72) on explicit feature tensors.
+    losses/lpips.py imports `torchvision.models` only to build the VGG16 stack and loads `vgg16_lpips.pt` in __init__; both are
+    absent, so the module object is created without running LPIPS.__init__ (attributes set by hand from the reference's own
+    ScalingLayer / NetLinLayer classes) and `net` is a stand-in that hands back the stored feature tensors: what gets pinned is
+    everything AFTER the feature extractor (normalisation, squared difference, lin layers, spatial mean, level sum) plus the
+    scaling layer.  The VGG16 topology itself stays unpinned (see favae_oracle.py)."""
+    tvm = types.ModuleType("torchvision.models")
+    sys.modules.setdefault("torchvision.models", tvm)
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    import losses.lpips as RLP
+    chns = [64, 128, 256, 512, 512]
+    hw = [(8, 8), (4, 6), (4, 4), (2, 2), (2, 2)]
+    ref = RLP.LPIPS.__new__(RLP.LPIPS)
+    torch.nn.Module.__init__(ref)
+    ref.scaling_layer = RLP.ScalingLayer()
+    ref.chns = chns
+    LP = O.lpips_det_state()
+    for k, c in enumerate(chns):
+        lin = RLP.NetLinLayer(c, use_dropout=True)
+        lin.model[1].weight.data.copy_(LP["lin%d.model.1.weight" % k])
+        setattr(ref, "lin%d" % k, lin)
+    ref.eval()                                                     # train_favae.py:308
+    out = {}
+    pre0, pre1 = [], []
+    for k, (c, (h, w)) in enumerate(zip(chns, hw)):
+        a = (2 * O._hash_uniform(2 * c * h * w, 100 + k).reshape(2, c, h, w) - 0.6).float() * (1.0 + k)
+        b = (2 * O._hash_uniform(2 * c * h * w, 200 + k).reshape(2, c, h, w) - 0.6).float() * (1.0 + k)
+        if k == 3:
+            b[0, :, 0, 0] = -1.0                                   # an all-zero post-ReLU pixel: F.normalize's eps clamp
+        pre0.append(a)
+        pre1.append(b)
+        out["pre0_%d" % k], out["pre1_%d" % k] = npy(a), npy(b)
+    post1 = [torch.relu(t).requires_grad_(True) for t in pre1]
+    feats = [[torch.relu(t) for t in pre0], post1]
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.calls = 0
+
+        def forward(self, X):
+            self.calls += 1
+            return feats[self.calls - 1]
+    ref.net = Net()
+    img0 = O.det_input(2, 8, 8, 5)
+    img1 = O.det_input(2, 8, 8, 6)
+    val = ref(img0, img1)
+    val.sum().backward()
+    out["val"] = npy(val)
+    for k in range(5):
+        out["gpost1_%d" % k] = npy(post1[k].grad)
+    out["img"] = npy(img0)
+    out["scaled"] = npy(ref.scaling_layer(img0))
+    # oracle agreement
+    check("lpips_head.val", O.lpips_head(LP, feats[0], [t.detach() for t in post1]), val, 1e-6)
+    check("lpips_head.scaled", O.lpips_scaling(LP, img0), ref.scaling_layer(img0), 1e-7)
+    np.savez_compressed(os.path.join(OUT, "lpips_head.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["blocks", "blur", "vq", "hinge", "models", "cfg1", "gan"]
+    which = sys.argv[1:] or ["blocks", "blur", "vq", "hinge", "models", "cfg1", "gan", "lpips"]
     if "blocks" in which:
         gen_blocks()
     if "blur" in which:
@@ -548,6 +608,8 @@ if __name__ == "__main__":
         gen_cfg1_full()
     if "gan" in which:
         gen_gan()
+    if "lpips" in which:
+        gen_lpips_head()
     print("oracle-vs-reference max relative differences:")
     for name, r in report:
         print(f"  {name:55s} {r:.3e}")

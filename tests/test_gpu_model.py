@@ -380,3 +380,84 @@ def test_zero_and_nonfinite_operands():
     xn[0, 5, 3, 3] = float("nan")
     yn = K.fused_conv(xn, w.detach(), None, None, None, None, K.ConvCfg(3, 3, 1, 1))
     assert torch.isnan(yn).any()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# (d) LPIPS perceptual term (losses/lpips.py).  VGG16 topology unpinned (torchvision absent), head pinned by
+#     tests/golden/lpips_head.npz (test_gpu_ops.py); here: the whole module against the CPU oracle on deterministic weights.
+# --------------------------------------------------------------------------------------------------------------
+def _lpips_module():
+    from losses.lpips import LPIPS
+    lp = LPIPS(pretrained=False)
+    lp.load_state_dict(O.lpips_det_state(), strict=True)
+    return lp.to(DEV).eval()
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (32, 96)])
+def test_lpips_vs_oracle(hw):
+    """lpips(x, x_recon): per-image values and the gradient w.r.t. the second argument (train_favae.py:77)."""
+    LP = O.lpips_det_state()
+    lp = _lpips_module()
+    x = O.det_input(2, hw[0], hw[1], 41)
+    y = (O.det_input(2, hw[0], hw[1], 42) * 0.8).requires_grad_(True)
+    ref = O.lpips_forward(LP, x, y)
+    (gref,) = torch.autograd.grad(ref.mean(), y)
+    yd = y.detach().to(DEV).requires_grad_(True)
+    val = lp(x.to(DEV), yd)
+    assert val.shape == (2,)
+    close(val, ref, 1e-4, "lpips value")
+    (gd,) = torch.autograd.grad(val.mean(), yd)
+    close(gd, gref, 1e-3, "d lpips / d x_recon")
+    with torch.no_grad():
+        assert float(lp(x.to(DEV), x.to(DEV)).abs().max()) == 0.0
+    assert all(p.grad is None for p in lp.parameters())
+
+
+def test_lpips_features_vs_oracle():
+    """the five VGG16 taps (pre-activation here, post-ReLU in the reference: relu(ours) == theirs)"""
+    LP = O.lpips_det_state()
+    lp = _lpips_module()
+    x = O.det_input(1, 64, 64, 43)
+    ref = O.lpips_vgg_features(LP, O.lpips_scaling(LP, x))
+    with torch.no_grad():
+        got = lp.net(lp.scaling_layer(x.to(DEV)))
+    for k in range(5):
+        assert got[k].shape == ref[k].shape
+        close(torch.relu(got[k]), ref[k], 1e-4, "relu%d" % (k + 1))
+
+
+def test_train_step_with_lpips_vs_oracle():
+    """One stage-0 step with the perceptual term (loss_recon = L1 + pw * LPIPS, train_favae.py:77-79) against the oracle:
+    losses and the gradients that reach the generator."""
+    from favae_step import TrainStep
+    model, cfg, state = build("cfg1_k3")
+    LP = O.lpips_det_state()
+    ts = TrainStep(model, lr=1e-4, dsl_weight=0.01, lpips=_lpips_module(), perceptual_weight=1.0)
+    orc = O.OracleTrainer(cfg, O.StepConfig(lr=1e-4, dsl_weight=0.01, with_disc_forward=True, perceptual_weight=1.0), state,
+                          lpips_state=LP)
+    x = O.det_input(2, 64, 64, 100)
+    ro = orc.step(x)
+    out = ts.step(x.to(DEV))
+    for k in ("loss_l1", "loss_perceptual", "loss_recon", "loss_quant", "loss_ffl", "loss_dsl", "loss_g"):
+        close(out[k].reshape(-1), ro[k].reshape(-1), 1e-4, k)
+    named = dict(model.named_parameters())
+    worst = 0.0
+    for k in orc.keys:
+        go = ro["grads"].get(k)
+        if go is None or float(go.abs().max()) <= 1e-6:
+            continue
+        worst = max(worst, rel(named[k].grad, go))
+    assert worst < 2e-3, f"gradients with the perceptual term: worst per-tensor max-rel {worst:.3e}"
+
+
+def test_gan_lpips_trainstep_runs():
+    """BASELINE config 5 wiring: discriminator training + LPIPS + FFL + DSL in one iteration; finite and deterministic."""
+    from favae_step import TrainStep
+    outs = []
+    for _ in range(2):
+        model, cfg, state = build("cfg1_k3")
+        ts = TrainStep(model, lr=1e-4, train_disc=True, lpips=_lpips_module())
+        o = ts.step(O.det_input(2, 64, 64, 7).to(DEV))
+        outs.append((o["loss_g"].detach().cpu(), o["loss_d"].detach().cpu(), ts.pflat.detach().cpu().clone()))
+        assert torch.isfinite(outs[-1][0]).all() and torch.isfinite(outs[-1][2]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])

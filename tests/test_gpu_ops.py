@@ -418,3 +418,111 @@ def test_hinge_terms(K, golden_dir):
     check(grd[0], gr[0], 1e-6, "d hinge_d / d real")
     check(grd[1], gr[1], 1e-6, "d hinge_d / d fake")
     check(torch.autograd.grad(lgd, fd)[0], gg, 1e-6, "d hinge_g / d fake")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LPIPS pieces (losses/lpips.py): ReLU-on-load convs, 2x2 max pooling, level distance, scaling layer
+# ---------------------------------------------------------------------------------------------------------------
+RELU_CONV_CASES = [
+    # (N, Cin, H, W, Cout): VGG16 shapes -- 64-wide layers take the fp32 matrix kernels, >= 128 outputs the split path / halo
+    (2, 64, 16, 16, 64),
+    (1, 64, 12, 20, 128),
+    (2, 128, 8, 16, 128),
+    (1, 128, 8, 16, 256),
+    (1, 256, 6, 6, 512),
+]
+
+
+@pytest.mark.parametrize("case", RELU_CONV_CASES)
+def test_relu_conv(K, case):
+    """conv3x3(relu(x)) with the ReLU applied on the operand load (FAVAE_ACT_RELU): forward and data gradient (frozen weights:
+    the VGG16 stack of LPIPS has requires_grad = False, losses/lpips.py:30-31)."""
+    import favae_hip as H
+    N, Cin, Hh, W, Cout = case
+    x = rnd((N, Cin, Hh, W), 11, 2.0)
+    w = rnd((Cout, Cin, 3, 3), 12, math.sqrt(6.0 / (9 * Cin)))
+    b = rnd((Cout,), 13, 0.1)
+    dy = rnd((N, Cout, Hh, W), 14)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(F.relu(xr), w, b, padding=1)
+    (gr,) = torch.autograd.grad(yr, xr, dy)
+    cfg = K.ConvCfg(3, 3, 1, 1, act=H.ACT_RELU, norm="act")
+    xd = x.to(dev()).requires_grad_(True)
+    wd = w.to(dev()).contiguous(memory_format=torch.channels_last)
+    yd = K.fused_conv(xd, wd, b.to(dev()), cfg=cfg)
+    check(yd, yr, 2e-5, "relu conv fwd")
+    (gd,) = torch.autograd.grad(yd, xd, dy.to(dev()))
+    check(gd, gr, 2e-5, "relu conv dgrad")
+    assert bool(((gd.cpu() != 0) <= (x > 0)).all()), "gradient leaked through a negative pre-activation"
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 8, 12), (1, 128, 6, 4), (3, 8, 2, 2)])
+def test_maxpool2(K, shape):
+    x = rnd(shape, 21)
+    x[0, :, 0, 0] = x[0, :, 0, 1]                      # ties: first element in scan order takes the gradient (aten)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    dy = rnd(tuple(yr.shape), 22)
+    (gr,) = torch.autograd.grad(yr, xr, dy)
+    xd = x.to(dev()).requires_grad_(True)
+    yd = K.MaxPool2Fn.apply(xd)
+    assert torch.equal(yd.cpu(), yr.detach()), "max pooling must be bit-exact"
+    (gd,) = torch.autograd.grad(yd, xd, dy.to(dev()))
+    assert torch.equal(gd.cpu(), gr), "max pooling gradient must be bit-exact"
+
+
+def test_maxpool2_commutes_with_relu(K):
+    """the identity the LPIPS path relies on: relu(maxpool(pre)) == maxpool(relu(pre)), gradients included"""
+    x = rnd((2, 64, 8, 8), 23)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(F.relu(xr), 2, 2)
+    dy = rnd(tuple(yr.shape), 24)
+    (gr,) = torch.autograd.grad(yr, xr, dy)
+    xd = x.to(dev()).requires_grad_(True)
+    yd = F.relu(K.MaxPool2Fn.apply(xd))
+    assert torch.equal(yd.cpu(), yr.detach())
+    (gd,) = torch.autograd.grad(yd, xd, dy.to(dev()))
+    assert torch.equal(gd.cpu(), gr)
+
+
+def test_lpips_level_against_reference_golden(K, golden_dir):
+    """LPIPS.forward after the feature extractor (losses/lpips.py:43-53) on the stored feature tensors: value and the gradient
+    w.r.t. the second argument's features, as captured from the reference classes (oracle/gen_golden.py:gen_lpips_head)."""
+    g = np.load(os.path.join(golden_dir, "lpips_head.npz"))
+    LP = O.lpips_det_state()
+    val = None
+    pre1 = []
+    for k in range(5):
+        a = torch.from_numpy(g["pre0_%d" % k]).to(dev())
+        b = torch.from_numpy(g["pre1_%d" % k]).to(dev()).requires_grad_(True)
+        pre1.append(b)
+        val = K.LpipsLevelFn.apply(a, b, LP["lin%d.model.1.weight" % k].to(dev()), val)
+    check(val, torch.from_numpy(g["val"]), 2e-6, "lpips value")
+    grads = torch.autograd.grad(val.sum(), pre1)
+    for k in range(5):
+        want = torch.from_numpy(g["gpost1_%d" % k]) * (torch.from_numpy(g["pre1_%d" % k]) > 0)
+        check(grads[k], want, 2e-5, "lpips level %d gradient" % k)
+
+
+def test_lpips_level_identical_inputs_and_weights(K):
+    """d(x, x) = 0 exactly; per-image gradient scaling g[n] is honoured"""
+    a = rnd((2, 128, 4, 4), 31).to(dev())
+    w = rnd((128,), 32).abs().to(dev())
+    v = K.LpipsLevelFn.apply(a, a.clone(), w, None)
+    assert float(v.abs().max()) == 0.0
+    b = rnd((2, 128, 4, 4), 33).to(dev()).requires_grad_(True)
+    v = K.LpipsLevelFn.apply(a, b, w, None)
+    (g1,) = torch.autograd.grad((v * torch.tensor([1.0, 0.0], device=dev())).sum(), b, retain_graph=True)
+    assert float(g1[1].abs().max()) == 0.0 and float(g1[0].abs().max()) > 0.0
+
+
+def test_scaling_layer_against_reference_golden(K, golden_dir):
+    g = np.load(os.path.join(golden_dir, "lpips_head.npz"))
+    from losses.lpips import ScalingLayer
+    sl = ScalingLayer().to(dev())
+    x = torch.from_numpy(g["img"]).to(dev()).requires_grad_(True)
+    y = sl(x)
+    check(y, torch.from_numpy(g["scaled"]), 1e-6, "ScalingLayer")
+    (gx,) = torch.autograd.grad(y.sum(), x)
+    want = (1.0 / torch.tensor([.458, .448, .450])).view(1, 3, 1, 1).expand(2, 3, 8, 8)
+    check(gx, want, 1e-6, "ScalingLayer gradient")

@@ -278,3 +278,47 @@ def test_gan_iteration(golden_dir):
     assert np.array_equal(r["out"]["indices"].numpy(), g["gan_128.indices"])
     r["logits_fake"] = r["out"]["logits_fake"]
     check_gan_golden(g, r, tr.P, lr)
+
+
+# --------------------------------------------------------------------------------------------
+# LPIPS: head + scaling layer pinned by the reference classes, VGG16 topology by shape bookkeeping only
+# --------------------------------------------------------------------------------------------
+def test_lpips_head_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "lpips_head.npz"))
+    LP = O.lpips_det_state()
+    f0 = [torch.relu(torch.from_numpy(g["pre0_%d" % k])) for k in range(5)]
+    f1 = [torch.relu(torch.from_numpy(g["pre1_%d" % k])).requires_grad_(True) for k in range(5)]
+    val = O.lpips_head(LP, f0, f1)
+    close(val.detach(), g["val"], 1e-6, "lpips head value")
+    grads = torch.autograd.grad(val.sum(), f1)
+    for k in range(5):
+        close(grads[k], g["gpost1_%d" % k], 1e-6, "lpips head gradient %d" % k)
+    close(O.lpips_scaling(LP, torch.from_numpy(g["img"])), g["scaled"], 1e-7, "ScalingLayer")
+
+
+def test_lpips_state_dict_keys_match_module():
+    """the build's LPIPS module exposes the state_dict keys / shapes of the reference module (so vgg16_lpips.pt loads strict)"""
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fa-vae_amd")
+    if pkg not in sys.path:
+        sys.path.insert(0, pkg)
+    from losses.lpips import LPIPS
+    lp = LPIPS(pretrained=False)
+    want = O.lpips_param_shapes()
+    got = {k: tuple(v.shape) for k, v in lp.state_dict().items()}
+    assert got == want
+    assert all(not p.requires_grad for p in lp.parameters())
+    lp.load_state_dict(O.lpips_det_state(), strict=True)
+    with pytest.raises(FileNotFoundError):
+        LPIPS()                                            # the reference loads vgg16_lpips.pt unconditionally (losses/lpips.py:33-37)
+
+
+def test_lpips_oracle_properties():
+    LP = O.lpips_det_state()
+    x, y = O.det_input(2, 32, 32, 1), O.det_input(2, 32, 32, 2)
+    d = O.lpips_forward(LP, x, y)
+    assert d.shape == (2,) and bool((d > 0).all())
+    assert float(O.lpips_forward(LP, x, x).abs().max()) == 0.0
+    close(O.lpips_forward(LP, y, x), d, 1e-6, "symmetry")
+    f = O.lpips_vgg_features(LP, O.lpips_scaling(LP, x))
+    assert [tuple(t.shape[1:]) for t in f] == [(64, 32, 32), (128, 16, 16), (256, 8, 8), (512, 4, 4), (512, 2, 2)]
