@@ -18,7 +18,7 @@ import torch.distributed as dist
 from favae_hip import ops as K
 from focal_frequency_loss import FocalFrequencyLoss
 from losses.hinge import hinge_d_loss, hinge_g_loss
-from losses.vqgan_losses import recon_ffl_features_loss, recon_ffl_loss
+from losses.vqgan_losses import recon_ffl_features_loss, recon_ffl_loss, recon_sl_gaussian_features_loss
 
 
 def _flatten(params, dev):
@@ -42,7 +42,8 @@ def _flatten(params, dev):
 
 class TrainStep:
     def __init__(self, model, lr, betas=(0.5, 0.9), eps=1e-8, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01,
-                 sigma_lr=2.0e-7, distributed=False, train_disc=False, disc_weight=0.75, lpips=None, perceptual_weight=1.0):
+                 sigma_lr=2.0e-7, distributed=False, train_disc=False, disc_weight=0.75, lpips=None, perceptual_weight=1.0,
+                 sl_weight=0.0, gaussian_kernel=None, gaussian_sigma=None):
         self.model = model
         self.lpips = lpips                                   # losses.lpips.LPIPS in eval mode (train_favae.py:308) or None
         self.pw = perceptual_weight if lpips is not None else 0.0
@@ -51,6 +52,9 @@ class TrainStep:
         self.train_disc, self.disc_weight = train_disc, disc_weight
         self.ffl = FocalFrequencyLoss(loss_weight=ffl_weight, alpha=1.0) if ffl_weight > 0 else None
         self.dsl = FocalFrequencyLoss(loss_weight=dsl_weight, alpha=1.0) if dsl_weight > 0 else None
+        # --SL_weight / --gaussian_kernel / --gaussian_sigma: fixed-sigma Spectrum Loss (train_favae.py:101-103,324-326)
+        self.sl = FocalFrequencyLoss(loss_weight=sl_weight, alpha=1.0) if sl_weight > 0 else None
+        self.sl_kernel, self.sl_sigma = gaussian_kernel, gaussian_sigma
         self.distributed = distributed and dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.distributed else 1
         self.t = 0
@@ -84,6 +88,10 @@ class TrainStep:
         if self.dsl is not None:
             out["loss_dsl"], out["loss_dsl_levels"] = recon_ffl_features_loss(self.dsl, enc_feats, dec_feats, x.device)
             loss_g = loss_g + out["loss_dsl"]
+        if self.sl is not None:                              # reverses dec_feats in place once more, like the reference
+            out["loss_sl"], out["loss_sl_levels"] = recon_sl_gaussian_features_loss(self.sl, self.sl_kernel, self.sl_sigma,
+                                                                                    enc_feats, dec_feats, x.device)
+            loss_g = loss_g + out["loss_sl"]
         if self.train_disc:                                  # train_favae.py:82-88
             out["loss_disc"] = hinge_g_loss(_logits_fake)
             out["weight_d"] = self.adaptive_weight(loss_recon, out["loss_disc"])

@@ -1,4 +1,4 @@
-"""Frequency-loss glue of FA-VAE (reference losses/vqgan_losses.py:13-30), same function names and return values.
+"""Frequency-loss glue of FA-VAE (reference losses/vqgan_losses.py:13-50), same function names and return values.
 
 `ffl` is any callable (pred, target) -> scalar; with `focal_frequency_loss.FocalFrequencyLoss` from this tree each
 call is one fused HIP FFT-loss.  The reference evaluates every feature term twice (once for the sum, once for the
@@ -23,5 +23,24 @@ def recon_ffl_features_loss(ffl, en_feat, de_feat, device):
 
 
 def recon_sl_gaussian_features_loss(ffl, gaussian_kernel, gaussian_sigma, en_feat, de_feat, device):
-    raise NotImplementedError("fixed-sigma Spectrum Loss (SL, torchvision GaussianBlur) is outside the accelerated hot "
-                              "path (SURVEY 2.1: only train_favae_celeba.sh experiment 3 uses it)")
+    """Spectrum Loss with a fixed sigma (vqgan_losses.py:34-50).  The reference blurs every feature with
+    torchvision.transforms.GaussianBlur((k, k), sigma): kernel1d = normalised exp(-0.5 (x / sigma)^2) on
+    linspace(-(k-1)/2, (k-1)/2, k), outer product, reflect padding k//2, depthwise conv -- the same operator as the codec's
+    own _gaussian_blur (models/codec.py:255-277), so the same HIP blur kernel runs with a constant sigma (no sigma gradient).
+    A (min, max) sigma range would be sampled per call by torchvision; the reference passes one float (--gaussian_sigma)."""
+    from favae_hip import ops as K
+    if isinstance(gaussian_sigma, (tuple, list)):
+        if float(gaussian_sigma[0]) != float(gaussian_sigma[1]):
+            raise NotImplementedError("a sigma range is sampled randomly by torchvision; pass a single sigma")
+        gaussian_sigma = gaussian_sigma[0]
+    sigma = torch.full((1,), float(gaussian_sigma), dtype=torch.float32, device=device)
+    de_feat.reverse()                                        # in place (vqgan_losses.py:37)
+    en_b = [K.gaussian_blur(f, sigma, 0, gaussian_kernel) for f in en_feat]
+    de_b = [K.gaussian_blur(f, sigma, 0, gaussian_kernel) for f in de_feat]
+    loss = torch.zeros(1, device=device)
+    losses = []
+    for i in range(len(en_b)):
+        li = ffl(de_b[i], en_b[i])
+        loss = loss + li
+        losses.append(li)
+    return loss / len(en_b), losses

@@ -461,3 +461,29 @@ def test_gan_lpips_trainstep_runs():
         outs.append((o["loss_g"].detach().cpu(), o["loss_d"].detach().cpu(), ts.pflat.detach().cpu().clone()))
         assert torch.isfinite(outs[-1][0]).all() and torch.isfinite(outs[-1][2]).all()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_train_step_with_fixed_sigma_spectrum_loss():
+    """--SL_weight on the plain-FCM model (features un-blurred by the model, blurred with a fixed sigma by the loss,
+    losses/vqgan_losses.py:34-50).  DSL is off: with both terms on the reference reverses dec_feats twice and pairs features of
+    different shapes (its FFL then raises), so the two are mutually exclusive there as well."""
+    from favae_step import TrainStep
+    model, cfg, state = build("ffl_with_fcm")
+    ts = TrainStep(model, lr=1e-4, dsl_weight=0.0, sl_weight=0.02, gaussian_kernel=5, gaussian_sigma=1.3)
+    orc = O.OracleTrainer(cfg, O.StepConfig(lr=1e-4, dsl_weight=0.0, with_disc_forward=True, sl_weight=0.02, gaussian_kernel=5,
+                                            gaussian_sigma=1.3), state)
+    x = O.det_input(2, 64, 64, 100)
+    ro = orc.step(x)
+    out = ts.step(x.to(DEV))
+    for k in ("loss_l1", "loss_quant", "loss_ffl", "loss_sl", "loss_g"):
+        close(out[k].reshape(-1), ro[k].reshape(-1), 1e-4, k)
+    for a, b in zip(out["loss_sl_levels"], ro["loss_sl_levels"]):
+        close(a.reshape(-1), b.reshape(-1), 1e-4, "SL level")
+    named = dict(model.named_parameters())
+    worst = 0.0
+    for k in orc.keys:
+        go = ro["grads"].get(k)
+        if go is None or float(go.abs().max()) <= 1e-6:
+            continue
+        worst = max(worst, rel(named[k].grad, go))
+    assert worst < 2e-3, f"gradients with the SL term: worst per-tensor max-rel {worst:.3e}"

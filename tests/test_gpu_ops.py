@@ -526,3 +526,30 @@ def test_scaling_layer_against_reference_golden(K, golden_dir):
     (gx,) = torch.autograd.grad(y.sum(), x)
     want = (1.0 / torch.tensor([.458, .448, .450])).view(1, 3, 1, 1).expand(2, 3, 8, 8)
     check(gx, want, 1e-6, "ScalingLayer gradient")
+
+
+def test_spectrum_loss_fixed_sigma(K):
+    """recon_sl_gaussian_features_loss (losses/vqgan_losses.py:34-50): fixed-sigma blur of both feature lists + DSL sum, value
+    and gradients to both sides against the oracle; the in-place reverse of de_feat is preserved."""
+    from focal_frequency_loss import FocalFrequencyLoss
+    from losses.vqgan_losses import recon_sl_gaussian_features_loss
+    shapes = [(2, 32, 32, 32), (2, 64, 16, 16), (2, 64, 16, 16), (2, 32, 16, 16)]
+    en = [rnd(s, 50 + i) for i, s in enumerate(shapes)]
+    de = [rnd(s, 60 + i) for i, s in enumerate(reversed(shapes))]
+    for ks, sigma in ((9, 3.0), (3, 0.8)):
+        en_r = [t.clone().requires_grad_(True) for t in en]
+        de_r = [t.clone().requires_grad_(True) for t in de]
+        de_list = list(de_r)
+        ref, ref_l = O.recon_sl_gaussian_features_loss(ks, sigma, en_r, de_list, 0.01)
+        g_ref = torch.autograd.grad(ref.sum(), en_r + de_r)
+        en_d = [t.to(dev()).requires_grad_(True) for t in en]
+        de_d = [t.to(dev()).requires_grad_(True) for t in de]
+        de_dl = list(de_d)
+        got, got_l = recon_sl_gaussian_features_loss(FocalFrequencyLoss(loss_weight=0.01, alpha=1.0), ks, sigma, en_d, de_dl, dev())
+        assert de_dl[0] is de_d[3], "de_feat must be reversed in place"
+        check(got, ref, 1e-4, "SL value")
+        for a, b in zip(got_l, ref_l):
+            check(a.reshape(-1), b.reshape(-1), 1e-4, "SL level")
+        g_got = torch.autograd.grad(got.sum(), en_d + de_d)
+        for i, (a, b) in enumerate(zip(g_got, g_ref)):
+            check(a, b, 2e-4, "SL gradient %d" % i)
