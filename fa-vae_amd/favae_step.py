@@ -70,6 +70,75 @@ class TrainStep:
             self.dparams = list(model.discriminator.parameters())
             self.dpflat, self.dgflat, self.dmflat, self.dvflat = _flatten(self.dparams, dev)
 
+    # ------------------------------------------------------------------------------------------------------------
+    # checkpoint wire format of the reference (train_favae.py:366-379): {"model", "opt_g", "opt_d", "epoch", "step", "loss_recon"}
+    # with opt_* = torch.optim.Adam.state_dict().  The flat moment buffers are exported / imported in that layout, so a
+    # checkpoint written here loads into the reference's optimizers (and vice versa).
+    # ------------------------------------------------------------------------------------------------------------
+    def _adam_state_dict(self, groups, mflat, vflat, step):
+        state, pgroups, idx, off = {}, [], 0, 0
+        for params, lr in groups:
+            ids = []
+            for p in params:
+                n = p.numel()
+                if step > 0:
+                    state[idx] = {"step": torch.tensor(float(step)),
+                                  "exp_avg": mflat[off:off + n].as_strided(p.shape, p.stride()).clone(),
+                                  "exp_avg_sq": vflat[off:off + n].as_strided(p.shape, p.stride()).clone()}
+                ids.append(idx)
+                idx += 1
+                off += n
+            pgroups.append({"lr": lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                            "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                            "decoupled_weight_decay": False, "params": ids})
+        return {"state": state, "param_groups": pgroups}
+
+    def _load_adam_state(self, sd, params, mflat, vflat):
+        off, step = 0, 0
+        for i, p in enumerate(params):
+            n = p.numel()
+            st = sd["state"].get(i)
+            if st is not None:
+                mflat[off:off + n].as_strided(p.shape, p.stride()).copy_(st["exp_avg"])
+                vflat[off:off + n].as_strided(p.shape, p.stride()).copy_(st["exp_avg_sq"])
+                step = max(step, int(st["step"]))
+            else:
+                mflat[off:off + n].zero_()
+                vflat[off:off + n].zero_()
+            off += n
+        return step
+
+    def _g_groups(self):
+        n_main_params = len(self.params) - (1 if hasattr(self.model, "sigmas") else 0)
+        groups = [(self.params[:n_main_params], self.lr)]
+        if n_main_params < len(self.params):
+            groups.append((self.params[n_main_params:], self.sigma_lr))       # train_favae.py:296-299
+        return groups
+
+    def opt_g_state_dict(self):
+        return self._adam_state_dict(self._g_groups(), self.mflat, self.vflat, self.t)
+
+    def opt_d_state_dict(self):
+        if not self.train_disc:              # the reference creates (and saves) opt_d even when it never steps: empty state
+            return self._adam_state_dict([(list(self.model.discriminator.parameters()), self.lr)], None, None, 0)
+        return self._adam_state_dict([(self.dparams, self.lr)], self.dmflat, self.dvflat, self.t)
+
+    def load_opt_state_dicts(self, opt_g=None, opt_d=None):
+        """Resume the optimizer moments and step count from torch.optim.Adam state dicts (the reference saves them but only
+        restores the model on --resume, train_favae.py:335-341; restoring them is optional here too)."""
+        if opt_g is not None:
+            self.t = self._load_adam_state(opt_g, self.params, self.mflat, self.vflat)
+        if opt_d is not None and self.train_disc:
+            self.t = max(self.t, self._load_adam_state(opt_d, self.dparams, self.dmflat, self.dvflat))
+
+    def checkpoint(self, epoch, step, loss_recon=None):
+        """the dict the reference hands to utils.save_model (train_favae.py:366-374)"""
+        state = {"model": self.model.state_dict(), "opt_g": self.opt_g_state_dict(), "opt_d": self.opt_d_state_dict(),
+                 "epoch": epoch, "step": step}
+        if loss_recon is not None:
+            state["loss_recon"] = loss_recon
+        return state
+
     def losses(self, x):
         """Forward + loss assembly of train() :75-102."""
         m = self.model
