@@ -32,23 +32,47 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA (MI355X_MICROARCH
 SPLIT_PRODUCTS = {2: 3, 3: 6}         # 16-bit MFMA products issued per fp32 multiply-add: planes -> products (conv_split.h)
 
 
+# name -> (description, codebook, n_embed, model kwargs, oracle config kwargs, default batch per GPU)
+CONFIGS = {
+    "celeba_f16": ("BASELINE configs[1]: FA-VAE f=16 CelebA-HQ config, codebook %d, embed_dim 256, residual FCM + non-pairwise DSL "
+                   "(k=9, sigma0=3)", 16384, 256,
+                   dict(ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_gauss_resblock=True),
+                   dict(variant="gauss_resblock"), 32),
+    "imagenet_f4": ("BASELINE configs[3]: FA-VAE f=4 ImageNet config, codebook %d, embed_dim 3 projected to codebook_dim 256, "
+                    "ch_mult (1,2,4), conv FCM with one sigma per pair (use_same_conv_gauss, num_groups 3, k=9, sigma0=3)", 8192, 3,
+                    dict(ch_mult=(1, 2, 4), attn_resolutions=[], codebook_dim=256, use_same_conv_gauss=True, num_groups=3),
+                    dict(n_embed=3, ch_mult=(1, 2, 4), attn_resolutions=(), codebook_dim=256, variant="same_conv_gauss", num_groups=3), 16),
+    "ffhq_f16": ("model of BASELINE configs[4]: FA-VAE f=16 FFHQ config, codebook %d, embed_dim 256, conv FCM with one sigma per pair "
+                 "(use_same_conv_gauss, num_groups 32, k=9, sigma0=3), fp32", 2048, 256,
+                 dict(ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_same_conv_gauss=True, num_groups=32),
+                 dict(variant="same_conv_gauss", num_groups=32), 32),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE config: 32)")
-    ap.add_argument("--codebook", type=int, default=16384)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the config's, 32 for celeba_f16)")
+    ap.add_argument("--codebook", type=int, default=None, help="codebook size (default: the config's)")
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gan", action="store_true",
                     help="also train the discriminator (BASELINE config-5 wiring: hinge terms, adaptive weight, stage 1; perceptual "
                          "term off) -- not the headline workload, reported under config.workload")
+    ap.add_argument("--config", default="celeba_f16", choices=sorted(CONFIGS),
+                    help="celeba_f16 = BASELINE configs[1] (the headline metric, default); imagenet_f4 = configs[3]; ffhq_f16 = "
+                         "the model of configs[4] (add --gan --lpips for its loss path; fp32 here, not bf16)")
     ap.add_argument("--lpips", action="store_true",
                     help="add the perceptual term lpips(x, x_recon) (train_favae.py:77-79) on deterministic stand-in VGG16/lin "
                          "weights (vgg16_lpips.pt is not available offline: timing only) -- not the headline workload")
     ap.add_argument("--cpu-batch", type=int, default=8, help="images in the bounded CPU-baseline sample")
-    return ap.parse_args()
+    args = ap.parse_args()
+    desc, cb, n_embed, mk, ok, batch = CONFIGS[args.config]
+    args.codebook = args.codebook or cb
+    args.batch = args.batch or batch
+    return args
 
 
 class ConvEventHook:
@@ -118,7 +142,7 @@ def cpu_baseline(args, torch):
     import favae_oracle as O
     ncores = usable_cores(torch)
     torch.set_num_threads(ncores)
-    cfg = O.OracleConfig(codebook_size=args.codebook, variant="gauss_resblock", kernel_size=9)
+    cfg = O.OracleConfig(codebook_size=args.codebook, kernel_size=9, **CONFIGS[args.config][4])
     sc = O.StepConfig(lr=4.5e-6 * args.batch, with_disc_forward=True)
     tr = O.OracleTrainer(cfg, sc)
     B = args.cpu_batch
@@ -127,7 +151,7 @@ def cpu_baseline(args, torch):
     tr.step(O.det_input(B, args.res, args.res, 1235))
     dt = time.perf_counter() - t0
     return {"value": B / dt, "unit": "images/s", "cores": ncores, "kind": "port",
-            "sample": f"1 timed training step (after 1 warm-up step) of the same f=16 config at batch {B}, "
+            "sample": f"1 timed training step (after 1 warm-up step) of the same {args.config} config at batch {B}, "
                       f"oracle/favae_oracle.py on torch {torch.__version__} CPU, {dt:.1f} s"}
 
 
@@ -159,9 +183,9 @@ def main():
 
     favae_hip.load()
     torch.manual_seed(0)                           # favae_scripts/train_favae.py:235
-    model = VQGANFCM(args.codebook, 256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
-                     use_l2_quantizer=True, sync_codebook=use_dist, commitment_weight=1.0, kernel_size=9, dsl_init_sigma=3.0,
-                     device=dev, use_gauss_resblock=True).to(dev)
+    desc, _, n_embed, mk, _, _ = CONFIGS[args.config]
+    model = VQGANFCM(args.codebook, n_embed, use_cosine_sim=True, use_l2_quantizer=True, sync_codebook=use_dist,
+                     commitment_weight=1.0, kernel_size=9, dsl_init_sigma=3.0, device=dev, **mk).to(dev)
     lr = 4.5e-6 * args.batch * world               # train_favae.py:250-251
     lpips = None
     if args.lpips:
@@ -215,7 +239,7 @@ def main():
     if rank == 0:
         conv = hook.summary()
         res = {
-            "metric": "images/sec (256x256, f=16 FA-VAE train step)",
+            "metric": "images/sec (256x256, f=16 FA-VAE train step)" if args.config == "celeba_f16" else "images/sec (%dx%d FA-VAE train step, config %s)" % (args.res, args.res, args.config),
             "value": args.batch * world * args.steps / dt,
             "unit": "images/s",
             "n_gpus": world,
@@ -227,9 +251,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: FA-VAE f=16 CelebA-HQ config, codebook %d, embed_dim 256, residual FCM + "
-                                   "non-pairwise DSL (k=9, sigma0=3), FFL 1.0 + DSL 0.01, %dx%d, batch %d per GPU, stage-0 step "
-                                   "(LPIPS/disc training off, disc forward on)" % (args.codebook, args.res, args.res, args.batch)
+            "config": {"workload": (desc % args.codebook) + ", FFL 1.0 + DSL 0.01, %dx%d, batch %d per GPU, stage-0 step "
+                                   "(LPIPS/disc training off, disc forward on)" % (args.res, args.res, args.batch)
                                    + (" + discriminator training (hinge, adaptive weight, stage 1)" if args.gan else "")
                                    + (" + LPIPS perceptual term (stand-in weights)" if args.lpips else ""),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss_g_last": loss},
