@@ -29,7 +29,7 @@ for p in (os.path.join(ROOT, "fa-vae_amd"), os.path.join(ROOT, "oracle")):
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
 PEAK_16BIT_MFMA_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
-SPLIT_PRODUCTS = {2: 3, 3: 6}         # 16-bit MFMA products issued per fp32 multiply-add: planes -> products (conv_split.h)
+SPLIT_PRODUCTS = {1: 1, 2: 3, 3: 6}        # 16-bit MFMA products issued per fp32 multiply-add: planes -> products (conv_split.h)
 
 
 # name -> (description, codebook, n_embed, model kwargs, oracle config kwargs, default batch per GPU)
@@ -67,6 +67,11 @@ def parse():
     ap.add_argument("--lpips", action="store_true",
                     help="add the perceptual term lpips(x, x_recon) (train_favae.py:77-79) on deterministic stand-in VGG16/lin "
                          "weights (vgg16_lpips.pt is not available offline: timing only) -- not the headline workload")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
+                    help="fp32 (default, the headline: fp32-grade convs by operand splitting, parity 1e-4) or fp16 = the 16-bit "
+                         "mixed-precision mode asked for by BASELINE configs[4] (conv operands rounded to ONE scaled fp16 plane, fp32 "
+                         "accumulation, everything else fp32; like the reference under accelerate mixed precision) -- not the "
+                         "headline workload, reported as dtype f16 and under config.workload")
     ap.add_argument("--cpu-batch", type=int, default=8, help="images in the bounded CPU-baseline sample")
     args = ap.parse_args()
     desc, cb, n_embed, mk, ok, batch = CONFIGS[args.config]
@@ -182,6 +187,9 @@ def main():
     from models.vqgan_fcm import VQGANFCM
 
     favae_hip.load()
+    if args.precision == "fp16":
+        from favae_hip import ops as _Kp
+        _Kp.set_conv_mode("h1")
     torch.manual_seed(0)                           # favae_scripts/train_favae.py:235
     desc, _, n_embed, mk, _, _ = CONFIGS[args.config]
     model = VQGANFCM(args.codebook, n_embed, use_cosine_sim=True, use_l2_quantizer=True, sync_codebook=use_dist,
@@ -249,12 +257,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.precision == "fp32" else "f16",
             "data": "synthetic",
             "config": {"workload": (desc % args.codebook) + ", FFL 1.0 + DSL 0.01, %dx%d, batch %d per GPU, stage-0 step "
                                    "(LPIPS/disc training off, disc forward on)" % (args.res, args.res, args.batch)
                                    + (" + discriminator training (hinge, adaptive weight, stage 1)" if args.gan else "")
-                                   + (" + LPIPS perceptual term (stand-in weights)" if args.lpips else ""),
+                                   + (" + LPIPS perceptual term (stand-in weights)" if args.lpips else "")
+                                   + (" -- MIXED PRECISION: conv operands in one scaled fp16 plane (FAVAE_CONV_MODE=h1), fp32 "
+                                      "accumulation; not fp32-grade, not the headline" if args.precision == "fp16" else ""),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss_g_last": loss},
         }
         if conv:

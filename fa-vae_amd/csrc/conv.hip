@@ -29,17 +29,20 @@ bool force_generic() {
 }
 // 128-wide convs run on the split-precision matrix path (conv_split.h).  FAVAE_CONV_MODE = h3 (default: two scaled fp16
 // planes, 3 MFMAs, needs operand maxima) | b6 (three bf16 planes, 6 MFMAs) | fp32 (the fp32-MFMA kernels; also FAVAE_CONV_B6=0).
-// Returns the number of planes: 2, 3 or 0.
+// h1 = ONE scaled fp16 plane, 1 MFMA: the 16-bit mixed-precision mode, not fp32-grade (BASELINE config 5).
+// Returns the number of planes: 1, 2, 3 or 0.  favae_set_conv_mode overrides the environment at run time.
+static int g_conv_mode = -1;
 int conv_mode() {
-    static int v = -1;
-    if (v < 0) {
+    if (g_conv_mode < 0) {
         const char* e = getenv("FAVAE_CONV_MODE");
         const char* b = getenv("FAVAE_CONV_B6");
-        v = 2;
+        int v = 2;
         if (e && e[0] == 'b') v = 3;
+        else if (e && e[0] == 'h' && e[1] == '1') v = 1;
         else if ((e && e[0] == 'f') || (b && b[0] == '0')) v = 0;
+        g_conv_mode = v;
     }
-    return v;
+    return g_conv_mode;
 }
 bool use_b6() { return conv_mode() != 0; }
 // FAVAE_WGRAD_ROW3=0 disables the three-taps-per-workgroup weight-gradient kernel (A/B switch)
@@ -699,13 +702,25 @@ static bool sp_fwd_eligible(const favae_conv_desc* d, bool has_affine) {
     return d->Cout > 64 && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) && (d->gather == FAVAE_GATHER_PLAIN || !has_affine);
 }
 
+static int wrec_bytes(int planes) {
+    return planes == 1 ? sp::Scheme<1>::WREC : (planes == 2 ? sp::Scheme<2>::WREC : sp::Scheme<3>::WREC);
+}
+
+extern "C" int favae_set_conv_mode(int planes) {
+    FAVAE_REQUIRE(planes >= 0 && planes <= 3);
+    g_conv_mode = planes;
+    return FAVAE_OK;
+}
+
+extern "C" int favae_get_conv_mode(void) { return conv_mode(); }
+
 extern "C" int favae_conv_wants_split_weights(const favae_conv_desc* d, int has_affine) {
     return sp_fwd_eligible(d, has_affine != 0) ? conv_mode() : 0;
 }
 
 extern "C" size_t favae_split_weights_bytes(int64_t n, int planes) {
-    if (n <= 0 || n % 4 || (planes != 2 && planes != 3)) return 0;
-    return (size_t)sp::WHDR + (size_t)(n / 4) * (planes == 2 ? sp::Scheme<2>::WREC : sp::Scheme<3>::WREC);
+    if (n <= 0 || n % 4 || planes < 1 || planes > 3) return 0;
+    return (size_t)sp::WHDR + (size_t)(n / 4) * wrec_bytes(planes);
 }
 
 namespace {
@@ -746,17 +761,21 @@ extern "C" int favae_absmax(const float* x, int64_t n, float* out, favae_stream_
 }
 
 extern "C" int favae_split_weights(const float* in, void* out, int64_t n, int planes, favae_stream_t stream) {
-    FAVAE_REQUIRE(in && out && n > 0 && n % 4 == 0 && (planes == 2 || planes == 3));
+    FAVAE_REQUIRE(in && out && n > 0 && n % 4 == 0 && planes >= 1 && planes <= 3);
     FAVAE_REQUIRE((((uintptr_t)out) & 15) == 0);
     hipStream_t s = (hipStream_t)stream;
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     unsigned* rec = (unsigned*)((char*)out + sp::WHDR);
-    if (planes == 2) {
+    if (planes <= 2) {
         const int rc = launch_absmax(in, n, (float*)out, s);
         if (rc != FAVAE_OK) return rc;
-        hipLaunchKernelGGL((split_w_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
-                           (const float*)out);
+        if (planes == 2)
+            hipLaunchKernelGGL((split_w_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
+                               (const float*)out);
+        else
+            hipLaunchKernelGGL((split_w_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
+                               (const float*)out);
     } else {
         hipLaunchKernelGGL((split_w_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
                            (const float*)nullptr);
@@ -779,7 +798,7 @@ extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, co
                                     const float* x_absmax, const float* bias, const float* resid, const float* scale,
                                     const float* shift, float* y, favae_stream_t stream) {
     if (!sp_fwd_eligible(d, scale != nullptr)) return FAVAE_ERR_UNSUPPORTED;
-    FAVAE_REQUIRE(wsplit && (planes == 3 || (planes == 2 && x_absmax)));
+    FAVAE_REQUIRE(wsplit && (planes == 3 || ((planes == 2 || planes == 1) && x_absmax)));
     return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream);
 }
 
@@ -856,7 +875,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
                         (size_t)d->N * a.out_img * d->Cout * 4 < ((size_t)1 << 32) && (d->gather == FAVAE_GATHER_PLAIN || xf == 0);
     if (special && !(buf_ok && use_b6() && bn == 128 && w6 && d->gather == FAVAE_GATHER_PLAIN)) return FAVAE_ERR_UNSUPPORTED;
     a.x_bytes = (unsigned)xb; a.aff_bytes = (unsigned)ab;
-    a.w_bytes = (unsigned)(wplanes == 3 ? wb / 16 * sp::Scheme<3>::WREC : (wplanes == 2 ? wb / 16 * sp::Scheme<2>::WREC : wb));
+    a.w_bytes = (unsigned)(wplanes ? wb / 16 * wrec_bytes(wplanes) : wb);
 #define FAVAE_LAUNCH_BUF(G, X)                                                                                     \
     do {                                                                                                           \
         if (bn == 128) hipLaunchKernelGGL((conv_fwd_buf_kernel<128, 2, 2, G, X>), grid, blk, 0, s, a);             \
@@ -872,6 +891,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
 #define FAVAE_LAUNCH_HALO(X)                                                                              \
     do {                                                                                                  \
         if (wplanes == 2) hipLaunchKernelGGL((conv3x3_halo_sp_kernel<X, 2>), hgrid, dim3(512), 0, s, a);  \
+        else if (wplanes == 1) hipLaunchKernelGGL((conv3x3_halo_sp_kernel<X, 1>), hgrid, dim3(512), 0, s, a); \
         else hipLaunchKernelGGL((conv3x3_halo_sp_kernel<X, 3>), hgrid, dim3(512), 0, s, a);               \
     } while (0)
         if (xf == 0) FAVAE_LAUNCH_HALO(0);
@@ -883,6 +903,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
 #define FAVAE_LAUNCH_B6(G, X)                                                                     \
     do {                                                                                          \
         if (wplanes == 2) hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, true, 8, 2>), grid, dim3(512), 0, s, a);        \
+        else if (wplanes == 1) hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, true, 8, 1>), grid, dim3(512), 0, s, a);   \
         else if (b6_waves() == 8) {                                                               \
             if (w6) hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, true, 8, 3>), grid, dim3(512), 0, s, a);   \
             else hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, false, 8, 3>), grid, dim3(512), 0, s, a);     \
@@ -937,7 +958,8 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
                                 void* ws, size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && x && dy && dw && ws);
     // fp16 planes need both operand maxima; without them the bf16 scheme (no range restrictions) runs
-    const int np = (conv_mode() == 2 && x_absmax && dy_absmax) ? 2 : 3;
+    const int cm = conv_mode();
+    const int np = ((cm == 2 || cm == 1) && x_absmax && dy_absmax) ? cm : 3;
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     if (ws_bytes < favae_conv_wgrad_workspace(d)) return FAVAE_ERR_WORKSPACE;
     {
@@ -1034,6 +1056,7 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
 #define FAVAE_LAUNCH_ROW3(X)                                                                              \
     do {                                                                                                  \
         if (np == 2) hipLaunchKernelGGL((conv_wgrad_row3_sp_kernel<X, 2>), g3, dim3(512), 0, s, a);       \
+        else if (np == 1) hipLaunchKernelGGL((conv_wgrad_row3_sp_kernel<X, 1>), g3, dim3(512), 0, s, a);  \
         else hipLaunchKernelGGL((conv_wgrad_row3_sp_kernel<X, 3>), g3, dim3(512), 0, s, a);               \
     } while (0)
         if (xf == 0) FAVAE_LAUNCH_ROW3(0);
@@ -1044,6 +1067,7 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
 #define FAVAE_LAUNCH_WSP(X, U)                                                                            \
     do {                                                                                                  \
         if (np == 2) hipLaunchKernelGGL((conv_wgrad_sp_kernel<X, U, 2>), grid, dim3(256), 0, s, a);       \
+        else if (np == 1) hipLaunchKernelGGL((conv_wgrad_sp_kernel<X, U, 1>), grid, dim3(256), 0, s, a);  \
         else hipLaunchKernelGGL((conv_wgrad_sp_kernel<X, U, 3>), grid, dim3(256), 0, s, a);               \
     } while (0)
         if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_WSP(0, true);
@@ -1174,7 +1198,7 @@ __global__ __launch_bounds__(256) void weight_flip_split_kernel(const float* __r
         tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * KH * KW + tap) * Cin + ci] : 0.f;
     }
     __syncthreads();
-    const float Sw = (NP == 2 && amax_src) ? sp::pow2_scale(amax_src) : 1.f;
+    const float Sw = (sp::Scheme<NP>::SCALED && amax_src) ? sp::pow2_scale(amax_src) : 1.f;
     const int tapf = (KH - 1 - kh) * KW + (KW - 1 - kw);
     // 32 ci x 8 co-quads = 256 records per tile: thread -> (ci = tid / 8, quad = tid % 8)
     const int r = threadIdx.x >> 3, qd = threadIdx.x & 7;
@@ -1192,11 +1216,14 @@ __global__ __launch_bounds__(256) void weight_flip_split_kernel(const float* __r
 
 extern "C" int favae_weight_flip_split(const float* w, void* out, int Cout, int KH, int KW, int Cin, int planes,
                                        const float* absmax_src, favae_stream_t stream) {
-    FAVAE_REQUIRE(w && out && Cout > 0 && KH > 0 && KW > 0 && Cin > 0 && Cout % 4 == 0 && (planes == 3 || (planes == 2 && absmax_src)));
+    FAVAE_REQUIRE(w && out && Cout > 0 && KH > 0 && KW > 0 && Cin > 0 && Cout % 4 == 0 && (planes == 3 || ((planes == 2 || planes == 1) && absmax_src)));
     FAVAE_REQUIRE((((uintptr_t)out) & 15) == 0);
     dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), KH * KW);
     if (planes == 2)
         hipLaunchKernelGGL((weight_flip_split_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, Cout, KH, KW,
+                           Cin, absmax_src);
+    else if (planes == 1)
+        hipLaunchKernelGGL((weight_flip_split_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, Cout, KH, KW,
                            Cin, absmax_src);
     else
         hipLaunchKernelGGL((weight_flip_split_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, Cout, KH, KW,
@@ -1215,7 +1242,7 @@ template <int NP>
 __global__ __launch_bounds__(256) void downsample_dgrad_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
                                                                        int Cout, int Cin, const float* __restrict__ amax_src) {
     if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(out)[0] = amax_src ? amax_src[0] : 0.f;
-    const float Sw = (NP == 2 && amax_src) ? sp::pow2_scale(amax_src) : 1.f;
+    const float Sw = (sp::Scheme<NP>::SCALED && amax_src) ? sp::pow2_scale(amax_src) : 1.f;
     const size_t q = Cout / 4, per_tap = (size_t)Cin * q;          // records per (phase tap)
     const size_t total = 9 * per_tap;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -1247,12 +1274,15 @@ __global__ __launch_bounds__(256) void downsample_dgrad_weights_kernel(const flo
 
 extern "C" int favae_downsample_dgrad_weights(const float* w, void* out, int Cout, int Cin, int planes, const float* absmax_src,
                                               favae_stream_t stream) {
-    FAVAE_REQUIRE(w && out && Cout > 0 && Cin > 0 && Cout % 4 == 0 && (planes == 3 || (planes == 2 && absmax_src)));
+    FAVAE_REQUIRE(w && out && Cout > 0 && Cin > 0 && Cout % 4 == 0 && (planes == 3 || ((planes == 2 || planes == 1) && absmax_src)));
     FAVAE_REQUIRE((((uintptr_t)out) & 15) == 0);
     const size_t total = (size_t)9 * Cin * (Cout / 4);
     const unsigned blocks = (unsigned)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
     if (planes == 2)
         hipLaunchKernelGGL((downsample_dgrad_weights_kernel<2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
+                           Cout, Cin, absmax_src);
+    else if (planes == 1)
+        hipLaunchKernelGGL((downsample_dgrad_weights_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
                            Cout, Cin, absmax_src);
     else
         hipLaunchKernelGGL((downsample_dgrad_weights_kernel<3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,

@@ -1,5 +1,5 @@
 // fp32 convolutions on the 16-bit matrix pipe by exact operand splitting (included by conv.hip).  Default conv path;
-// FAVAE_CONV_MODE=h3|b6|fp32 selects the scheme (fp32 = the fp32-MFMA kernels of conv_buf.h / conv_fast.h / conv.hip).
+// FAVAE_CONV_MODE=h3|b6|fp32|h1 selects the scheme (fp32 = the fp32-MFMA kernels of conv_buf.h / conv_fast.h / conv.hip).
 //
 // Scheme<3> "b6" -- three bf16 planes by truncation, a = a1 + a2 + a3 (8 + 8 + 8 significand bits, exact); products of two
 //   bf16 are exact in fp32, and keeping the six terms with i + j <= 4 (a1b1, a1b2, a2b1, a2b2, a1b3, a3b1) leaves a relative
@@ -44,6 +44,7 @@ __device__ __forceinline__ float pow2_inv(float S) {
 template <int NP> struct Scheme;
 
 template <> struct Scheme<3> {
+    static constexpr bool SCALED = false;  // bf16 keeps the fp32 exponent: no operand ranges needed
     static constexpr int ROWB = 112;       // LDS row: 3 planes x 32 B (16 k) + 16 B pad -> conflict-free ds_read_b128
     static constexpr int WREC = 24;        // bytes per pre-split 4-float weight record {plane0[4], plane1[4], plane2[4]}
     // split four consecutive-k floats into three planes of 4 bf16 (2 dwords each), exact by truncation
@@ -75,6 +76,7 @@ template <> struct Scheme<3> {
 };
 
 template <> struct Scheme<2> {
+    static constexpr bool SCALED = true;
     static constexpr int ROWB = 80;        // 2 planes x 32 B + 16 B pad (20-bank row stride: conflict-free ds_read_b128)
     static constexpr int WREC = 16;        // {plane0[4 fp16], plane1[4]}
     static __device__ __forceinline__ void split4(const float4 v, float S, uint2 (&p)[2]) {
@@ -98,13 +100,33 @@ template <> struct Scheme<2> {
     }
 };
 
+// "h1": ONE scaled fp16 plane, one MFMA per product block -- the mixed-precision mode (fp16 operands with an 11-bit
+// significand, fp32 accumulation; BASELINE config 5 asks for 16-bit compute).  Same power-of-two scaling as h3, so the fp16
+// exponent range is never the limit.  NOT fp32-grade: per-product relative error ~2^-12 (FAVAE_CONV_MODE=h1 / favae_set_conv_mode(1)).
+template <> struct Scheme<1> {
+    static constexpr bool SCALED = true;
+    static constexpr int ROWB = 48;        // 32 B + 16 B pad (12-bank row stride: 16 consecutive rows hit 16 distinct bank quads)
+    static constexpr int WREC = 8;         // {plane0[4 fp16]}
+    static __device__ __forceinline__ void split4(const float4 v, float S, uint2 (&p)[1]) {
+        const half2_t h01 = {(_Float16)(v.x * S), (_Float16)(v.y * S)}, h23 = {(_Float16)(v.z * S), (_Float16)(v.w * S)};
+        p[0] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+    }
+    static __device__ __forceinline__ void mma(const bf16x8_t (&a)[1], const bf16x8_t (&b)[1], f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a[0]), __builtin_bit_cast(half8_t, b[0]), c, 0, 0, 0);
+    }
+};
+
 // one pre-split weight record (4 consecutive k) -> NP plane pieces
 template <int NP, typename R>
 __device__ __forceinline__ void load_wrec(R rw, unsigned voff, unsigned soff, uint2 (&p)[NP]) {
-    const float4 t = bload(rw, voff, soff);
-    p[0] = make_uint2(__float_as_uint(t.x), __float_as_uint(t.y));
-    p[1] = make_uint2(__float_as_uint(t.z), __float_as_uint(t.w));
-    if constexpr (NP == 3) p[2] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rw, voff + 16u, soff, 0));
+    if constexpr (NP == 1) {
+        p[0] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rw, voff, soff, 0));
+    } else {
+        const float4 t = bload(rw, voff, soff);
+        p[0] = make_uint2(__float_as_uint(t.x), __float_as_uint(t.y));
+        p[1] = make_uint2(__float_as_uint(t.z), __float_as_uint(t.w));
+        if constexpr (NP == 3) p[2] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rw, voff + 16u, soff, 0));
+    }
 }
 
 template <int NP>
@@ -148,7 +170,7 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_sp_kernel(ConvArgs a) {
     const int m0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
     const int q4 = tid & 3, c4 = q4 * 4;
     const int taps = a.KH * a.KW;
-    const float Sa = NP == 2 ? sp::pow2_scale(a.x_amax) : 1.f;
+    const float Sa = S::SCALED ? sp::pow2_scale(a.x_amax) : 1.f;
 
     const auto rx = make_rsrc(a.x, a.x_bytes);
     const auto rw = make_rsrc(a.w, a.w_bytes);
@@ -265,7 +287,7 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_sp_kernel(ConvArgs a) {
     }
 
     float un_a = 1.f, un_w = 1.f;
-    if constexpr (NP == 2) { un_a = sp::pow2_inv(Sa); un_w = sp::pow2_inv(sp::pow2_scale(a.w_amax)); }
+    if constexpr (S::SCALED) { un_a = sp::pow2_inv(Sa); un_w = sp::pow2_inv(sp::pow2_scale(a.w_amax)); }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -285,7 +307,7 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_sp_kernel(ConvArgs a) {
                         o = ((size_t)on * a.out_img + (size_t)oh * a.out_step * a.out_row + ow * a.out_step + a.out_off) * a.Cout + col;
                     }
                     float v = acc[i][j][r];
-                    if constexpr (NP == 2) v = v * un_a * un_w;
+                    if constexpr (S::SCALED) v = v * un_a * un_w;
                     v += bv;
                     if (a.resid) v += a.resid[o];
                     a.y[o] = v;
@@ -325,7 +347,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_sp_kernel(WgradArgs a) {
     const int p_begin = z * a.chunk;
     const int p_end = min(a.M, p_begin + a.chunk);
     const int T = (p_end > p_begin) ? (p_end - p_begin + BKP - 1) / BKP : 0;
-    const float So = NP == 2 ? sp::pow2_scale(a.dy_amax) : 1.f, Si = NP == 2 ? sp::pow2_scale(a.x_amax) : 1.f;
+    const float So = S::SCALED ? sp::pow2_scale(a.dy_amax) : 1.f, Si = S::SCALED ? sp::pow2_scale(a.x_amax) : 1.f;
 
     const auto rx = make_rsrc(a.x, a.x_bytes);
     // dense dy: rows >= p_end read as zeros through the descriptor's range check; dy on a sub-grid (a.dy_step == 2, dispatcher
@@ -443,7 +465,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_sp_kernel(WgradArgs a) {
         __syncthreads();
     }
     float un_o = 1.f, un_i = 1.f;
-    if constexpr (NP == 2) { un_o = sp::pow2_inv(So); un_i = sp::pow2_inv(Si); }
+    if constexpr (S::SCALED) { un_o = sp::pow2_inv(So); un_i = sp::pow2_inv(Si); }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -454,7 +476,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_sp_kernel(WgradArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wo * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 float v = acc[i][j][r];
-                if constexpr (NP == 2) v = v * un_o * un_i;
+                if constexpr (S::SCALED) v = v * un_o * un_i;
                 if (co < a.Cout) a.part[(((size_t)z * a.Cout + co) * taps + tap) * a.Cin + ci] = v;
             }
         }
@@ -465,7 +487,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_sp_kernel(WgradArgs a) {
 template <int NP>
 __global__ __launch_bounds__(256) void split_w_kernel(const float4* __restrict__ in, unsigned* __restrict__ out, size_t n4,
                                                       const float* __restrict__ amax) {
-    const float Sw = NP == 2 ? sp::pow2_scale(amax) : 1.f;
+    const float Sw = sp::Scheme<NP>::SCALED ? sp::pow2_scale(amax) : 1.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         uint2 p[NP];
         sp::Scheme<NP>::split4(in[i], Sw, p);
@@ -486,7 +508,7 @@ __global__ __launch_bounds__(256) void split_w_kernel(const float4* __restrict__
 // Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, H % 8 == 0, W % 16 == 0, Cin % 16 == 0, pre-split weights.
 // ---------------------------------------------------------------------------------------------------------------
 template <int XFORM, int NP>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP == 2 ? 6 : 4, 8))) void conv3x3_halo_sp_kernel(ConvArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6 : 4, 8))) void conv3x3_halo_sp_kernel(ConvArgs a) {
     using S = sp::Scheme<NP>;
     constexpr int TH = 8, TW = 16, HW = TW + 2, HROWS = (TH + 2) * HW;          // 180 halo pixels
     // halo row pitch = 18 rows rounded up to a multiple of 256 B: pitch % 256 == 0 puts the second tile row of a wave's 32 MFMA
@@ -509,7 +531,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP == 2 ? 6
     const int n = spt / tiles_h;
     const int n0 = tn * 128;
     const int q4 = tid & 3;
-    const float Sa = NP == 2 ? sp::pow2_scale(a.x_amax) : 1.f;
+    const float Sa = S::SCALED ? sp::pow2_scale(a.x_amax) : 1.f;
 
     const auto rx = make_rsrc(a.x, a.x_bytes);
     const auto rw = make_rsrc(a.w, a.w_bytes);
@@ -611,7 +633,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP == 2 ? 6
     }
 
     float un_a = 1.f, un_w = 1.f;
-    if constexpr (NP == 2) { un_a = sp::pow2_inv(Sa); un_w = sp::pow2_inv(sp::pow2_scale(a.w_amax)); }
+    if constexpr (S::SCALED) { un_a = sp::pow2_inv(Sa); un_w = sp::pow2_inv(sp::pow2_scale(a.w_amax)); }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + (lane & 31);
@@ -622,7 +644,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP == 2 ? 6
             const int pr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);          // pixel of the tile
             const size_t o = ((size_t)((n * a.Hin + ty0 + (pr >> 4)) * a.Win + tx0 + (pr & 15))) * a.Cout + col;
             float v = acc[j][r];
-            if constexpr (NP == 2) v = v * un_a * un_w;
+            if constexpr (S::SCALED) v = v * un_a * un_w;
             v += bv;
             if (a.resid) v += a.resid[o];
             a.y[o] = v;
@@ -656,7 +678,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_sp_kernel(WgradArgs a) {
     const int p_begin = z * a.chunk;
     const int p_end = min(a.M, p_begin + a.chunk);
     const int T = (p_end > p_begin) ? (p_end - p_begin + 15) / 16 : 0;
-    const float So = NP == 2 ? sp::pow2_scale(a.dy_amax) : 1.f, Si = NP == 2 ? sp::pow2_scale(a.x_amax) : 1.f;
+    const float So = S::SCALED ? sp::pow2_scale(a.dy_amax) : 1.f, Si = S::SCALED ? sp::pow2_scale(a.x_amax) : 1.f;
 
     const auto rx = make_rsrc(a.x, a.x_bytes);
     const auto rdy = make_rsrc(a.dy, (unsigned)p_end * (unsigned)a.Cout * 4u);
@@ -754,7 +776,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_sp_kernel(WgradArgs a) {
         __syncthreads();
     }
     float un_o = 1.f, un_i = 1.f;
-    if constexpr (NP == 2) { un_o = sp::pow2_inv(So); un_i = sp::pow2_inv(Si); }
+    if constexpr (S::SCALED) { un_o = sp::pow2_inv(So); un_i = sp::pow2_inv(Si); }
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
@@ -765,7 +787,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_sp_kernel(WgradArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 float v = acc[kw][j][r];
-                if constexpr (NP == 2) v = v * un_o * un_i;
+                if constexpr (S::SCALED) v = v * un_o * un_i;
                 if (co < a.Cout) a.part[(((size_t)z * a.Cout + co) * 9 + kh * 3 + kw) * a.Cin + ci] = v;
             }
         }

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* da, const flo
 
 }  // namespace
 
-extern "C" int favae_abi_version(void) { return 5; }
+extern "C" int favae_abi_version(void) { return 6; }
 
 extern "C" int favae_hinge_mean(const float* x, int64_t n, int mode, float* loss, void* ws, size_t ws_bytes,
                                 favae_stream_t stream) {

@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfavae_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02, ACT_RELU = 0, 1, 2, 3
@@ -34,6 +34,8 @@ SIGNATURES = {
     "favae_abi_version": (c_int, []),
     "favae_conv_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _S]),
     "favae_conv_wants_split_weights": (c_int, [POINTER(ConvDesc), c_int]),
+    "favae_set_conv_mode": (c_int, [c_int]),
+    "favae_get_conv_mode": (c_int, []),
     "favae_split_weights_bytes": (c_size_t, [c_int64, c_int]),
     "favae_split_weights": (c_int, [_P, _P, c_int64, c_int, _S]),
     "favae_conv_fwd_split": (c_int, [POINTER(ConvDesc), _P, _P, c_int, _P, _P, _P, _P, _P, _P, _S]),

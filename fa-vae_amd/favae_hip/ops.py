@@ -138,12 +138,35 @@ _FP16_PLANES = None
 
 
 def _fp16_planes():
-    """True when the library runs its split-precision convs with two scaled fp16 planes (FAVAE_CONV_MODE=h3, the default)."""
+    """True when the library runs its split-precision convs with scaled fp16 planes, which need operand ranges
+    (FAVAE_CONV_MODE=h3, the default: two planes; h1: one plane, the 16-bit mixed-precision mode)."""
     global _FP16_PLANES
     if _FP16_PLANES is None:
         d = make_conv_desc(1, 16, 16, 128, 16, 16, 128, 3, 3, 1, 1, GATHER_PLAIN, ACT_NONE, 1)
-        _FP16_PLANES = query("favae_conv_wants_split_weights", byref(d), 0) == 2
+        _FP16_PLANES = query("favae_conv_wants_split_weights", byref(d), 0) in (1, 2)
     return _FP16_PLANES
+
+
+_WREC = {1: 8, 2: 16, 3: 24}          # bytes of one pre-split record (4 weights) per plane count
+CONV_MODES = {"fp32": 0, "h1": 1, "h3": 2, "b6": 3}
+
+
+def set_conv_mode(mode):
+    """Select the conv arithmetic at run time (same meaning as FAVAE_CONV_MODE): "h3" (default, fp32-grade, two scaled fp16
+    planes), "b6" (fp32-grade, three bf16 planes), "fp32" (fp32-MFMA kernels) or "h1" -- ONE scaled fp16 plane with fp32
+    accumulation: the 16-bit mixed-precision mode (what `accelerate --mixed_precision` gives the reference's convs), not
+    fp32-grade.  Returns the previous mode name."""
+    global _FP16_PLANES
+    prev = query("favae_get_conv_mode")
+    _chk_mode = CONV_MODES[mode]
+    if query("favae_set_conv_mode", _chk_mode) != 0:
+        raise RuntimeError("favae_set_conv_mode failed")
+    _FP16_PLANES = None
+    return {v: k for k, v in CONV_MODES.items()}[prev]
+
+
+def get_conv_mode():
+    return {v: k for k, v in CONV_MODES.items()}[query("favae_get_conv_mode")]
 
 
 def absmax(t):
@@ -247,9 +270,9 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
             n = w_ohwi.numel()
             wsp = torch.empty(query("favae_split_weights_bytes", n, planes), dtype=torch.uint8, device=w_ohwi.device)
             call("favae_split_weights", ptr(w_ohwi), ptr(wsp), n, planes)
-            if planes == 2:
+            if planes in (1, 2):
                 w_amax = wsp[:4].view(torch.float32)          # header of the record buffer (keeps the buffer alive while saved)
-        if planes == 2 and x_bound is None:
+        if planes in (1, 2) and x_bound is None:
             if scale is not None:
                 raise RuntimeError("a transformed conv operand needs its range bound (gn_stats(with_bound=True))")
             x_bound = absmax(x)
@@ -307,7 +330,7 @@ class FusedConvFn(torch.autograd.Function):
         d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad,
                            GATHER_UPSAMPLE2 if cfg.upsample else GATHER_PLAIN, cfg.act if scale is not None else ACT_NONE,
                            per_image)
-        if xb is None and query("favae_conv_wants_split_weights", byref(d), 0) == 2:
+        if xb is None and query("favae_conv_wants_split_weights", byref(d), 0) in (1, 2):
             xb = absmax(x)
         w_amax = _conv_launch(d, x, wk, b, resid, scale, shift, y, xb)
         ctx.cfg = cfg
@@ -397,15 +420,15 @@ class FusedConvFn(torch.autograd.Function):
                 # Downsample: data gradient by output parity (favae_downsample_dgrad_weights) instead of a zero-dilated input
                 d00 = make_conv_desc(N, Ho, Wo, Cout, Ho, Wo, Cin, 2, 2, 1, 1, GATHER_PLAIN, ACT_NONE, 1, lattice=(2, 1, 0, 0))
                 planes = query("favae_conv_wants_split_weights", byref(d00), 0)
-                if planes == 3 or (planes == 2 and w_amax is not None):
+                if planes == 3 or (planes in (1, 2) and w_amax is not None):
                     phased = planes
             if phased:
                 planes = phased
                 da = new_cl(N, Cin, Hin, Win, dev)
                 wph = torch.empty(query("favae_split_weights_bytes", 9 * Cin * Cout, planes), dtype=torch.uint8, device=dev)
                 call("favae_downsample_dgrad_weights", ptr(wk), ptr(wph), Cout, Cin, planes, ptr(w_amax))
-                rec = (Cin * Cout // 4) * (16 if planes == 2 else 24)
-                if planes == 2 and dyb is None:
+                rec = (Cin * Cout // 4) * _WREC[planes]
+                if planes in (1, 2) and dyb is None:
                     dyb = absmax(dy)
                 for ph, (khn, kwn, off) in enumerate(((2, 2, 0), (2, 1, 4), (1, 2, 6), (1, 1, 8))):
                     ph_pad, pw_pad = khn - 1, kwn - 1
@@ -486,14 +509,14 @@ class UpsampleConvFn(torch.autograd.Function):
         planes = query("favae_conv_wants_split_weights", byref(_phase_desc(N, H, W, Cin, Cout, 0)), 0)
         wsp = torch.empty(query("favae_split_weights_bytes", weff.numel(), planes), dtype=torch.uint8, device=dev)
         call("favae_split_weights", ptr(weff), ptr(wsp), weff.numel(), planes)
-        rec = (Cout * 4 * Cin // 4) * (16 if planes == 2 else 24)
-        xb = absmax(x) if planes == 2 else None
+        rec = (Cout * 4 * Cin // 4) * _WREC[planes]
+        xb = absmax(x) if planes in (1, 2) else None
         y = new_cl(N, Cout, 2 * H, 2 * W, dev)
         for ph in range(4):
             call("favae_conv_fwd_split", byref(_phase_desc(N, H, W, Cin, Cout, ph, ph * rec)), ptr(x), ptr(wsp), planes, ptr(xb),
                  ptr(b), None, None, None, ptr(y))
         ctx.planes, ctx.has_b, ctx.params = planes, b is not None, (w, b)
-        ctx.save_for_backward(x, weff, xb, wsp[:4].view(torch.float32) if planes == 2 else None)
+        ctx.save_for_backward(x, weff, xb, wsp[:4].view(torch.float32) if planes in (1, 2) else None)
         return y
 
     @staticmethod
@@ -506,7 +529,7 @@ class UpsampleConvFn(torch.autograd.Function):
         planes = ctx.planes
         p_w, p_b = ctx.params
         dx = dw = db = None
-        dyb = torch.empty((1,), dtype=torch.float32, device=dev) if planes == 2 else None
+        dyb = torch.empty((1,), dtype=torch.float32, device=dev) if planes in (1, 2) else None
         if ctx.has_b and ctx.needs_input_grad[2]:
             M = N * 4 * H * W
             ws = workspace(query("favae_colsum_workspace", M, Cout), dev)

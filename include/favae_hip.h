@@ -83,7 +83,15 @@ int favae_conv_fwd(const favae_conv_desc* d, const float* x, const float* w, con
  * caller splits the OHWI weights once with favae_split_weights() into a buffer of favae_split_weights_bytes() and calls
  * favae_conv_fwd_split() -- same semantics as favae_conv_fwd.  With planes == 2 the kernels also need `x_absmax`: a device
  * float holding an upper bound of |T(x)| (favae_absmax() of x for T = identity; the bound favae_gn_stats() emits otherwise);
- * planes == 3 has no range restriction and ignores it.  Both schemes keep fp32-grade products (tools/conv_accuracy.py). */
+ * planes == 3 has no range restriction and ignores it.  Both schemes keep fp32-grade products (tools/conv_accuracy.py).
+ * planes == 1 ("h1") is the 16-bit mixed-precision mode: ONE scaled fp16 plane per operand (11-bit significand), fp32
+ * accumulation, same range arguments as planes == 2 -- what `accelerate launch --mixed_precision fp16|bf16` turns the reference's
+ * F.conv2d calls into (favae_scripts/train_favae.py:240 builds the Accelerator; BASELINE config 5).  Not fp32-grade.
+ * favae_set_conv_mode(planes) selects the scheme for subsequent calls (0 = fp32-MFMA kernels, 1, 2 = default, 3); it overrides
+ * the FAVAE_CONV_MODE environment variable (fp32 | h1 | h3 | b6) read on first use.  Process-wide, not thread-safe against
+ * concurrent launches. */
+int favae_set_conv_mode(int planes);
+int favae_get_conv_mode(void);
 int favae_conv_wants_split_weights(const favae_conv_desc* d, int has_affine);
 size_t favae_split_weights_bytes(int64_t n, int planes);
 int favae_split_weights(const float* in, void* out, int64_t n, int planes, favae_stream_t stream);

@@ -367,6 +367,38 @@ def test_train_step_is_deterministic():
     assert torch.equal(e1, e2)
 
 
+def test_mixed_precision_step_tracks_fp32_grade_step():
+    """16-bit mixed-precision mode (ops.set_conv_mode("h1"): conv operands in one scaled fp16 plane, fp32 accumulation --
+    BASELINE configs[4] "bf16").  Not a parity mode: the bar is that one full training step (forward, every loss, backward,
+    Adam) stays within fp16-operand tolerance of the default fp32-grade step on identical state and input, and that it is
+    not bit-identical to it (the h1 kernels ran)."""
+    from models.vqgan_fcm import VQGANFCM
+    from favae_step import TrainStep
+    from favae_hip import ops as K
+    mk, ok = MODEL_KW["cfg1"]
+    state = O.det_state(O.OracleConfig(**ok), with_disc=True)
+
+    def run(mode):
+        prev = K.set_conv_mode(mode)
+        try:
+            model = VQGANFCM(**mk, device=DEV)
+            model.load_state_dict(state, strict=True)
+            ts = TrainStep(model.to(DEV), lr=1e-4)
+            out = ts.step(O.det_input(2, 128, 128, 91).to(DEV))
+            torch.cuda.synchronize()
+            return {k: out[k].detach().clone() for k in ("x_recon", "loss_l1", "loss_ffl", "loss_dsl", "loss_quant", "loss_g")}
+        finally:
+            K.set_conv_mode(prev)
+
+    a, b = run("h3"), run("h1")
+    assert K.get_conv_mode() == "h3"
+    assert not torch.equal(a["x_recon"], b["x_recon"])
+    close(b["x_recon"], a["x_recon"], 3e-2, "x_recon h1 vs h3")
+    for k in ("loss_l1", "loss_ffl", "loss_dsl", "loss_g"):
+        close(b[k], a[k], 2e-2, k + " h1 vs h3")
+    assert torch.isfinite(b["loss_quant"]).all()
+
+
 def test_zero_and_nonfinite_operands():
     """fp16 split scheme edge cases: an all-zero operand (max = 0 -> scale 1) gives exact zeros; a NaN input propagates."""
     from favae_hip import ops as K

@@ -79,6 +79,25 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
 def test_fused_conv_fwd_bwd(K, case):
+    _conv_case(K, case, 1.0)
+
+
+@pytest.mark.parametrize("case", CONV_CASES[12:23], ids=[str(i) for i in range(12, 23)])
+def test_conv_mixed_precision_h1(K, case):
+    """16-bit mixed-precision mode (one scaled fp16 plane, fp32 accumulation; BASELINE config 5 "bf16"): every split-path
+    kernel family (halo fwd / dgrad, row3 and per-tap wgrad, strided, phase-wise Upsample) within fp16-operand tolerance of
+    the fp32 reference -- and measurably different from it, i.e. the h1 kernels really ran."""
+    prev = K.set_conv_mode("h1")
+    try:
+        assert K.get_conv_mode() == "h1"
+        errs = _conv_case(K, case, 100.0)
+        assert max(errs["y"], errs["dx"], errs["dw"]) > 2e-5, errs
+    finally:
+        K.set_conv_mode(prev)
+    assert K.get_conv_mode() == prev
+
+
+def _conv_case(K, case, tol_scale):
     N, Cin, H, W, Cout, k, s, p, pbr, up, groups, use_res = case
     x = rnd((N, Cin, H, W), 1).requires_grad_(True)
     w = rnd((Cout, Cin, k, k), 2, math.sqrt(3.0 / (Cin * k * k))).requires_grad_(True)
@@ -113,15 +132,16 @@ def test_fused_conv_fwd_bwd(K, case):
     yd = K.fused_conv(xd, wd, bd, gwd, gbd, rd, cfg)
     assert tuple(yd.shape) == tuple(y.shape)
     (yd * gy.to(d)).sum().backward()
-    check(yd, y, 2e-5, "y")
-    check(xd.grad, x.grad, 5e-5, "dx")
-    check(wd.grad, w.grad, 5e-5, "dw")
+    check(yd, y, 2e-5 * tol_scale, "y")
+    check(xd.grad, x.grad, 5e-5 * tol_scale, "dx")
+    check(wd.grad, w.grad, 5e-5 * tol_scale, "dw")
     check(bd.grad, b.grad, 5e-5, "db")
     if groups:
-        check(gwd.grad, gw.grad, 1e-4, "dgamma")
-        check(gbd.grad, gb.grad, 1e-4, "dbeta")
+        check(gwd.grad, gw.grad, 1e-4 * tol_scale, "dgamma")
+        check(gbd.grad, gb.grad, 1e-4 * tol_scale, "dbeta")
     if use_res:
         check(rd.grad, res.grad, 1e-6, "dres")
+    return {"y": relerr(yd, y), "dx": relerr(xd.grad, x.grad), "dw": relerr(wd.grad, w.grad)}
 
 
 def test_conv_large_tile_shapes(K):
