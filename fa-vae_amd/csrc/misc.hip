@@ -158,9 +158,66 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* da, const flo
     }
 }
 
+// uint8 HWC pixels -> normalised fp32 NHWC: y = (u/255 - mean[c]) / std[c], the ToTensor + Normalize tail of the reference's
+// input pipeline (datasets/general_dataloader.py:33-38) in the layout the convs consume.  Same fp32 operations in the same
+// order as torchvision (true division by 255, subtract, true division) -> bit-identical values.  A thread converts 4 pixels of
+// an RGB image (12 bytes in, three float4 out); other channel counts take the scalar loop.
+struct U8Norm { float mean[4], std[4]; };
+__global__ __launch_bounds__(256) void u8_norm_rgb_kernel(const unsigned* __restrict__ in, float4* __restrict__ out, long groups,
+                                                          U8Norm p) {
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < groups; g += (long)gridDim.x * 256) {
+        const unsigned w0 = in[3 * g], w1 = in[3 * g + 1], w2 = in[3 * g + 2];
+        float v[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = (float)((w0 >> (8 * k)) & 255u);
+            v[4 + k] = (float)((w1 >> (8 * k)) & 255u);
+            v[8 + k] = (float)((w2 >> (8 * k)) & 255u);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[k] = __fdiv_rn(__fsub_rn(__fdiv_rn(v[k], 255.f), p.mean[k % 3]), p.std[k % 3]);
+        out[3 * g] = make_float4(v[0], v[1], v[2], v[3]);
+        out[3 * g + 1] = make_float4(v[4], v[5], v[6], v[7]);
+        out[3 * g + 2] = make_float4(v[8], v[9], v[10], v[11]);
+    }
+}
+__global__ __launch_bounds__(256) void u8_norm_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, long n, int C,
+                                                      U8Norm p) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        out[i] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)in[i], 255.f), p.mean[c]), p.std[c]);
+    }
+}
+
 }  // namespace
 
-extern "C" int favae_abi_version(void) { return 6; }
+extern "C" int favae_abi_version(void) { return 7; }
+
+extern "C" int favae_u8_to_float_nhwc(const unsigned char* in, float* out, int64_t pixels, int C, const float* mean, const float* std,
+                                      favae_stream_t stream) {
+    FAVAE_REQUIRE(in && out && pixels > 0 && C >= 1 && C <= 4 && mean && std);
+    U8Norm p{};
+    for (int c = 0; c < C; ++c) {
+        FAVAE_REQUIRE(std[c] != 0.f);
+        p.mean[c] = mean[c];
+        p.std[c] = std[c];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)pixels * C;
+    long done = 0;
+    if (C == 3 && ((((uintptr_t)in) & 3) == 0) && ((((uintptr_t)out) & 15) == 0) && pixels >= 4) {
+        const long groups = pixels / 4;
+        hipLaunchKernelGGL(u8_norm_rgb_kernel, dim3(ew_blocks(groups)), dim3(256), 0, s, (const unsigned*)in, (float4*)out, groups, p);
+        FAVAE_CHECK_LAUNCH();
+        done = groups * 12;
+    }
+    if (done < n) {
+        // the remainder starts at a multiple of 12 elements, so channel phase 0 is preserved
+        hipLaunchKernelGGL(u8_norm_kernel, dim3(ew_blocks(n - done)), dim3(256), 0, s, in + done, out + done, n - done, C, p);
+        FAVAE_CHECK_LAUNCH();
+    }
+    return FAVAE_OK;
+}
 
 extern "C" int favae_hinge_mean(const float* x, int64_t n, int mode, float* loss, void* ws, size_t ws_bytes,
                                 favae_stream_t stream) {

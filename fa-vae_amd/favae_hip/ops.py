@@ -6,6 +6,7 @@ code reads like the reference's NCHW code while every kernel sees coalesced chan
 from __future__ import annotations
 
 import math
+import ctypes
 import os
 from ctypes import byref
 
@@ -73,6 +74,22 @@ class _ToCLFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g
+
+
+def u8_to_float(x_u8, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)):
+    """(N,H,W,C) uint8 device tensor -> (N,C,H,W) fp32 channels_last tensor, (u/255 - mean)/std: the ToTensor + Normalize tail of
+    datasets/general_dataloader.py:33-38 on the device (bit-identical to torchvision's fp32 arithmetic), written straight in the
+    layout the convs read.  The batch crosses PCIe as bytes."""
+    if not (x_u8.is_cuda and x_u8.dtype == torch.uint8 and x_u8.dim() == 4 and x_u8.is_contiguous()):
+        raise RuntimeError("u8_to_float needs a contiguous (N,H,W,C) uint8 tensor on the GPU (no CPU path)")
+    N, H, W, C = x_u8.shape
+    if not (1 <= C <= 4 and len(mean) == C and len(std) == C):
+        raise RuntimeError("u8_to_float: 1..4 channels with one mean/std per channel")
+    out = torch.empty((N, H, W, C), dtype=torch.float32, device=x_u8.device)
+    m = (ctypes.c_float * C)(*[float(v) for v in mean])
+    sd = (ctypes.c_float * C)(*[float(v) for v in std])
+    call("favae_u8_to_float_nhwc", ptr(x_u8), ptr(out), N * H * W, C, m, sd)
+    return out.permute(0, 3, 1, 2)
 
 
 def as_cl(t):

@@ -281,6 +281,12 @@ int favae_sqdiff_bwd(const float* a, const float* b, const float* g, float scale
                      float* out, favae_stream_t stream);
 /* y = alpha*x + beta*y */
 int favae_axpby(const float* x, float alpha, float* y, float beta, int64_t n, favae_stream_t stream);
+/* Input pipeline tail on the device: uint8 HWC pixels (PIL decode + resize stay on the host workers) -> fp32 NHWC,
+ * y = (u/255 - mean[c]) / std[c] -- T.ToTensor() + T.Normalize(mean, std) of datasets/general_dataloader.py:33-38 with the same
+ * fp32 operations (bit-identical), written in the layout the convs read.  `mean`, `std`: HOST arrays of C floats (C <= 4).
+ * The batch crosses PCIe as bytes (4x less than the reference's float batch). */
+int favae_u8_to_float_nhwc(const unsigned char* in, float* out, int64_t pixels, int C, const float* mean, const float* std,
+                           favae_stream_t stream);
 /* layout converters: NCHW <-> NHWC */
 int favae_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, favae_stream_t stream);
 int favae_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, favae_stream_t stream);
