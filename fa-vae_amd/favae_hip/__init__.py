@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfavae_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02, ACT_RELU = 0, 1, 2, 3
@@ -88,6 +88,10 @@ SIGNATURES = {
     "favae_sqdiff_bwd": (c_int, [_P, _P, _P, c_float, c_int64, _P, _P, _S]),
     "favae_axpby": (c_int, [_P, c_float, _P, c_float, c_int64, _S]),
     "favae_u8_to_float_nhwc": (c_int, [_P, _P, c_int64, c_int, POINTER(ctypes.c_float), POINTER(ctypes.c_float), _S]),
+    "favae_affine_rows": (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int, c_int, _S]),
+    "favae_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, _S]),
+    "favae_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, _S]),
+    "favae_dropout": (c_int, [_P, _P, _P, c_int64, c_float, ctypes.c_uint32, _S]),
     "favae_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     "favae_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     "favae_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _S]),

@@ -771,6 +771,216 @@ class AttnCoreFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# attention FCM (TransEncoderBlock, models/codec.py:108-122): materialised GroupNorm, LayerNorm, dropout, 8-head attention
+# ---------------------------------------------------------------------------------------------------------------
+_DROP = {"seed": 0, "calls": 0}
+
+
+def set_dropout_seed(seed):
+    """Base seed of the counter-based dropout masks (favae_dropout): call once per training step with a fresh value (TrainStep
+    uses its step count).  Every dropout site of the following forward takes the next derived seed; the backward regenerates the
+    mask from the seed its forward saved.  The oracle derives the same sequence (favae_oracle.DropoutState)."""
+    _DROP["seed"] = int(seed) & 0xFFFFFFFF
+    _DROP["calls"] = 0
+
+
+def _next_dropout_seed():
+    _DROP["calls"] += 1
+    return (_DROP["seed"] * 0x9E3779B1 + 0x85EBCA6B * _DROP["calls"]) & 0xFFFFFFFF
+
+
+def _dense(t):
+    return to_cl(t) if t.dim() == 4 else t.contiguous()
+
+
+class DropoutFn(torch.autograd.Function):
+    """y = keep(seed, i) [and x > 0] ? x / (1 - p) : 0 over the tensor's memory order (nn.Dropout in train mode; relu=True fuses
+    the ReLU in front of it: linear2(dropout(relu(linear1(x)))) of the encoder layer's feed-forward block)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, relu):
+        x = _dense(x)
+        _require_gpu(x)
+        y = torch.empty_like(x)
+        call("favae_dropout", ptr(x), ptr(x) if relu else None, ptr(y), x.numel(), float(p), seed)
+        ctx.p, ctx.seed, ctx.relu = float(p), seed, relu
+        ctx.save_for_backward(x if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _dense(dy)
+        dx = torch.empty_like(dy)
+        call("favae_dropout", ptr(dy), ptr(x) if ctx.relu else None, ptr(dx), dy.numel(), ctx.p, ctx.seed)
+        return dx, None, None, None
+
+
+def dropout(x, p, training, relu=False):
+    """nn.Dropout(p) (optionally behind a ReLU).  Eval mode / p == 0: identity (or the plain ReLU)."""
+    p = float(p) if training else 0.0
+    if p == 0.0 and not relu:
+        return x
+    return DropoutFn.apply(x, p, _next_dropout_seed() if p > 0.0 else 0, relu)
+
+
+class GNApplyFn(torch.autograd.Function):
+    """y = act(GroupNorm(x)) materialised (TransEncoderBlock.norm, whose output is also the block's residual branch; the
+    GN-SiLU in front of a training-mode Dropout).  Statistics and backward are the kernels of the fused path."""
+
+    @staticmethod
+    def forward(ctx, x, gn_w, gn_b, groups, eps, act):
+        x = to_cl(x)
+        _require_gpu(x)
+        N, C, H, W = x.shape
+        mean, rstd, scale, shift = gn_stats(x, gn_w, gn_b, groups, eps)
+        y = new_cl(N, C, H, W, x.device)
+        call("favae_affine_rows", ptr(x), ptr(scale), ptr(shift), ptr(y), N, H * W, C, act)
+        ctx.groups, ctx.act, ctx.params = groups, act, (gn_w, gn_b)
+        ctx.save_for_backward(x, gn_w, gn_b, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gn_w, gn_b, mean, rstd = ctx.saved_tensors
+        dy = to_cl(dy)
+        N, C, H, W = x.shape
+        dev = x.device
+        dx = new_cl(N, C, H, W, dev)
+        tg, tb = _direct_grad(ctx.params[0]), _direct_grad(ctx.params[1])
+        direct = tg is not None and tb is not None
+        dgw = dgb = None
+        if not direct:
+            dgw = torch.empty((C,), dtype=torch.float32, device=dev)
+            dgb = torch.empty_like(dgw)
+        ws = workspace(query("favae_gn_workspace", N, H * W, C), dev)
+        call("favae_gn_act_bwd", ptr(dy), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), N, H * W, C, ctx.groups, ctx.act,
+             None, ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0, ptr(ws), ws.numel())
+        return dx, dgw, dgb, None, None, None
+
+
+def gn_apply(x, gn_w, gn_b, groups=32, eps=1e-5, act=ACT_NONE):
+    return GNApplyFn.apply(x, gn_w, gn_b, groups, eps, act)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm(C) over the channel dimension of an (N, C, H, W) channels-last tensor = over each token's C features
+    (norm1 / norm2 of nn.TransformerEncoderLayer with batch_first tokens (B, HW, C): the same memory)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = to_cl(x)
+        _require_gpu(x)
+        N, C, H, W = x.shape
+        rows = N * H * W
+        dev = x.device
+        y = new_cl(N, C, H, W, dev)
+        mean = torch.empty((rows,), dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        call("favae_layernorm_fwd", ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, C, float(eps))
+        ctx.params = (w, b)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dy = to_cl(dy)
+        N, C, H, W = x.shape
+        rows = N * H * W
+        dev = x.device
+        dx = new_cl(N, C, H, W, dev)
+        t = new_cl(N, C, H, W, dev)
+        call("favae_layernorm_bwd", ptr(dy), ptr(x), ptr(w), ptr(mean), ptr(rstd), ptr(dx), ptr(t), rows, C)
+        out = []
+        for src, prm in ((t, ctx.params[0]), (dy, ctx.params[1])):           # dgamma = colsum(dy * xhat), dbeta = colsum(dy)
+            ws = workspace(query("favae_colsum_workspace", rows, C), dev)
+            tgt = _direct_grad(prm)
+            g = None
+            if tgt is None:
+                g = torch.empty((C,), dtype=torch.float32, device=dev)
+            call("favae_colsum", ptr(src), ptr(g if tgt is None else tgt), rows, C, 0 if tgt is None else 1, None, ptr(ws), ws.numel())
+            out.append(g)
+        return dx, out[0], out[1], None
+
+
+def layer_norm(x, w, b, eps=1e-5):
+    return LayerNormFn.apply(x, w, b, eps)
+
+
+class MHACoreFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dh)) [dropout] v per head, on the packed in-projection output (N, 3C, H, W) channels-last =
+    tokens (N, L, 3C); head h owns features [h dh, (h+1) dh) of each of q, k, v (nn.MultiheadAttention, batch_first).  One
+    batched GEMM per head and product (head = pointer offset + row stride 3C); the probabilities of all heads share one
+    (N, heads, L, L) buffer so softmax / dropout / softmax-backward are single launches."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, p, seed):
+        qkv = to_cl(qkv)
+        _require_gpu(qkv)
+        N, C3, H, W = qkv.shape
+        C, L = C3 // 3, H * W
+        dh = C // heads
+        dev = qkv.device
+        alpha = 1.0 / math.sqrt(dh)
+        P = torch.empty((N, heads, L, L), dtype=torch.float32, device=dev)
+        base = qkv.data_ptr()
+        for h in range(heads):
+            q, k = base + 4 * h * dh, base + 4 * (C + h * dh)
+            call("favae_bgemm", 0, 0, L, L, dh, alpha, q, C3, L * C3, k, C3, L * C3, P.data_ptr() + 4 * h * L * L, L, heads * L * L, N, 0)
+        call("favae_softmax_rows", ptr(P), ptr(P), N * heads * L, L)
+        Pd = P
+        if p > 0.0:
+            Pd = torch.empty_like(P)
+            call("favae_dropout", ptr(P), None, ptr(Pd), P.numel(), float(p), seed)
+        o = new_cl(N, C, H, W, dev)
+        for h in range(heads):
+            v = base + 4 * (2 * C + h * dh)
+            call("favae_bgemm", 0, 1, L, dh, L, 1.0, Pd.data_ptr() + 4 * h * L * L, L, heads * L * L, v, C3, L * C3,
+                 o.data_ptr() + 4 * h * dh, C, L * C, N, 0)
+        ctx.heads, ctx.p, ctx.seed = heads, float(p), seed
+        ctx.save_for_backward(qkv, P, Pd if p > 0.0 else None)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, P, Pd = ctx.saved_tensors
+        if Pd is None:
+            Pd = P
+        do = to_cl(do)
+        heads = ctx.heads
+        N, C3, H, W = qkv.shape
+        C, L = C3 // 3, H * W
+        dh = C // heads
+        dev = qkv.device
+        alpha = 1.0 / math.sqrt(dh)
+        dqkv = new_cl(N, C3, H, W, dev)
+        base, dbase, dob = qkv.data_ptr(), dqkv.data_ptr(), do.data_ptr()
+        dP = torch.empty_like(P)
+        sP = heads * L * L
+        for h in range(heads):
+            v, dv = base + 4 * (2 * C + h * dh), dbase + 4 * (2 * C + h * dh)
+            ph, doh = 4 * h * L * L, dob + 4 * h * dh
+            call("favae_bgemm", 1, 1, L, dh, L, 1.0, Pd.data_ptr() + ph, L, sP, doh, C, L * C, dv, C3, L * C3, N, 0)
+            call("favae_bgemm", 0, 0, L, L, dh, 1.0, doh, C, L * C, v, C3, L * C3, dP.data_ptr() + ph, L, sP, N, 0)
+        if ctx.p > 0.0:
+            call("favae_dropout", ptr(dP), None, ptr(dP), dP.numel(), ctx.p, ctx.seed)
+        call("favae_softmax_rows_bwd", ptr(P), ptr(dP), ptr(dP), N * heads * L, L, alpha)
+        for h in range(heads):
+            q, k = base + 4 * h * dh, base + 4 * (C + h * dh)
+            dq, dk = dbase + 4 * h * dh, dbase + 4 * (C + h * dh)
+            ph = 4 * h * L * L
+            call("favae_bgemm", 0, 1, L, dh, L, 1.0, dP.data_ptr() + ph, L, sP, k, C3, L * C3, dq, C3, L * C3, N, 0)
+            call("favae_bgemm", 1, 1, L, dh, L, 1.0, dP.data_ptr() + ph, L, sP, q, C3, L * C3, dk, C3, L * C3, N, 0)
+        return dqkv, None, None, None
+
+
+def mha_core(qkv, heads, p, training):
+    p = float(p) if training else 0.0
+    return MHACoreFn.apply(qkv, heads, p, _next_dropout_seed() if p > 0.0 else 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # learnable-sigma Gaussian blur (models/codec.py:255-277)
 # ---------------------------------------------------------------------------------------------------------------
 class BlurFn(torch.autograd.Function):

@@ -196,6 +196,7 @@ class TrainStep:
     def step(self, x):
         self.model.train()
         self.gflat.zero_()
+        K.set_dropout_seed(self.t + 1)                       # dropout sites (attention FCM only): fresh masks every step
         out = self.losses(x)
         out["loss_g"].sum().backward()
         K.sync_side_stream()                                 # weight gradients run on a second stream (ops._SIDE)

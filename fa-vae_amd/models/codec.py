@@ -11,6 +11,7 @@ Reference map (file:line in the reference repo):
   Upsample codec.py:11-18 | Downsample :21-31 | ResnetBlock :34-57 | NonResnetBlock :62-84 | AttnBlock :87-102
   Encoder :125-188 | EncoderGauss :193-314 | Decoder :400-466 | DecoderFcm :471-550 | DecoderFcmGauss :557-693
   DecoderFcmGaussSame :700-788 | DecoderFcmGaussSameResblock :794-876 | DecoderFcmResGauss :882-1004
+  TransEncoderBlock :108-122 | DecoderFcmAttnGauss :1011-1129
 """
 import torch
 import torch.nn as nn
@@ -62,8 +63,6 @@ class _NormActConvBlock(nn.Module):
 
     def __init__(self, in_c, out_c, dropout, num_groups=32):
         super().__init__()
-        if dropout != 0.0:
-            raise NotImplementedError("only Dropout(0.0) is on the accelerated path (every shipped config uses 0.0)")
         self.block = nn.Sequential(
             nn.GroupNorm(num_groups, in_c), nn.SiLU(),
             nn.Conv2d(in_c, out_c, kernel_size=3, stride=1, padding=1),
@@ -81,6 +80,12 @@ class _NormActConvBlock(nn.Module):
 
     def _conv2(self, h, resid):
         b = self.block
+        if self.training and b[5].p > 0.0:
+            # Dropout between SiLU and the conv (only DecoderFcmAttnGauss.fcm_4 has p = 0.1, codec.py:1069): the activated
+            # tensor has to exist to be masked, so this one site runs GroupNorm+SiLU materialised -> dropout -> plain conv
+            t = K.gn_apply(h, b[3].weight, b[3].bias, self._cfg.groups, self._cfg.eps, ACT_SILU)
+            t = K.dropout(t, b[5].p, True)
+            return K.fused_conv(t, b[6].weight, b[6].bias, resid=resid, cfg=_C3)
         return K.fused_conv(h, b[6].weight, b[6].bias, b[3].weight, b[3].bias, resid, self._cfg)
 
 
@@ -121,10 +126,34 @@ class AttnBlock(nn.Module):
 
 
 class TransEncoderBlock(nn.Module):
+    """FCM with attention architecture (codec.py:108-122): GroupNorm(32) -> nn.TransformerEncoderLayer(in_c, nhead=8,
+    batch_first=True) on the (B, HW, C) tokens -> back to (B, C, H, W).  The layer's defaults are what the reference gets:
+    dim_feedforward 2048, dropout 0.1, ReLU, post-norm, LayerNorm eps 1e-5.  The nn modules are parameter containers (same
+    state_dict keys: norm.*, attn.self_attn.in_proj_*, attn.self_attn.out_proj.*, attn.linear1/2.*, attn.norm1/2.*); tokens are the
+    channels-last memory of the 4-D tensor, so the linear layers are 1x1 convs on the split-precision matrix path."""
+
     def __init__(self, in_c):
         super().__init__()
-        raise NotImplementedError("TransEncoderBlock (--use_gauss_attn, paper Table 2 row 9) is outside the accelerated "
-                                  "hot path (SURVEY 2.4 K13)")
+        self.norm = nn.GroupNorm(32, in_c)
+        self.attn = nn.TransformerEncoderLayer(in_c, nhead=8, batch_first=True)
+
+    def forward(self, x):
+        a = self.attn
+        sa = a.self_attn
+        tr = self.training
+        h = K.gn_apply(x, self.norm.weight, self.norm.bias, 32, self.norm.eps)             # the residual branch is GN(x)
+        # x = norm1(x + dropout1(self_attn(x)))   (TransformerEncoderLayer._sa_block, norm_first=False)
+        qkv = K.fused_conv(h, sa.in_proj_weight, sa.in_proj_bias, cfg=_C1)
+        o = K.mha_core(qkv, sa.num_heads, sa.dropout, tr)
+        s = K.fused_conv(o, sa.out_proj.weight, sa.out_proj.bias, cfg=_C1)
+        s = K.dropout(s, a.dropout1.p, tr)
+        x1 = K.layer_norm(K.add(h, s), a.norm1.weight, a.norm1.bias, a.norm1.eps)
+        # x = norm2(x + dropout2(linear2(dropout(relu(linear1(x))))))   (_ff_block)
+        f = K.fused_conv(x1, a.linear1.weight, a.linear1.bias, cfg=_C1)
+        f = K.dropout(f, a.dropout.p, tr, relu=True)
+        f = K.fused_conv(f, a.linear2.weight, a.linear2.bias, cfg=_C1)
+        f = K.dropout(f, a.dropout2.p, tr)
+        return K.layer_norm(K.add(x1, f), a.norm2.weight, a.norm2.bias, a.norm2.eps)
 
 
 def _final(block_in, out_ch, with_quant_conv=None):
@@ -266,20 +295,21 @@ class _DecoderFcmBase(nn.Module, _BlurMixin):
         self.device = device
         self.kernel_size = kernel_size
         block_in = ch * ch_mult[len(ch_mult) - 1]
-        if self.RES_FCM:
-            fcm = lambda c, g=32: ResnetBlock(c, c, dropout=dropout)
-        else:
-            fcm = lambda c, g=32: NonResnetBlock(c, c, dropout=dropout, num_groups=g)
-        self.fcm_1 = fcm(z_channels, num_groups)
+        self.fcm_1 = self._make_fcm(z_channels, 1, dropout, num_groups)
         self.conv_in = nn.Conv2d(z_channels, block_in, kernel_size=3, stride=1, padding=1)
-        self.fcm_2 = fcm(block_in)
+        self.fcm_2 = self._make_fcm(block_in, 2, dropout, 32)
         self.mid = nn.Sequential(ResnetBlock(block_in, block_in, dropout=dropout), AttnBlock(block_in),
                                  ResnetBlock(block_in, block_in, dropout=dropout))
-        self.fcm_3 = fcm(block_in)
+        self.fcm_3 = self._make_fcm(block_in, 3, dropout, 32)
         self.up, block_in = _make_up(ch, ch_mult, num_res_blocks, attn_resolutions, dropout, resolution, block_in)
-        self.fcm_4 = fcm(block_in)
+        self.fcm_4 = self._make_fcm(block_in, 4, dropout, 32)
         self.final = _final(block_in, out_ch)
         _conv_weights_channels_last(self)
+
+    def _make_fcm(self, c, index, dropout, num_groups):
+        if self.RES_FCM:
+            return ResnetBlock(c, c, dropout=dropout)
+        return NonResnetBlock(c, c, dropout=dropout, num_groups=num_groups)
 
     def _tap(self, h, i, inference):
         if not self.OWN_SIGMAS:
@@ -361,7 +391,16 @@ class DecoderFcmResGauss(_DecoderFcmBase):
                          dsl_init_sigma, device)
 
 
-class DecoderFcmAttnGauss(nn.Module):
-    def __init__(self, *args, **kwargs):
-        super().__init__()
-        raise NotImplementedError("DecoderFcmAttnGauss (--use_gauss_attn) is outside the accelerated hot path (SURVEY 2.4 K13)")
+class DecoderFcmAttnGauss(_DecoderFcmBase):
+    """--use_gauss_attn (codec.py:1011-1129, paper Table 2 row 9): fcm_1..3 are TransEncoderBlocks applied in sequence, fcm_4 a
+    ResnetBlock with dropout 0.1; own sigmas; under `inference` the taps are None (codec.py:1101-1125)."""
+    RES_FCM = True
+    OWN_SIGMAS = True
+
+    def __init__(self, ch=128, out_ch=3, ch_mult=[1, 1, 2, 2, 4], num_res_blocks=2, attn_resolutions=[16], dropout=0.0,
+                 resolution=256, z_channels=256, kernel_size=0, dsl_init_sigma=None, device=None):
+        super().__init__(ch, out_ch, ch_mult, num_res_blocks, attn_resolutions, dropout, resolution, z_channels, kernel_size,
+                         dsl_init_sigma, device)
+
+    def _make_fcm(self, c, index, dropout, num_groups):
+        return ResnetBlock(c, c, dropout=0.1) if index == 4 else TransEncoderBlock(c)

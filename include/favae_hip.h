@@ -281,6 +281,30 @@ int favae_sqdiff_bwd(const float* a, const float* b, const float* g, float scale
                      float* out, favae_stream_t stream);
 /* y = alpha*x + beta*y */
 int favae_axpby(const float* x, float alpha, float* y, float beta, int64_t n, favae_stream_t stream);
+/* ------------------------------------------------------------------------------------------------------------
+ * Attention FCM (--use_gauss_attn): TransEncoderBlock = GroupNorm(32) + nn.TransformerEncoderLayer(C, nhead 8, FFN 2048, ReLU,
+ * dropout 0.1, post-norm, batch_first), models/codec.py:108-122; DecoderFcmAttnGauss :1011-1129 (its fcm_4 is a
+ * ResnetBlock(dropout=0.1)).  The linear layers are 1x1 favae_conv_fwd calls on NHWC tokens, the heads are favae_bgemm /
+ * favae_softmax_rows calls on strided q/k/v views; what is new are the token-wise passes below.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* y[n,p,c] = act(x[n,p,c] * scale[n,c] + shift[n,c]): GroupNorm materialised from favae_gn_stats()' per-(image, channel) affine
+ * (the block's residual branch is the normalised tensor itself).  C % 4 == 0. */
+int favae_affine_rows(const float* x, const float* scale, const float* shift, float* y, int N, int64_t HW, int C, int act,
+                      favae_stream_t stream);
+/* nn.LayerNorm(C) over `rows` tokens of C contiguous floats (norm1 / norm2 of the encoder layer): y = (x - mean) * rstd * gamma +
+ * beta, biased variance, statistics in fp64; mean / rstd (rows floats each) are kept for the backward.  C % 4 == 0, C <= 2048. */
+int favae_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows, int C,
+                        float eps, favae_stream_t stream);
+/* dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = dy * gamma; dy_xhat[r][c] = dy * xhat, whose favae_colsum() is
+ * dgamma (dbeta = favae_colsum(dy)) -- both column sums stay deterministic and accumulate into the flat gradient buffer. */
+int favae_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                        float* dy_xhat, int64_t rows, int C, favae_stream_t stream);
+/* nn.Dropout(p) in training mode (and, with `gate`, ReLU followed by dropout): y[i] = keep(seed, i) && (gate == NULL ||
+ * gate[i] > 0) ? x[i] / (1 - p) : 0.  keep() is a counter-based hash of (i, seed) -- no generator state; the backward is the
+ * same call on dy with the same seed (and gate = the forward's pre-activation).  p == 0 keeps everything (pure ReLU with a
+ * gate).  x may alias y.  n < 2^32. */
+int favae_dropout(const float* x, const float* gate, float* y, int64_t n, float p, uint32_t seed, favae_stream_t stream);
+
 /* Input pipeline tail on the device: uint8 HWC pixels (PIL decode + resize stay on the host workers) -> fp32 NHWC,
  * y = (u/255 - mean[c]) / std[c] -- T.ToTensor() + T.Normalize(mean, std) of datasets/general_dataloader.py:33-38 with the same
  * fp32 operations (bit-identical), written in the layout the convs read.  `mean`, `std`: HOST arrays of C floats (C <= 4).

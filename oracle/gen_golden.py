@@ -591,9 +591,108 @@ def gen_lpips_head():
     np.savez_compressed(os.path.join(OUT, "lpips_head.npz"), **out)
 
 
+# =============================================================================================
+# G9: attention FCM (--use_gauss_attn): TransEncoderBlock and the whole DecoderFcmAttnGauss model.
+# The reference's dropout masks come from torch's generator and cannot be reproduced on the device, so the reference is captured
+# (a) in eval mode and (b) in train mode with every dropout probability set to 0 (EMA codebook update, train-mode VQ loss);
+# the dropout sites themselves are pinned between the oracle and the HIP path on the shared counter-based mask.
+# =============================================================================================
+def _zero_dropout(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+
+
+def gen_attn_fcm():
+    out = {}
+    # ---- block level -------------------------------------------------------------------------
+    for name, C, shp in (("trans64", 64, (2, 64, 6, 5)), ("trans256", 256, (1, 256, 4, 4))):
+        mod = RC.TransEncoderBlock(C)
+        P = fill_module(mod, "blk")
+        _zero_dropout(mod)
+        mod.train()
+        n = int(np.prod(shp))
+        x = (2 * O._hash_uniform(n, 31 + C).reshape(shp) - 1).float().requires_grad_(True)
+        y = mod(x)
+        gy = (2 * O._hash_uniform(y.numel(), 992).reshape(y.shape) - 1).float()
+        (y * gy).sum().backward()
+        mod.eval()
+        with torch.no_grad():
+            y_eval = mod(x.detach())                      # eval mode takes torch's fused encoder-layer fast path
+        out[f"{name}.x"], out[f"{name}.y"], out[f"{name}.gy"], out[f"{name}.gx"] = npy(x), npy(y), npy(gy), npy(x.grad)
+        out[f"{name}.y_eval"] = npy(y_eval)
+        for k, prm in mod.named_parameters():
+            out[f"{name}.g.{k}"] = npy(prm.grad)
+        Po = leafify({k: v.clone() for k, v in P.items()})
+        xo = x.detach().clone().requires_grad_(True)
+        yo = O.trans_encoder_block(Po, "blk", xo, training=True, drop=None)
+        (yo * gy).sum().backward()
+        check(f"attn_fcm/{name}/y", yo, y)
+        check(f"attn_fcm/{name}/y_eval", yo, y_eval)
+        check(f"attn_fcm/{name}/gx", xo.grad, x.grad, tol=1e-4)
+        for k, prm in mod.named_parameters():
+            check(f"attn_fcm/{name}/g.{k}", Po["blk." + k].grad, prm.grad, tol=1e-4)
+    # ---- whole model ---------------------------------------------------------------------------
+    mk = dict(codebook_size=256, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
+              use_l2_quantizer=True, kernel_size=3, dsl_init_sigma=3.0, use_gauss_attn=True, device="cpu")
+    ok = dict(codebook_size=256, variant="gauss_attn", kernel_size=3)
+    B, H, W, seed = 1, 64, 64, 41
+    tag = "gauss_attn_64"
+    model = VQGANFCM(**mk)
+    P = fill_module(model, "", sigma0=3.0)
+    cfg = O.OracleConfig(**ok)
+    shapes = O.param_shapes(cfg)
+    assert set(shapes) == set(P), (set(shapes) ^ set(P))
+    for k in P:
+        assert tuple(P[k].shape) == tuple(shapes[k]), k
+    _zero_dropout(model)
+    x = O.det_input(B, H, W, seed)
+    res = run_reference_step(model, x, dsl_w=0.01, ffl_w=1.0, cw=1.0)
+    res["loss_g"].sum().backward()
+    Po = leafify({k: v.clone() for k, v in P.items()})
+    ro = O.step_losses(Po, x, cfg, O.StepConfig(codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01), drop=None)
+    ro["loss_g"].sum().backward()
+    check(f"{tag}/x_recon", ro["out"]["x_recon"], res["x_recon"], tol=1e-4)
+    check(f"{tag}/z_q", ro["out"]["z_q"], res["z_q"], tol=1e-4)
+    for k in ("loss_q", "loss_l1", "loss_ffl", "loss_dsl", "loss_g"):
+        check(f"{tag}/{k}", ro["loss_quant" if k == "loss_q" else k], res[k], tol=1e-4)
+    pfx = tag + "."
+    summarize(pfx, res, model, out, x)
+    out[pfx + "indices"] = npy(ro["out"]["indices"])
+    top2 = ro["out"]["dist"].topk(2, dim=-1).values
+    out[pfx + "index_gap"] = npy((top2[..., 0] - top2[..., 1]).reshape(ro["out"]["indices"].shape))
+    named = dict(model.named_parameters())
+    for k in ("encoder.conv_in.weight", "decoder.final.2.weight", "decoder.sigmas", "encoder.sigmas",
+              "decoder.fcm_1.attn.self_attn.in_proj_weight", "decoder.fcm_2.attn.linear1.weight", "decoder.fcm_3.attn.norm2.weight",
+              "decoder.fcm_3.norm.weight", "decoder.fcm_4.block.6.weight"):
+        g = named[k].grad
+        out[pfx + "g." + k + ".sum"] = np.float64(g.double().sum().item())
+        out[pfx + "g." + k + ".abs"] = np.float64(g.double().abs().sum().item())
+        out[pfx + "g." + k + ".head"] = npy(g.reshape(-1)[:16])
+        check(f"{tag}/g.{k}", Po[k].grad, g, tol=2e-3)
+    # inference surface: eval mode, inference=True -> taps are None (codec.py:1101-1125)
+    model_i = VQGANFCM(**dict(mk, inference=True))
+    fill_module(model_i, "", sigma0=3.0)
+    model_i.eval()
+    with torch.no_grad():
+        zq, lq, ind, ef = model_i.encode(x)
+        xr, df = model_i.decode(zq)
+    assert all(f is None for f in df)
+    out[pfx + "inf.x_recon_sum"] = np.float64(xr.double().sum().item())
+    out[pfx + "inf.x_recon_abs"] = np.float64(xr.double().abs().sum().item())
+    out[pfx + "inf.indices"] = npy(ind)
+    oi = O.vqganfcm_forward({k: v.clone() for k, v in P.items()}, x, O.OracleConfig(**dict(ok, inference=True)), training=False)
+    check(f"{tag}/inf.x_recon", oi["x_recon"], xr, tol=1e-4)
+    assert torch.equal(oi["indices"].reshape(-1), ind.reshape(-1))
+    out[pfx + "shape"] = np.array([B, H, W, seed], np.int64)
+    np.savez_compressed(os.path.join(OUT, "attn_fcm.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["blocks", "blur", "vq", "hinge", "models", "cfg1", "gan", "lpips"]
+    which = sys.argv[1:] or ["blocks", "blur", "vq", "hinge", "models", "cfg1", "gan", "lpips", "attn_fcm"]
     if "blocks" in which:
         gen_blocks()
     if "blur" in which:
@@ -610,6 +709,8 @@ if __name__ == "__main__":
         gen_gan()
     if "lpips" in which:
         gen_lpips_head()
+    if "attn_fcm" in which:
+        gen_attn_fcm()
     print("oracle-vs-reference max relative differences:")
     for name, r in report:
         print(f"  {name:55s} {r:.3e}")

@@ -322,3 +322,74 @@ def test_lpips_oracle_properties():
     close(O.lpips_forward(LP, y, x), d, 1e-6, "symmetry")
     f = O.lpips_vgg_features(LP, O.lpips_scaling(LP, x))
     assert [tuple(t.shape[1:]) for t in f] == [(64, 32, 32), (128, 16, 16), (256, 8, 8), (512, 4, 4), (512, 2, 2)]
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).detach().double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# attention FCM (--use_gauss_attn): TransEncoderBlock and the DecoderFcmAttnGauss model, reference captured with
+# every dropout probability set to 0 (train mode) and in eval mode (oracle/gen_golden.py:gen_attn_fcm)
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,C", [("trans64", 64), ("trans256", 256)])
+def test_trans_encoder_block_against_reference_golden(golden_dir, name, C):
+    g = np.load(os.path.join(golden_dir, "attn_fcm.npz"))
+    x = torch.from_numpy(g[name + ".x"]).requires_grad_(True)
+    P = {}
+    mod_shapes = O.param_shapes(O.OracleConfig(codebook_size=16, n_embed=C, variant="gauss_attn"), with_disc=False)
+    for k, shp in mod_shapes.items():
+        if k.startswith("decoder.fcm_1."):
+            kk = "blk." + k[len("decoder.fcm_1."):]
+            P[kk] = O.det_value(kk, shp).requires_grad_(True)
+    y = O.trans_encoder_block(P, "blk", x, training=True, drop=None)
+    (y * torch.from_numpy(g[name + ".gy"])).sum().backward()
+    assert _rel(y, g[name + ".y"]) < 2e-5
+    assert _rel(y, g[name + ".y_eval"]) < 2e-5
+    assert _rel(x.grad, g[name + ".gx"]) < 1e-4
+    for k in P:
+        assert _rel(P[k].grad, g[name + ".g." + k[4:]]) < 1e-4, k
+
+
+def test_gauss_attn_model_against_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "attn_fcm.npz"))
+    t = "gauss_attn_64."
+    B, H, W, seed = (int(v) for v in g[t + "shape"])
+    cfg = O.OracleConfig(codebook_size=256, variant="gauss_attn", kernel_size=3)
+    P = O.det_state(cfg)
+    for k in O.trainable_keys(P):
+        P[k].requires_grad_(True)
+    x = O.det_input(B, H, W, seed)
+    r = O.step_losses(P, x, cfg, O.StepConfig(codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01), drop=None)
+    r["loss_g"].sum().backward()
+    assert np.array_equal(r["out"]["indices"].numpy(), g[t + "indices"])
+    xr = r["out"]["x_recon"]
+    assert abs(float(xr.double().sum()) - float(g[t + "x_recon_sum"])) < 1e-4 * float(g[t + "x_recon_abs"])
+    for k in ("loss_l1", "loss_ffl", "loss_dsl", "loss_g"):
+        assert _rel(r[k].reshape(-1), g[t + k]) < 1e-4, k
+    for k in ("decoder.fcm_1.attn.self_attn.in_proj_weight", "decoder.fcm_2.attn.linear1.weight", "decoder.fcm_4.block.6.weight"):
+        assert abs(float(P[k].grad.double().sum()) - float(g[t + "g." + k + ".sum"])) < 2e-3 * float(g[t + "g." + k + ".abs"]), k
+    # inference surface
+    ci = O.OracleConfig(codebook_size=256, variant="gauss_attn", kernel_size=3, inference=True)
+    oi = O.vqganfcm_forward(O.det_state(ci), x, ci, training=False)
+    assert all(f is None for f in oi["dec_feats"])
+    assert np.array_equal(oi["indices"].reshape(-1).numpy(), g[t + "inf.indices"].reshape(-1))
+    assert abs(float(oi["x_recon"].double().sum()) - float(g[t + "inf.x_recon_sum"])) < 1e-4 * float(g[t + "inf.x_recon_abs"])
+
+
+def test_dropout_mask_is_counter_based_and_reproducible():
+    """The shared dropout mask (oracle side): deterministic in (seed, index), keeps ~1-p of the elements, scales by 1/(1-p)."""
+    k1 = O.dropout_keep(1 << 16, 0.1, 12345)
+    assert torch.equal(k1, O.dropout_keep(1 << 16, 0.1, 12345))
+    assert not torch.equal(k1, O.dropout_keep(1 << 16, 0.1, 12346))
+    assert abs(float(k1.float().mean()) - 0.9) < 5e-3
+    d = O.DropoutState(7)
+    s1, s2 = d.next_seed(), d.next_seed()
+    assert s1 != s2 and O.DropoutState(7).next_seed() == s1
+    x = torch.ones(2, 8, 4, 4)
+    y = O.dropout_like_hip(x, 0.1, O.DropoutState(3), True)
+    vals = set(np.unique(y.numpy()).tolist())
+    assert vals <= {0.0, float(np.float32(1) / (np.float32(1) - np.float32(0.1)))}
+    assert torch.equal(O.dropout_like_hip(x, 0.1, None, True), x) and torch.equal(O.dropout_like_hip(x, 0.1, O.DropoutState(3), False), x)
