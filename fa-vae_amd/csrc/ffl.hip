@@ -60,21 +60,39 @@ __global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs a) {
     const size_t base = (size_t)o * L * a.inner + i0 + ic;            // full-length lines (real input, real output)
     const size_t base_in = (size_t)o * a.Lin * a.inner + i0 + ic;
     const size_t base_out = (size_t)o * a.Lout * a.inner + i0 + ic;
-    for (int l = bl; l < L; l += BL) {
-        float2 v = make_float2(0.f, 0.f);
-        if (ic_ok) {
-            if (IN == IN_DIFF) {
-                const size_t idx = base + (size_t)l * a.inner;
-                v.x = a.in0[idx] - a.in1[idx];
-            } else if (IN == IN_HALF && l >= a.Lin) {
-                v = reinterpret_cast<const float2*>(a.in0)[base_in + (size_t)(L - l) * a.inner];
-                v.y = -v.y;
-            } else {
-                v = reinterpret_cast<const float2*>(a.in0)[base_in + (size_t)l * a.inner];
+    // U independent loads in flight per thread before the first LDS store (the loop bounds are run-time values, so the
+    // compiler would otherwise serialise load -> store pairs: this pass is latency-bound with 8 waves per 64 KB tile)
+    constexpr int U = 8;
+    for (int l0 = bl; l0 < L; l0 += BL * U) {
+        float2 v[U];
+        float t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int l = l0 + u * BL;
+            v[u] = make_float2(0.f, 0.f);
+            t[u] = 0.f;
+            if (ic_ok && l < L) {
+                if (IN == IN_DIFF) {
+                    const size_t idx = base + (size_t)l * a.inner;
+                    v[u].x = a.in0[idx];
+                    t[u] = a.in1[idx];
+                } else if (IN == IN_HALF && l >= a.Lin) {
+                    v[u] = reinterpret_cast<const float2*>(a.in0)[base_in + (size_t)(L - l) * a.inner];
+                    v[u].y = -v[u].y;
+                } else {
+                    v[u] = reinterpret_cast<const float2*>(a.in0)[base_in + (size_t)l * a.inner];
+                }
             }
         }
-        const int r = (int)(__brev((unsigned)l) >> (32 - a.logL));
-        data[(a.logL ? r : 0) * IC + ic] = v;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int l = l0 + u * BL;
+            if (l < L) {
+                if (IN == IN_DIFF) v[u].x -= t[u];
+                const int r = (int)(__brev((unsigned)l) >> (32 - a.logL));
+                data[(a.logL ? r : 0) * IC + ic] = v[u];
+            }
+        }
     }
     __syncthreads();
     // ---- butterflies ------------------------------------------------------------------------------------------
