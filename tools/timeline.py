@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Timeline analysis of a rocprofv3 kernel trace of bench.py (rocpd sqlite): per training step, the busy time of each HIP
+queue, the overlap between the main and the weight-gradient stream, idle gaps, and per-kernel durations in a two-stream step
+next to the single-stream step of the same run.  usage: tools/timeline.py <results.db>"""
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    return re.sub(r"\(.*", "", n)[:60]
+
+
+db = sqlite3.connect(sys.argv[1])
+rows = db.execute("select name, start, end, queue_id, vgpr_count, accum_vgpr_count, lds_size, grid_x, workgroup_x from kernels order by start").fetchall()
+adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
+# a step ends with its last adam launch (two per step when the model has its own sigma group; detect by spacing)
+ends = [adam[i] for i in range(len(adam)) if i + 1 == len(adam) or rows[adam[i + 1]][1] - rows[adam[i]][2] > 5e6]
+steps, prev = [], 0
+for e in ends:
+    steps.append(rows[prev:e + 1])
+    prev = e + 1
+print("steps found:", len(steps))
+
+
+def union(iv):
+    iv = sorted(iv)
+    tot, cs, ce = 0, None, None
+    for s, e in iv:
+        if cs is None:
+            cs, ce = s, e
+        elif s <= ce:
+            ce = max(ce, e)
+        else:
+            tot += ce - cs
+            cs, ce = s, e
+    if cs is not None:
+        tot += ce - cs
+    return tot
+
+
+for si, st in enumerate(steps):
+    t0, t1 = st[0][1], max(r[2] for r in st)
+    qs = defaultdict(list)
+    for r in st:
+        qs[r[3]].append((r[1], r[2]))
+    allb = union([(r[1], r[2]) for r in st])
+    line = f"step {si}: wall {(t1 - t0) / 1e6:8.2f} ms  busy(any) {allb / 1e6:8.2f}  idle {(t1 - t0 - allb) / 1e6:6.2f}"
+    for q, iv in sorted(qs.items()):
+        line += f"  q{q}: busy {union(iv) / 1e6:7.2f} sum {sum(e - s for s, e in iv) / 1e6:7.2f} n {len(iv)}"
+    if len(qs) == 2:
+        a, b = [union(v) for _, v in sorted(qs.items())]
+        line += f"  overlap {(a + b - allb) / 1e6:7.2f}"
+    print(line)
+
+if len(steps) >= 4:
+    two, one = steps[-3], steps[-1]          # last two-stream step, last single-stream step
+    def agg(st):
+        d = defaultdict(lambda: [0, 0.0])
+        for r in st:
+            k = short(r[0])
+            d[k][0] += 1
+            d[k][1] += (r[2] - r[1]) / 1e6
+        return d
+    a2, a1 = agg(two), agg(one)
+    print("\nper kernel: ms in the two-stream step | single-stream step | inflation   (vgpr+agpr, lds)")
+    res = {short(r[0]): (r[4], r[5], r[6]) for r in two}
+    for k, (n, ms) in sorted(a2.items(), key=lambda kv: -kv[1][1])[:28]:
+        m1 = a1.get(k, [0, 0.0])[1]
+        print(f"  {k:60s} n={n:4d}  {ms:7.2f} | {m1:7.2f} | {ms / m1 if m1 else 0:5.2f}   v{res[k][0]}+a{res[k][1]} lds {res[k][2]}")
+    print(f"  sum {sum(v[1] for v in a2.values()):.2f} | {sum(v[1] for v in a1.values()):.2f}")
