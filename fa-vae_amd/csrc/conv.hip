@@ -821,7 +821,9 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
             if (tk == 1) {
                 t.Cw = d->Cout; t.xb = 64;
                 const int items = d->N * d->Hin * cdiv(d->Win, t.xb);
-                hipLaunchKernelGGL((thin_in_kernel<3, false>), dim3(items), dim3(256), 0, s, t);
+                // persistent workgroups: the 27 x 4 weights of a thread are loaded once per workgroup, not once per item
+                const int blocks = items < 4096 ? items : 4096;
+                hipLaunchKernelGGL((thin_in_kernel<3, false>), dim3(blocks), dim3(256), (size_t)3 * (t.xb + 2) * 3 * sizeof(float), s, t);
             } else {
                 t.Cw = d->Cin;
                 const int PL = 256 / (t.Cw / 4);
@@ -977,7 +979,10 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
                 t.Cw = d->Cout; t.xb = 64;
                 const int items = d->N * d->Hin * cdiv(d->Win, t.xb);
                 blocks = items < THIN_WGRAD_BLOCKS ? items : THIN_WGRAD_BLOCKS;
-                hipLaunchKernelGGL((thin_in_kernel<3, true>), dim3(blocks), dim3(256), (size_t)3 * 27 * t.Cw * sizeof(float), s, t);
+                size_t shm = (size_t)3 * 27 * t.Cw * sizeof(float);
+                const size_t stage_b = (size_t)3 * (t.xb + 2) * 3 * sizeof(float);
+                if (shm < stage_b) shm = stage_b;
+                hipLaunchKernelGGL((thin_in_kernel<3, true>), dim3(blocks), dim3(256), shm, s, t);
             } else {
                 t.Cw = d->Cin;
                 const int PL = 256 / (t.Cw / 4);
