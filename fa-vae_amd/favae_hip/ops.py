@@ -219,6 +219,28 @@ def sync_side_stream():
         _SIDE["used"] = False
 
 
+_GRAD_ONLY = None          # None | "data" | "param"  (see grad_only)
+
+
+class grad_only:
+    """Context manager for partial backward passes (the adaptive weight of train_favae.py:32-39 needs d loss / d x_recon and
+    d x_recon / d last-layer-weight, nothing else): "data" -> conv nodes skip their weight / bias gradients, "param" -> conv
+    nodes skip the data gradient (and the GroupNorm backward behind it).  Skipped gradients are returned as None, so the mode
+    must only be used around autograd.grad() calls that do not ask for them."""
+
+    def __init__(self, what):
+        assert what in ("data", "param")
+        self.what = what
+
+    def __enter__(self):
+        global _GRAD_ONLY
+        self.prev, _GRAD_ONLY = _GRAD_ONLY, self.what
+
+    def __exit__(self, *a):
+        global _GRAD_ONLY
+        _GRAD_ONLY = self.prev
+
+
 class no_direct_grad:
     """Context manager: gradients are returned to autograd instead of being accumulated straight into the flat gradient
     buffer -- needed by torch.autograd.grad() calls (the adaptive weight of train_favae.py:32-39), which must neither touch
@@ -374,6 +396,12 @@ class FusedConvFn(torch.autograd.Function):
         _, Cout, Ho, Wo = dy.shape
         dev = x.device
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = ctx.has_b and ctx.needs_input_grad[2]
+        has_gn = ctx.has_gn
+        if _GRAD_ONLY == "data":
+            need_w = need_b = False
+        elif _GRAD_ONLY == "param":
+            need_x = has_gn = False
         dx = dw = db = dgw = dgb = None
         late_wgrad = None
         gather = GATHER_UPSAMPLE2 if cfg.upsample else GATHER_PLAIN
@@ -382,7 +410,7 @@ class FusedConvFn(torch.autograd.Function):
         # range of dy for the fp16 split scheme: read off the bias-gradient pass when there is one
         want_range = xb is not None and _fp16_planes()
         dyb = torch.empty((1,), dtype=torch.float32, device=dev) if want_range else None
-        if ctx.has_b and ctx.needs_input_grad[2]:
+        if need_b:
             M = N * Ho * Wo
             ws = workspace(query("favae_colsum_workspace", M, Cout), dev)
             tgt = _direct_grad(p_b)
@@ -421,15 +449,15 @@ class FusedConvFn(torch.autograd.Function):
                 # launched AFTER this conv's data gradient (below): the side stream then starts it next to the HBM-bound
                 # GroupNorm-backward / bias-gradient kernels that follow instead of next to the other matrix-bound kernel
                 # (measured: 204 -> 196 ms/step; launching it before the data gradient only gave 208 -> 204)
-                if need_x or ctx.has_gn:
+                if need_x or has_gn:
                     late_wgrad = side_wgrad
                 else:
                     side_wgrad()
             else:                                             # accumulate straight into the flat gradient buffer
                 call("favae_conv_wgrad", byref(d), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(tgt), 1,
                      ptr(ws), ws.numel())
-        if need_x or ctx.has_gn:
-            if ctx.has_gn and mean is None:
+        if need_x or has_gn:
+            if has_gn and mean is None:
                 raise RuntimeError("gradient through a normalisation with frozen (running) statistics is not implemented")
             phased = None
             if (cfg.stride == 2 and not cfg.upsample and cfg.kh == 3 and cfg.kw == 3 and cfg.pad == 0 and cfg.pad_br == 1
@@ -473,7 +501,7 @@ class FusedConvFn(torch.autograd.Function):
                 dlow = new_cl(N, Cin, Hin, Win, dev)
                 call("favae_upsample2x_bwd", ptr(da), ptr(dlow), N, Hin, Win, Cin)
                 da = dlow
-            if ctx.has_gn:
+            if has_gn:
                 dx = new_cl(N, Cin, Hin, Win, dev)
                 tg, tb = _direct_grad(p_gw), _direct_grad(p_gb)
                 direct = tg is not None and tb is not None

@@ -163,22 +163,47 @@ class TrainStep:
             loss_g = loss_g + out["loss_sl"]
         if self.train_disc:                                  # train_favae.py:82-88
             out["loss_disc"] = hinge_g_loss(_logits_fake)
-            out["weight_d"] = self.adaptive_weight(loss_recon, out["loss_disc"])
+            out["weight_d"], g_recon, g_disc = self.adaptive_weight(loss_recon, out["loss_disc"], x_recon)
+            # loss_g.backward() would walk the LPIPS stack and the discriminator a second time to reach x_recon; their
+            # gradients at x_recon are already known from the adaptive weight, so step() back-propagates
+            #   rest = loss_g - loss_recon - w_d * disc_weight * loss_disc      (everything else, through the graph)
+            #   x_recon <- g_recon + w_d * disc_weight * g_disc                 (handed in at x_recon)
+            # -- the same total gradient for encoder / decoder / quantizer.  The discriminator's own stage-0 gradients, which
+            # the reference computes here and discards at opt_d.zero_grad() (train_favae.py:109), are not computed at all.
+            out["_bwd"] = (loss_g - loss_recon, x_recon, g_recon + (out["weight_d"] * self.disc_weight) * g_disc)
             loss_g = loss_g + out["weight_d"] * self.disc_weight * out["loss_disc"]
         out["logits_fake"] = _logits_fake
         out["loss_g"] = loss_g
         out["x_recon"] = x_recon
         return out
 
-    def adaptive_weight(self, loss_recon, loss_disc):
+    def adaptive_weight(self, loss_recon, loss_disc, x_recon):
         """compute_adaptive_weight (train_favae.py:32-39): ratio of the gradient norms at decoder.final[2].weight, clamped to
-        [0, 1e4] and detached.  Kept as a device scalar (the reference syncs with .item() here)."""
+        [0, 1e4] and detached.  Kept as a device scalar (the reference syncs with .item() here).
+        d loss / d last = (d loss / d x_recon) pulled back through the final conv only, so each loss is back-propagated to
+        x_recon ONCE (data gradients only: the LPIPS stack is frozen, the discriminator's stage-0 weight gradients are never
+        used) and only the final conv's weight gradient is evaluated on top; the two x_recon gradients are returned for reuse
+        by the main backward.  Returns (weight, d loss_recon / d x_recon, d loss_disc / d x_recon)."""
         last = self.model.decoder.final[2].weight
         with K.no_direct_grad():
-            grad_disc = torch.autograd.grad(loss_disc, last, retain_graph=True)[0]
-            grad_recon = torch.autograd.grad(loss_recon, last, retain_graph=True)[0]
+            with K.grad_only("data"):
+                g_recon = torch.autograd.grad(loss_recon, x_recon, retain_graph=True)[0]
+                g_disc = torch.autograd.grad(loss_disc, x_recon, retain_graph=True)[0]
+            with K.grad_only("param"):
+                grad_recon = torch.autograd.grad(x_recon, last, g_recon, retain_graph=True)[0]
+                grad_disc = torch.autograd.grad(x_recon, last, g_disc, retain_graph=True)[0]
         w = torch.norm(grad_recon) / (torch.norm(grad_disc) + 1e-4)
-        return torch.clamp(w, 0.0, 1e4).detach()
+        return torch.clamp(w, 0.0, 1e4).detach(), g_recon.detach(), g_disc.detach()
+
+    def backward(self, out):
+        """loss_g.backward() of train_favae.py:105 on the dict losses() returned.  With discriminator training the gradients of
+        loss_recon and loss_disc at x_recon were already computed for the adaptive weight and are handed in there (see losses())."""
+        bwd = out.pop("_bwd", None)
+        if bwd is None:
+            out["loss_g"].sum().backward()
+        else:
+            rest, x_recon, g_x = bwd
+            torch.autograd.backward([rest.sum(), x_recon], [None, g_x])
 
     def disc_step(self, x):
         """Stage 1 (train_favae.py:108-116): discriminator update on (x, x_recon.detach()); model(x, stage=1) recomputes the
@@ -198,7 +223,7 @@ class TrainStep:
         self.gflat.zero_()
         K.set_dropout_seed(self.t + 1)                       # dropout sites (attention FCM only): fresh masks every step
         out = self.losses(x)
-        out["loss_g"].sum().backward()
+        self.backward(out)
         K.sync_side_stream()                                 # weight gradients run on a second stream (ops._SIDE)
         if self.distributed:
             dist.all_reduce(self.gflat)                      # RCCL over xGMI; averaged inside the Adam kernel

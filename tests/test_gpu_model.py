@@ -283,7 +283,7 @@ def test_gan_iteration_against_reference_golden(golden_dir):
     # gradients must be read before Adam consumes them: run the pieces of TrainStep.step() by hand
     ts.gflat.zero_()
     out = ts.losses(x)
-    out["loss_g"].sum().backward()
+    ts.backward(out)
     named = dict(model.named_parameters())
     res = {"loss_disc": out["loss_disc"].detach().cpu(), "weight_d": float(out["weight_d"]), "loss_g": out["loss_g"].detach().cpu(),
            "logits_fake": out["logits_fake"].detach().cpu(),
