@@ -34,6 +34,7 @@ struct FftArgs {
     long plane_outer_div;  // outer index -> n : n = outer / plane_outer_div
     float scale;           // 1/sqrt(L)
     int inverse;
+    int generic;           // L is not a power of two: direct O(L^2) DFT per line instead of the radix-2 butterflies
 };
 
 enum { IN_COMPLEX = 0, IN_DIFF = 1, IN_HALF = 2 };   // IN_HALF: bins l > L/2 are the conjugates of bins L - l
@@ -42,14 +43,15 @@ enum { OUT_COMPLEX = 0, OUT_COMPLEX_MAX = 1, OUT_REAL = 2 };
 template <int IN, int OUT>
 __global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float2* tw = reinterpret_cast<float2*>(sm);                 // [L/2]
-    float2* data = reinterpret_cast<float2*>(sm) + (a.L / 2 > 0 ? a.L / 2 : 1);   // [L][IC]
     const int L = a.L, IC = a.IC, tid = threadIdx.x;
+    const int NTW = a.generic ? L : (L / 2 > 0 ? L / 2 : 1);    // twiddles: e^(-+2 pi i j / L), j < L/2 (all j for the direct DFT)
+    float2* tw = reinterpret_cast<float2*>(sm);                 // [NTW]
+    float2* data = reinterpret_cast<float2*>(sm) + NTW;         // [L][IC]
     const long chunks = (a.inner + IC - 1) / IC;
     const long o = blockIdx.x / chunks;
     const long i0 = (blockIdx.x % chunks) * IC;
 
-    for (int j = tid; j < L / 2; j += 256) {
+    for (int j = tid; j < (a.generic ? L : L / 2); j += 256) {
         float s, c;
         sincospif(2.0f * (float)j / (float)L, &s, &c);
         tw[j] = make_float2(c, a.inverse ? s : -s);
@@ -89,8 +91,8 @@ __global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs a) {
             const int l = l0 + u * BL;
             if (l < L) {
                 if (IN == IN_DIFF) v[u].x -= t[u];
-                const int r = (int)(__brev((unsigned)l) >> (32 - a.logL));
-                data[(a.logL ? r : 0) * IC + ic] = v[u];
+                const int r = a.generic ? l : (a.logL ? (int)(__brev((unsigned)l) >> (32 - a.logL)) : 0);
+                data[r * IC + ic] = v[u];
             }
         }
     }
@@ -104,7 +106,8 @@ __global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs a) {
         x0 = make_float2(x0.x + t.x, x0.y + t.y);
     };
     int s = 1;
-    if (a.logL & 1) {                                          // odd number of stages: one plain radix-2 stage first
+    if (a.generic) s = a.logL + 1;                             // no butterflies: the store phase evaluates the DFT sums
+    else if (a.logL & 1) {                                     // odd number of stages: one plain radix-2 stage first
         for (int b = bl; b < L / 2; b += BL) {
             const int p0 = b << 1;
             float2 x0 = data[p0 * IC + ic], x1 = data[(p0 + 1) * IC + ic];
@@ -140,7 +143,24 @@ __global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs a) {
     float mx = 0.f;
     const float gs = (OUT == OUT_REAL) ? a.gscale[0] * a.scale : a.scale;
     for (int l = bl; l < (OUT == OUT_REAL ? L : a.Lout); l += BL) {
-        float2 v = data[l * IC + ic];
+        float2 v;
+        if (a.generic) {
+            // any length (FA-VAE at resolutions that are not powers of two, e.g. 192 -> 12 x 12 latents): bin l of the line is
+            // sum_m data[m] w^(l m), the twiddle index (l m) mod L kept incrementally; data[m] is read by all bins of a column
+            // (conflict-free across ic), the twiddle is a broadcast.  O(L^2) per line -- a fallback, not the fast path.
+            float2 acc = make_float2(0.f, 0.f);
+            int j = 0;
+            for (int m = 0; m < L; ++m) {
+                const float2 d = data[m * IC + ic], w = tw[j];
+                acc.x = fmaf(d.x, w.x, fmaf(-d.y, w.y, acc.x));
+                acc.y = fmaf(d.x, w.y, fmaf(d.y, w.x, acc.y));
+                j += l;
+                if (j >= L) j -= L;
+            }
+            v = acc;
+        } else {
+            v = data[l * IC + ic];
+        }
         if (OUT == OUT_REAL) {
             const size_t idx = base + (size_t)l * a.inner;
             const float r = v.x * gs;
@@ -205,7 +225,9 @@ int ilog2(int v) {
 }
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 int pick_ic(int L) { return L <= 256 ? 32 : (L <= 512 ? 16 : 8); }
-size_t fft_shm(int L, int IC) { return ((size_t)(L / 2 > 0 ? L / 2 : 1) + (size_t)L * IC) * sizeof(float2); }
+size_t fft_shm(int L, int IC, bool generic) {
+    return ((size_t)(generic ? L : (L / 2 > 0 ? L / 2 : 1)) + (size_t)L * IC) * sizeof(float2);
+}
 constexpr int WEIGHT_BLOCKS = 2048;
 
 template <int IN, int OUT>
@@ -215,7 +237,8 @@ int launch_fft(FftArgs& a, hipStream_t s) {
     if (a.Lin <= 0) a.Lin = a.L;
     if (a.Lout <= 0) a.Lout = a.L;
     a.scale = 1.0f / sqrtf((float)a.L);
-    const size_t shm = fft_shm(a.L, a.IC);
+    a.generic = pow2(a.L) ? 0 : 1;
+    const size_t shm = fft_shm(a.L, a.IC, a.generic != 0);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)fft_lines_kernel<IN, OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -245,7 +268,7 @@ extern "C" size_t favae_ffl_workspace(int N, int H, int W, int C) {
 extern "C" int favae_ffl_fwd(const float* pred, const float* target, int N, int H, int W, int C, float loss_weight, float* loss,
                              float* spec, void* ws, size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(pred && target && loss && spec && ws && N > 0 && C > 0);
-    if (!pow2(H) || !pow2(W) || H > 1024 || W > 1024) return FAVAE_ERR_UNSUPPORTED;
+    if (H < 1 || W < 1 || H > 1024 || W > 1024) return FAVAE_ERR_UNSUPPORTED;
     if (ws_bytes < favae_ffl_workspace(N, H, W, C)) return FAVAE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     unsigned* planemax = (unsigned*)ws;
@@ -279,7 +302,7 @@ extern "C" int favae_ffl_fwd(const float* pred, const float* target, int N, int 
 extern "C" int favae_ffl_bwd(const float* spec, const float* gloss, int N, int H, int W, int C, float* gpred, float* gtarget,
                              void* ws, size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(spec && gloss && gpred && ws && N > 0 && C > 0);
-    if (!pow2(H) || !pow2(W) || H > 1024 || W > 1024) return FAVAE_ERR_UNSUPPORTED;
+    if (H < 1 || W < 1 || H > 1024 || W > 1024) return FAVAE_ERR_UNSUPPORTED;
     if (ws_bytes < favae_ffl_workspace(N, H, W, C)) return FAVAE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     FftArgs a{};

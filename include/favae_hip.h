@@ -196,7 +196,8 @@ int favae_blur_bwd(const float* x, const float* dy, const float* sigma, int ksiz
 /* ------------------------------------------------------------------------------------------------------------
  * Focal-frequency / dynamic-spectrum loss.  Replaces focal_frequency_loss.FocalFrequencyLoss(loss_weight, alpha=1)
  * (pip 0.3.0; call sites favae_scripts/train_favae.py:313,318,326, losses/vqgan_losses.py:14,25-26).
- * H and W must be powers of two <= 1024.
+ * 1 <= H, W <= 1024.  Power-of-two lengths (every shipped FA-VAE configuration: 256, 64, 16) run the in-LDS radix-2 FFT; any other
+ * length runs a direct O(L^2) DFT per line in the same kernel (same passes, same half-spectrum layout) -- a correct fallback, not a fast path.
  *   loss = loss_weight * mean( w * |F|^2 ),  F = fft2_ortho(pred - target),  w = clamp(|F| / max_plane|F|, 0, 1), NaN -> 0
  * `spec` (N*H*(W/2+1)*C*2 floats: the input is real, only the bins k <= W/2 of the Hermitian spectrum are kept; the loss counts
  * the others through their mirror images) receives (2*loss_weight/M) * w * F, from which favae_ffl_bwd forms

@@ -146,6 +146,15 @@ def test_train_step_f4_against_reference_golden(golden_dir):
     _golden_step(g, "f4_same_conv_32", "f4_same_conv")
 
 
+@pytest.mark.parametrize("gtag,mtag", [("cfg1_96", "cfg1"), ("nonpair_conv_80", "nonpair_conv")])
+def test_train_step_non_pow2_resolution_against_reference_golden(golden_dir, gtag, mtag):
+    """Full step (losses incl. FFL / DSL, gradients) at resolutions that are not powers of two -- 96x96 (6x6 latents) and 80x80
+    (5x5 latents, 5-tap blur on a 5-pixel map) -- against the reference's outputs: the focal-frequency loss runs the any-length
+    DFT fallback here, the blur its generic tile kernel."""
+    g = np.load(os.path.join(golden_dir, "models.npz"))
+    _golden_step(g, gtag, mtag)
+
+
 def test_train_step_cfg1_256_against_reference_golden(golden_dir):
     """BASELINE config 1 at full size: f=16, codebook 1024, 256x256, batch 2, FFL + DSL on."""
     g = np.load(os.path.join(golden_dir, "cfg1_256.npz"))

@@ -327,8 +327,26 @@ def test_ffl_known_answers(K):
     assert abs(float(K.focal_frequency_loss(p, torch.zeros_like(p), 1.0)) - A * A / 2) < 1e-6   # cosine -> A^2/2
 
 
-def test_ffl_rejects_non_pow2(K):
-    p = torch.zeros(1, 4, 6, 6, device=dev())
+@pytest.mark.parametrize("shape", [(2, 3, 12, 12), (1, 8, 6, 10), (2, 16, 24, 40), (1, 4, 15, 9), (1, 32, 16, 12), (1, 2, 5, 64),
+                                   (1, 3, 192, 192)])
+def test_ffl_any_length_vs_oracle(K, shape):
+    """Lengths that are not powers of two (the reference accepts any --resolution: 192 -> 12 x 12 latents; odd lengths have no
+    Nyquist bin) run the direct-DFT fallback of the line kernel: value 1e-4, gradients 1e-4 against the oracle."""
+    p = rnd(shape, 41).requires_grad_(True)
+    t = rnd(shape, 42).requires_grad_(True)
+    l = O.focal_frequency_loss(p, t, 0.37)
+    l.backward()
+    pd = p.detach().to(dev()).requires_grad_(True)
+    td = t.detach().to(dev()).requires_grad_(True)
+    ld = K.focal_frequency_loss(pd, td, 0.37)
+    ld.backward()
+    assert abs(float(ld) - float(l)) <= 1e-4 * abs(float(l)), (float(ld), float(l))
+    check(pd.grad, p.grad, 1e-4, "gpred")
+    check(td.grad, t.grad, 1e-4, "gtarget")
+
+
+def test_ffl_rejects_oversized_lines(K):
+    p = torch.zeros(1, 1, 2, 1025, device=dev())
     with pytest.raises(RuntimeError):
         K.focal_frequency_loss(p, p, 1.0)
 
