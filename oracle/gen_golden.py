@@ -312,9 +312,20 @@ GRAD_KEYS = ["encoder.conv_in.weight", "encoder.conv_in.bias", "decoder.final.2.
              "encoder.down.2.conv.weight", "decoder.up.6.conv.bias"]
 
 
-def gen_models():
+# the two remaining FCM / DSL wirings of models/vqgan_fcm.py:58-96 (pair-wise sigmas with residual FCMs; conv FCM + FFL without blur)
+MODEL_CASES_VARIANTS = {
+    "same_resblock_64": (dict(codebook_size=256, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
+                              use_l2_quantizer=True, kernel_size=3, dsl_init_sigma=3.0, use_same_gauss_resblock=True, device="cpu"),
+                         dict(codebook_size=256, variant="same_gauss_resblock", kernel_size=3), (1, 64, 64), 21),
+    "ffl_with_fcm_64": (dict(codebook_size=256, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
+                             use_l2_quantizer=True, use_ffl_with_fcm=True, dsl_init_sigma=3.0, device="cpu"),
+                        dict(codebook_size=256, variant="ffl_with_fcm"), (2, 64, 64), 22),
+}
+
+
+def gen_models(cases=None, fname="models.npz"):
     out = {}
-    for tag, (mk, ok, (B, H, W), seed) in MODEL_CASES.items():
+    for tag, (mk, ok, (B, H, W), seed) in (cases or MODEL_CASES).items():
         print("model case", tag, flush=True)
         model = VQGANFCM(**mk)
         P = fill_module(model, "", sigma0=mk["dsl_init_sigma"])
@@ -363,7 +374,7 @@ def gen_models():
                 check(f"{tag}/g.{k}", Po[k].grad, g, tol=2e-3)
         out[p + "shape"] = np.array([B, H, W, seed], np.int64)
         del model, model2
-    np.savez_compressed(os.path.join(OUT, "models.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
 def gen_cfg1_full():
@@ -692,7 +703,7 @@ def gen_attn_fcm():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["blocks", "blur", "vq", "hinge", "models", "cfg1", "gan", "lpips", "attn_fcm"]
+    which = sys.argv[1:] or ["blocks", "blur", "vq", "hinge", "models", "cfg1", "gan", "lpips", "attn_fcm", "variants"]
     if "blocks" in which:
         gen_blocks()
     if "blur" in which:
@@ -711,6 +722,8 @@ if __name__ == "__main__":
         gen_lpips_head()
     if "attn_fcm" in which:
         gen_attn_fcm()
+    if "variants" in which:
+        gen_models(MODEL_CASES_VARIANTS, "models_variants.npz")
     print("oracle-vs-reference max relative differences:")
     for name, r in report:
         print(f"  {name:55s} {r:.3e}")

@@ -155,6 +155,13 @@ def test_train_step_non_pow2_resolution_against_reference_golden(golden_dir, gta
     _golden_step(g, gtag, mtag)
 
 
+@pytest.mark.parametrize("gtag,mtag", [("same_resblock_64", "same_resblock"), ("ffl_with_fcm_64", "ffl_with_fcm")])
+def test_train_step_variants_against_reference_golden(golden_dir, gtag, mtag):
+    """The two remaining FCM / DSL wirings (pair-wise sigmas + residual FCMs; conv FCM + FFL without blur) against the reference."""
+    g = np.load(os.path.join(golden_dir, "models_variants.npz"))
+    _golden_step(g, gtag, mtag)
+
+
 def test_train_step_cfg1_256_against_reference_golden(golden_dir):
     """BASELINE config 1 at full size: f=16, codebook 1024, 256x256, batch 2, FFL + DSL on."""
     g = np.load(os.path.join(golden_dir, "cfg1_256.npz"))

@@ -199,6 +199,20 @@ def test_model_cases(golden_dir, tag):
     _check_model_case(g, tag, O.OracleConfig(**MODEL_CFGS[tag]))
 
 
+MODEL_CFGS_VARIANTS = {
+    "same_resblock_64": dict(codebook_size=256, variant="same_gauss_resblock", kernel_size=3),
+    "ffl_with_fcm_64": dict(codebook_size=256, variant="ffl_with_fcm"),
+}
+
+
+@pytest.mark.parametrize("tag", list(MODEL_CFGS_VARIANTS))
+def test_model_variant_cases(golden_dir, tag):
+    """pair-wise sigmas with residual FCMs (--use_same_gauss_resblock) and conv FCM + FFL without blur (--use_ffl_with_fcm):
+    reference outputs in tests/golden/models_variants.npz (oracle/gen_golden.py variants)"""
+    g = np.load(os.path.join(golden_dir, "models_variants.npz"))
+    _check_model_case(g, tag, O.OracleConfig(**MODEL_CFGS_VARIANTS[tag]))
+
+
 def test_param_inventory_matches_reference_count():
     # SURVEY section 5: 371 state_dict entries for the f=16 Res-FCM model (incl. discriminator)
     cfg = O.OracleConfig(codebook_size=1024, variant="gauss_resblock")
