@@ -635,7 +635,12 @@ def gen_attn_fcm():
         out[f"{name}.x"], out[f"{name}.y"], out[f"{name}.gy"], out[f"{name}.gx"] = npy(x), npy(y), npy(gy), npy(x.grad)
         out[f"{name}.y_eval"] = npy(y_eval)
         for k, prm in mod.named_parameters():
-            out[f"{name}.g.{k}"] = npy(prm.grad)
+            if prm.numel() <= 16384:
+                out[f"{name}.g.{k}"] = npy(prm.grad)
+            else:                                         # large weight gradients: summaries keep the fixture small
+                out[f"{name}.gsum.{k}"] = np.float64(prm.grad.double().sum().item())
+                out[f"{name}.gabs.{k}"] = np.float64(prm.grad.double().abs().sum().item())
+                out[f"{name}.ghead.{k}"] = npy(prm.grad.reshape(-1)[:256])
         Po = leafify({k: v.clone() for k, v in P.items()})
         xo = x.detach().clone().requires_grad_(True)
         yo = O.trans_encoder_block(Po, "blk", xo, training=True, drop=None)

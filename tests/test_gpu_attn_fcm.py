@@ -141,8 +141,9 @@ def test_trans_encoder_block_against_reference_golden(golden_dir, name, C):
     (y * torch.from_numpy(g[name + ".gy"]).to(DEV)).sum().backward()
     assert rel(y, g[name + ".y"]) < 2e-5
     assert rel(x.grad, g[name + ".gx"]) < 1e-4
+    from test_oracle_golden import _check_grad_fixture
     for k, p in mod.named_parameters():
-        assert rel(p.grad, g[name + ".g." + k]) < 2e-4, k
+        _check_grad_fixture(g, name, k, p.grad, rel, 2e-4)
 
 
 def test_trans_encoder_block_train_mode_dropout_vs_oracle():

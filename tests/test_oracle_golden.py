@@ -349,6 +349,19 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def _check_grad_fixture(g, name, k, grad, rel_fn, tol):
+    """full gradient when the fixture holds it, else its summaries (sum / abs-sum / first 256 elements)"""
+    full = name + ".g." + k
+    if full in g.files:
+        assert rel_fn(grad, g[full]) < tol, k
+        return
+    gd = grad.detach().cpu().double()
+    ga = float(g[name + ".gabs." + k])
+    assert abs(float(gd.sum()) - float(g[name + ".gsum." + k])) < tol * ga, k
+    assert abs(float(gd.abs().sum()) - ga) < tol * ga, k
+    assert rel_fn(grad.detach().cpu().reshape(-1)[:256], g[name + ".ghead." + k]) < 10 * tol, k
+
+
 # --------------------------------------------------------------------------------------------------------------
 # attention FCM (--use_gauss_attn, SURVEY 8(f).2): TransEncoderBlock and the DecoderFcmAttnGauss model, reference captured with
 # every dropout probability set to 0 (train mode) and in eval mode (oracle/gen_golden.py:gen_attn_fcm)
@@ -369,7 +382,7 @@ def test_trans_encoder_block_against_reference_golden(golden_dir, name, C):
     assert _rel(y, g[name + ".y_eval"]) < 2e-5
     assert _rel(x.grad, g[name + ".gx"]) < 1e-4
     for k in P:
-        assert _rel(P[k].grad, g[name + ".g." + k[4:]]) < 1e-4, k
+        _check_grad_fixture(g, name, k[4:], P[k].grad, _rel, 1e-4)
 
 
 def test_gauss_attn_model_against_reference_golden(golden_dir):
