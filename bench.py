@@ -98,8 +98,12 @@ class ConvEventHook:
         xf = 0 if not has_affine else {0: 1, 1: 2, 2: 3, 3: 3}[d.act]
         halo = (d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1 and d.gather == 0 and d.Hout == d.Hin and
                 d.Wout == d.Win and d.Hin % 8 == 0 and d.Win % 16 == 0)
-        if halo:
+        if halo and d.lat_step != 2 and d.pad_dw == 0:
             return "conv3x3_halo_sp_kernel<%d, %d>" % (xf, planes)
+        halo2 = (d.KH == 2 and d.KW == 2 and d.stride == 1 and d.gather == 0 and d.lat_step == 2 and d.Hout == d.Hin and
+                 d.Wout == d.Win and d.Hin % 8 == 0 and d.Win % 16 == 0 and xf == 0 and os.environ.get("FAVAE_CONV_HALO2", "1") != "0")
+        if halo2:
+            return "conv3x3_halo_sp_kernel<0, %d, 2>" % planes      # 2x2 phase convs (Upsample, Downsample data gradient)
         return "conv_fwd_sp_kernel<%d, %d, true, 8, %d>" % (d.gather, xf, planes)
 
     def __call__(self, name, args, launch):
@@ -269,7 +273,7 @@ def main():
         }
         if conv:
             def entry(kn, c):
-                planes = int(kn.rstrip(">").split(",")[-1])
+                planes = int(kn.rstrip(">").split(",")[1 if kn.startswith("conv3x3_halo") else -1])
                 peak = PEAK_16BIT_MFMA_TFLOPS / SPLIT_PRODUCTS[planes]
                 e = excl.get(kn)
                 return {"bound": "mfma", "achieved": c["tflops"], "peak": peak, "unit": "TFLOP/s",

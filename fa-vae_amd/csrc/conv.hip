@@ -45,6 +45,12 @@ int conv_mode() {
     return g_conv_mode;
 }
 bool use_b6() { return conv_mode() != 0; }
+// FAVAE_CONV_HALO2=0 sends the 2x2 phase convs back to the im2col split kernel (A/B switch)
+bool use_halo2() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FAVAE_CONV_HALO2"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
 // FAVAE_WGRAD_ROW3=0 disables the three-taps-per-workgroup weight-gradient kernel (A/B switch)
 bool use_row3() {
     static int v = -1;
@@ -884,23 +890,29 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         else if (bn == 64) hipLaunchKernelGGL((conv_fwd_buf_kernel<64, 2, 2, G, X>), grid, blk, 0, s, a);          \
         else hipLaunchKernelGGL((conv_fwd_buf_kernel<32, 4, 1, G, X>), grid, blk, 0, s, a);                        \
     } while (0)
-    const bool halo_ok = !special && buf_ok && use_b6() && w6 && use_halo() && bn == 128 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
-                         d->pad == 1 && d->gather == FAVAE_GATHER_PLAIN && d->Hout == d->Hin && d->Wout == d->Win &&
-                         d->Hin % 8 == 0 && d->Win % 16 == 0;
-    if (halo_ok) {
+    const bool halo_common = buf_ok && use_b6() && w6 && use_halo() && bn == 128 && d->stride == 1 && d->gather == FAVAE_GATHER_PLAIN &&
+                             d->Hout == d->Hin && d->Wout == d->Win && d->Hin % 8 == 0 && d->Win % 16 == 0;
+    const bool halo_ok = !special && halo_common && d->KH == 3 && d->KW == 3 && d->pad == 1;
+    // 2x2 phase convs (Upsample forward / data gradient, first phase of the Downsample data gradient): one side on a sub-grid
+    const bool halo2_ok = special && halo_common && use_halo2() && d->KH == 2 && d->KW == 2 && d->lat_step == 2 && xf == 0 &&
+                          (d->pad == 0 || d->pad == 1) && (a.pad_w == 0 || a.pad_w == 1);
+    if (halo_ok || halo2_ok) {
         a.tiles_n = cdiv(d->Cout, 128);
         const dim3 hgrid((unsigned)(d->N * (d->Hin / 8) * (d->Win / 16) * a.tiles_n));
-#define FAVAE_LAUNCH_HALO(X)                                                                              \
-    do {                                                                                                  \
-        if (wplanes == 2) hipLaunchKernelGGL((conv3x3_halo_sp_kernel<X, 2>), hgrid, dim3(512), 0, s, a);  \
-        else if (wplanes == 1) hipLaunchKernelGGL((conv3x3_halo_sp_kernel<X, 1>), hgrid, dim3(512), 0, s, a); \
-        else hipLaunchKernelGGL((conv3x3_halo_sp_kernel<X, 3>), hgrid, dim3(512), 0, s, a);               \
+#define FAVAE_LAUNCH_HALO_K(X, KS)                                                                            \
+    do {                                                                                                      \
+        if (wplanes == 2) hipLaunchKernelGGL((conv3x3_halo_sp_kernel<X, 2, KS>), hgrid, dim3(512), 0, s, a);  \
+        else if (wplanes == 1) hipLaunchKernelGGL((conv3x3_halo_sp_kernel<X, 1, KS>), hgrid, dim3(512), 0, s, a); \
+        else hipLaunchKernelGGL((conv3x3_halo_sp_kernel<X, 3, KS>), hgrid, dim3(512), 0, s, a);               \
     } while (0)
-        if (xf == 0) FAVAE_LAUNCH_HALO(0);
+#define FAVAE_LAUNCH_HALO(X) FAVAE_LAUNCH_HALO_K(X, 3)
+        if (halo2_ok) FAVAE_LAUNCH_HALO_K(0, 2);
+        else if (xf == 0) FAVAE_LAUNCH_HALO(0);
         else if (xf == 1) FAVAE_LAUNCH_HALO(1);
         else if (xf == 2) FAVAE_LAUNCH_HALO(2);
         else FAVAE_LAUNCH_HALO(3);
 #undef FAVAE_LAUNCH_HALO
+#undef FAVAE_LAUNCH_HALO_K
     } else if (buf_ok && use_b6() && bn == 128) {
 #define FAVAE_LAUNCH_B6(G, X)                                                                     \
     do {                                                                                          \

@@ -507,17 +507,19 @@ __global__ __launch_bounds__(256) void split_w_kernel(const float4* __restrict__
 // Per-thread global offsets are constants of the launch: only the scalar offsets advance (K chunk, tap).
 // Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, H % 8 == 0, W % 16 == 0, Cin % 16 == 0, pre-split weights.
 // ---------------------------------------------------------------------------------------------------------------
-template <int XFORM, int NP>
+template <int XFORM, int NP, int KS = 3>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6 : 4, 8))) void conv3x3_halo_sp_kernel(ConvArgs a) {
     using S = sp::Scheme<NP>;
-    constexpr int TH = 8, TW = 16, HW = TW + 2, HROWS = (TH + 2) * HW;          // 180 halo pixels
+    // KS = 3: the 3x3 stride-1 pad-1 conv.  KS = 2: a 2x2 phase conv of an Upsample / of the Downsample data gradient (top / left
+    // padding a.pad / a.pad_w in {0, 1}, ONE side of the conv on every second pixel of a tensor of twice the size: a.in_* / a.out_*).
+    constexpr int TH = 8, TW = 16, HW = TW + KS - 1, HROWS = (TH + KS - 1) * HW, TAPS = KS * KS;   // 3x3: 180 halo pixels
     // halo row pitch = 18 rows rounded up to a multiple of 256 B: pitch % 256 == 0 puts the second tile row of a wave's 32 MFMA
     // rows on the same bank phase as pixels 16..31 of a contiguous run -> the ds_read_b128 fragment reads are conflict-free
     constexpr int HPITCH = (HW * S::ROWB + 255) / 256 * 256;
     static_assert((16 * S::ROWB) % 256 == 0, "row stride must keep 16-pixel runs bank-periodic");
-    constexpr int HALO_B = (TH + 2) * HPITCH, BT_B = 128 * S::ROWB;
+    constexpr int HALO_B = (TH + KS - 1) * HPITCH, BT_B = 128 * S::ROWB;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO_B + 2 * BT_B];
-    unsigned char* Hs = lds;                    // [2][10][HPITCH]
+    unsigned char* Hs = lds;                    // [2][TH + KS - 1][HPITCH]
     unsigned char* Bs = lds + 2 * HALO_B;       // [2][128][ROWB]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = tile % a.tiles_n;
     int spt = tile / a.tiles_n;                 // spatial tile index
-    const int tiles_w = a.Win / TW, tiles_h = a.Hin / TH;
+    const int tiles_w = a.Wout / TW, tiles_h = a.Hout / TH;
     const int tx0 = (spt % tiles_w) * TW; spt /= tiles_w;
     const int ty0 = (spt % tiles_h) * TH;
     const int n = spt / tiles_h;
@@ -550,13 +552,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
         const int hrow = i >> 2;
         const int hy = hrow / HW, hx = hrow - hy * HW;
         hoff[j] = hy * HPITCH + hx * S::ROWB;
-        const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+        const int y = ty0 - a.pad + hy, x = tx0 - a.pad_w + hx;
         hok[j] = hrow < HROWS && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
-        vh[j] = hok[j] ? (unsigned)((((n * a.Hin + y) * a.Win + x) * a.Cin + q4 * 4) * 4) : FAVAE_OOB;
+        vh[j] = hok[j] ? (unsigned)(((n * a.in_img + y * a.in_step * a.in_row + x * a.in_step + a.in_off) * a.Cin + q4 * 4) * 4) : FAVAE_OOB;
     }
     const unsigned vs = (unsigned)((n * a.aff_stride + q4 * 4) * 4);
     const int brow = tid >> 2;                                           // weight row (output channel) staged by this thread
-    const unsigned vb = (n0 + brow < a.Cout) ? (unsigned)(((n0 + brow) * 9 * a.Cin + q4 * 4) / 4 * S::WREC) : FAVAE_OOB;
+    const unsigned vb = (n0 + brow < a.Cout) ? (unsigned)(((n0 + brow) * TAPS * a.Cin + q4 * 4) / 4 * S::WREC) : FAVAE_OOB;
 
     float4 rh[2], rsc, rsh;
     uint2 rbp[NP];
@@ -608,13 +610,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
     for (int kc = 0; kc < KC; ++kc) {
         const int hb = kc & 1;
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap, ++it) {
+        for (int tap = 0; tap < TAPS; ++tap, ++it) {
             const int cur = it & 1;
-            const bool last_tap = tap == 8, more_kc = kc + 1 < KC;
+            const bool last_tap = tap == TAPS - 1, more_kc = kc + 1 < KC;
             if (!last_tap) load_b(kc, tap + 1);
             else if (more_kc) load_b(kc + 1, 0);
-            if (tap == 4 && more_kc) load_halo(kc + 1);                  // in flight over taps 4..8
-            const int kh = tap / 3, kw = tap - kh * 3;
+            if (tap == TAPS / 2 && more_kc) load_halo(kc + 1);           // in flight over the second half of the taps
+            const int kh = tap / KS, kw = tap - kh * KS;
             const unsigned char* Ab = Afr + hb * HALO_B + kh * HPITCH + kw * S::ROWB;
             const unsigned char* Bb = Bfr + cur * BT_B;
             bf16x8_t af[NP], bf[2][NP];
@@ -642,7 +644,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int pr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);          // pixel of the tile
-            const size_t o = ((size_t)((n * a.Hin + ty0 + (pr >> 4)) * a.Win + tx0 + (pr & 15))) * a.Cout + col;
+            const size_t o = ((size_t)n * a.out_img + (size_t)(ty0 + (pr >> 4)) * a.out_step * a.out_row + (tx0 + (pr & 15)) * a.out_step +
+                              a.out_off) * a.Cout + col;
             float v = acc[j][r];
             if constexpr (S::SCALED) v = v * un_a * un_w;
             v += bv;
