@@ -331,7 +331,10 @@ def test_gan_iteration_against_reference_golden(golden_dir):
     # perturbed x_recon (8e-4 on logits_fake_d) then switches individual LeakyReLU slopes in D.  Aggregates stay within 1e-2,
     # single gradient elements within 1e-1.  The tight check of the discriminator's backward itself (5e-4) is
     # test_discriminator_forward_backward_vs_oracle; logits_real / loss_d (unperturbed input) stay at 1e-4.
-    tols = dict(stage0=1e-4, weight_d=2e-3, loss_g=5e-4, grads=5e-3, logits_fake_d=3e-3, dgrad_head=1e-1, dgrad_abs=1e-2, bn=1e-3)
+    # Generator gradients of stage 0 are g_recon + weight_d * disc_weight * g_disc with the two terms largely cancelling behind the
+    # decoder (decoder tensors: <= 1e-3 of the tensor max here; encoder tensors, after the cancellation: 3e-3 .. 6e-3 with either
+    # 2x2-phase kernel family, tools/experiments/gan_grad_err.py) -- bar 1e-2; the un-cancelled training step keeps 5e-3 (_golden_step).
+    tols = dict(stage0=1e-4, weight_d=2e-3, loss_g=5e-4, grads=1e-2, logits_fake_d=3e-3, dgrad_head=1e-1, dgrad_abs=1e-2, bn=1e-3)
     check_gan_golden(g, res, P, lr, close_fn=close_fn, tols=tols)
 
 
