@@ -9,7 +9,7 @@ fused Adam) with the batch already resident in HBM.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement"):
   value      whole-job images/s  (sum over ranks / max-over-ranks time, barrier + synchronize on both sides)
-  roofline   dominant kernel = the conv3x3_halo_sp_kernel<xform, planes> instantiation with the largest time share (3x3
+  roofline   dominant kernel = the conv3x3_halo_sp_kernel<xform, planes, kernel size> instantiation with the largest time share (3x3
              forward / data-gradient conv on the split-precision matrix path): algorithmic FLOPs (2*M*Cout*KH*KW*Cin per
              launch) / launch durations measured with HIP events on the launch stream inside the timed region;
              peak = 2500 TFLOP/s dense 16-bit MFMA / products per fp32 multiply-add (3 with two fp16 planes, 6 with three bf16)
@@ -99,7 +99,7 @@ class ConvEventHook:
         halo = (d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1 and d.gather == 0 and d.Hout == d.Hin and
                 d.Wout == d.Win and d.Hin % 8 == 0 and d.Win % 16 == 0)
         if halo and d.lat_step != 2 and d.pad_dw == 0:
-            return "conv3x3_halo_sp_kernel<%d, %d>" % (xf, planes)
+            return "conv3x3_halo_sp_kernel<%d, %d, 3>" % (xf, planes)
         halo2 = (d.KH == 2 and d.KW == 2 and d.stride == 1 and d.gather == 0 and d.lat_step == 2 and d.Hout == d.Hin and
                  d.Wout == d.Win and d.Hin % 8 == 0 and d.Win % 16 == 0 and xf == 0 and os.environ.get("FAVAE_CONV_HALO2", "1") != "0")
         if halo2:
@@ -294,7 +294,7 @@ def main():
                                        "scaled fp16 planes, 3 v_mfma_f32_32x32x16_f16 products per fp32 multiply-add, peak = 2500/3 "
                                        "TFLOP/s; planes=3 -> three bf16 planes, 6 products, peak = 2500/6; achieved = algorithmic "
                                        "fp32 FLOPs / launch time; template args = <fused input transform (0 plain: data gradients "
-                                       "and un-normalised convs, 2 GroupNorm+SiLU), planes>")
+                                       "and un-normalised convs, 2 GroupNorm+SiLU), planes, kernel size (3: the 3x3 convs, 2: 2x2 phase convs)>")
             res["roofline"]["stream_note"] = ("achieved/frac: launch durations inside the timed region, where weight-gradient kernels "
                                               "run concurrently on a second HIP stream (data-gradient launches share the CUs with "
                                               "them); *_single_stream: the same launches in 2 untimed steps with that stream off")
