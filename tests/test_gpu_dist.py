@@ -24,3 +24,13 @@ def test_bench_under_torchrun_rccl():
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["parallelism"] == "dp1"
     assert res["config"]["loss_g_last"] == res["config"]["loss_g_last"]          # not NaN
+
+
+def test_model_under_torch_ddp():
+    """The drop-in VQGANFCM wrapped in torch DDP(find_unused_parameters=True, broadcast_buffers=True) -- what accelerate.prepare does
+    to it in the reference's train_favae.py -- trains one iteration with torch.optim.Adam and lands on the parameters of the
+    unwrapped run (child process: it owns a process group)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ddp_probe.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    assert "DDP PROBE OK" in out.stdout
