@@ -65,7 +65,7 @@ def parse():
                     help="celeba_f16 = BASELINE configs[1] (the headline metric, default); imagenet_f4 = configs[3]; ffhq_f16 = "
                          "the model of configs[4] (add --gan --lpips for its loss path; fp32 here, not bf16)")
     ap.add_argument("--lpips", action="store_true",
-                    help="add the perceptual term lpips(x, x_recon) (train_favae.py:77-79) on deterministic stand-in VGG16/lin "
+                    help="add the perceptual term lpips(x, x_recon) (train_favae.py:77-79) on random-init VGG16/lin "
                          "weights (vgg16_lpips.pt is not available offline: timing only) -- not the headline workload")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
                     help="fp32 (default, the headline: fp32-grade convs by operand splitting, parity 1e-4) or fp16 = the 16-bit "
@@ -186,8 +186,8 @@ def main():
     dev = torch.device("cuda", local)
 
     import favae_hip
-    import favae_oracle as O                       # deterministic synthetic data only (det_input); checker otherwise
     from favae_step import TrainStep
+    from utils import synthetic_batch              # the GPU leg never touches oracle/ (only cpu_baseline() below does)
     from models.vqgan_fcm import VQGANFCM
 
     favae_hip.load()
@@ -202,12 +202,11 @@ def main():
     lpips = None
     if args.lpips:
         from losses.lpips import LPIPS
-        lpips = LPIPS(pretrained=False)
-        lpips.load_state_dict(O.lpips_det_state(), strict=True)
+        lpips = LPIPS(pretrained=False)            # random-init VGG16 / lin weights (vgg16_lpips.pt is not available offline)
         lpips = lpips.to(dev).eval()               # train_favae.py:308
     ts = TrainStep(model, lr=lr, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, distributed=use_dist, train_disc=args.gan,
                    lpips=lpips, perceptual_weight=1.0)
-    xs = [O.det_input(args.batch, args.res, args.res, 1234 + 17 * rank + i).to(dev) for i in range(2)]
+    xs = [synthetic_batch(args.batch, args.res, args.res, 1234 + 17 * rank + i).to(dev) for i in range(2)]
 
     hook = ConvEventHook(torch)
     favae_hip.set_call_hook(hook)
@@ -266,7 +265,7 @@ def main():
             "config": {"workload": (desc % args.codebook) + ", FFL 1.0 + DSL 0.01, %dx%d, batch %d per GPU, stage-0 step "
                                    "(LPIPS/disc training off, disc forward on)" % (args.res, args.res, args.batch)
                                    + (" + discriminator training (hinge, adaptive weight, stage 1)" if args.gan else "")
-                                   + (" + LPIPS perceptual term (stand-in weights)" if args.lpips else "")
+                                   + (" + LPIPS perceptual term (random-init weights: timing only)" if args.lpips else "")
                                    + (" -- MIXED PRECISION: conv operands in one scaled fp16 plane (FAVAE_CONV_MODE=h1), fp32 "
                                       "accumulation; not fp32-grade, not the headline" if args.precision == "fp16" else ""),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss_g_last": loss},

@@ -1,4 +1,4 @@
-"""Harness helpers the reference training script imports (reference utils.py:108-119)."""
+"""Harness helpers the reference training script imports (reference utils.py:108-119), and the synthetic image batch of bench.py."""
 import os
 
 import torch
@@ -13,3 +13,29 @@ def save_model(state, path):
     os.replace(tmp, path)
     if os.path.exists(old):
         os.remove(old)
+
+
+def synthetic_batch(B, H, W, seed=1234, dtype=torch.float32):
+    """Synthetic RGB batch in [-1, 1] (smooth triangle waves + integer-hash noise), exactly reproducible on every machine: no RNG,
+    no libm.  The workload generator of bench.py / SURVEY 8(d) ("synthetic 256x256x3 batches"); the test suite checks it against the
+    oracle's own generator so that parity inputs and bench inputs are the same family."""
+    n = B * 3 * H * W
+    M = 0xFFFFFFFF
+    x = (torch.arange(n, dtype=torch.int64) + 1) * 0x9E3779B1 + (seed * 0x85EBCA6B + 0x1234567)
+    x &= M
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & M
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & M
+    x ^= x >> 16
+    u = (x.to(torch.float64) / 4294967296.0).reshape(B, 3, H, W)
+    yy = torch.arange(H, dtype=torch.float64).view(1, 1, H, 1) / H
+    xx = torch.arange(W, dtype=torch.float64).view(1, 1, 1, W) / W
+    cc = torch.arange(3, dtype=torch.float64).view(1, 3, 1, 1)
+    bb = torch.arange(B, dtype=torch.float64).view(B, 1, 1, 1)
+
+    def tri(t):
+        t = t - torch.floor(t)
+        return 4.0 * (t - 0.5).abs() - 1.0
+    base = 0.5 * tri(2.0 * xx + 0.31 * cc + 0.17 * bb) + 0.3 * tri(3.0 * yy + 0.23 * cc)
+    return (base + 0.4 * (2.0 * u - 1.0)).clamp(-1.0, 1.0).to(dtype)

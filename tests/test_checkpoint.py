@@ -92,3 +92,15 @@ def test_fresh_trainstep_exports_empty_adam_state():
     sd = ts.opt_g_state_dict()
     assert sd["state"] == {} and len(sd["param_groups"][0]["params"]) == len(ts.params)
     torch.optim.Adam(ts.params, lr=1e-4, betas=(0.5, 0.9)).load_state_dict(sd)
+
+
+def test_synthetic_batch_is_the_oracle_input_family():
+    """bench.py's workload generator (utils.synthetic_batch, product package) == the oracle's det_input, bit for bit: the GPU leg of
+    the bench does not import anything from oracle/."""
+    import favae_oracle as O
+    from utils import synthetic_batch
+    for (B, H, W, seed) in ((2, 16, 16, 1234), (1, 8, 24, 7), (3, 32, 32, 1251)):
+        assert torch.equal(synthetic_batch(B, H, W, seed), O.det_input(B, H, W, seed))
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    main_src = src[src.index("def main():"):]
+    assert "favae_oracle" not in main_src, "only cpu_baseline() may touch oracle/"
