@@ -44,4 +44,8 @@ for cin, cout, hw, k in SHAPES:
     dw = torch.empty(cout, k, k, cin, device=dev)
     ws = H.workspace(H.query("favae_conv_wgrad_workspace", byref(d)), dev)
     t_w = timeit(lambda: H.call("favae_conv_wgrad", byref(d), H.ptr(x), H.ptr(y), H.ptr(scale), H.ptr(shift), H.ptr(xb), H.ptr(yb), H.ptr(dw), 0, H.ptr(ws), ws.numel()))
-    print(f"{cin:4d}->{cout:4d} @{hw:3d} k{k}: fwd {flops/t_f*1e-12:6.1f}  dgrad {flops/t_d*1e-12:6.1f}  wgrad {flops/t_w*1e-12:6.1f} TFLOP/s   ({t_f*1e3:.2f} / {t_d*1e3:.2f} / {t_w*1e3:.2f} ms)", flush=True)
+    # the same weight gradient without the fused GroupNorm+SiLU on the x operand (plain conv): isolates the cost of the transform
+    d0 = H.make_conv_desc(B, hw, hw, cin, hw, hw, cout, k, k, 1, k // 2, 0, H.ACT_NONE, 1)
+    xb0 = K.absmax(x)
+    t_w0 = timeit(lambda: H.call("favae_conv_wgrad", byref(d0), H.ptr(x), H.ptr(y), None, None, H.ptr(xb0), H.ptr(yb), H.ptr(dw), 0, H.ptr(ws), ws.numel()))
+    print(f"{cin:4d}->{cout:4d} @{hw:3d} k{k}: fwd {flops/t_f*1e-12:6.1f}  dgrad {flops/t_d*1e-12:6.1f}  wgrad {flops/t_w*1e-12:6.1f} (plain x: {flops/t_w0*1e-12:6.1f}) TFLOP/s   ({t_f*1e3:.2f} / {t_d*1e3:.2f} / {t_w*1e3:.2f} ms)", flush=True)
