@@ -29,32 +29,35 @@ class VQGANFCM(nn.Module):
         dec_kw = dict(z_channels=n_embed, ch_mult=ch_mult, attn_resolutions=attn_resolutions)
         gauss_kw = dict(kernel_size=kernel_size, dsl_init_sigma=dsl_init_sigma, device=device)
 
-        def pairwise_sigmas():
-            self.sigmas = nn.Parameter(torch.tensor([dsl_init_sigma] * 4), requires_grad=True)
-            self.kernel_size = kernel_size
-            self.padding = [kernel_size // 2] * 4
-
-        if use_non_pair_conv:                       # non pair-wise DSL, convolutional FCM
-            self.gauss_kernels = None
-            self.encoder = EncoderGauss(**enc_kw, **gauss_kw)
-            self.decoder = DecoderFcmGauss(**dec_kw, **gauss_kw)
-        elif use_same_conv_gauss:                   # pair-wise DSL, convolutional FCM
-            pairwise_sigmas()
-            self.encoder = Encoder(**enc_kw)
-            self.decoder = DecoderFcmGaussSame(**dec_kw, kernel_size=kernel_size, device=device, num_groups=num_groups)
-        elif use_same_gauss_resblock:               # pair-wise DSL, residual FCM
-            pairwise_sigmas()
-            self.encoder = Encoder(**enc_kw)
-            self.decoder = DecoderFcmGaussSameResblock(**dec_kw, kernel_size=kernel_size, device=device)
-        elif use_gauss_resblock:                    # non pair-wise DSL, residual FCM  (BASELINE configs 1-3)
-            self.encoder = EncoderGauss(**enc_kw, **gauss_kw)
-            self.decoder = DecoderFcmResGauss(**dec_kw, **gauss_kw)
-        elif use_gauss_attn:
-            self.encoder = EncoderGauss(**enc_kw, **gauss_kw)
-            self.decoder = DecoderFcmAttnGauss(**dec_kw, **gauss_kw)
-        elif use_ffl_with_fcm:                      # convolutional FCM + FFL, no blur
-            self.encoder = Encoder(**enc_kw)
-            self.decoder = DecoderFcm(**dec_kw)
+        # Variant table (reference models/vqgan_fcm.py:58-96, first matching flag wins, in the reference's order):
+        #   flag -> (encoder class, decoder class, model-level pair-wise sigmas?, decoder takes the gaussian kwargs?)
+        variants = (
+            (use_non_pair_conv, EncoderGauss, DecoderFcmGauss, False, True),             # non pair-wise DSL, convolutional FCM
+            (use_same_conv_gauss, Encoder, DecoderFcmGaussSame, True, False),            # pair-wise DSL, convolutional FCM
+            (use_same_gauss_resblock, Encoder, DecoderFcmGaussSameResblock, True, False),  # pair-wise DSL, residual FCM
+            (use_gauss_resblock, EncoderGauss, DecoderFcmResGauss, False, True),         # non pair-wise DSL, residual FCM (BASELINE configs 1-3)
+            (use_gauss_attn, EncoderGauss, DecoderFcmAttnGauss, False, True),            # non pair-wise DSL, attention FCM
+            (use_ffl_with_fcm, Encoder, DecoderFcm, False, False),                       # convolutional FCM + FFL, no blur
+        )
+        for flag, enc_cls, dec_cls, pairwise, dec_gauss in variants:
+            if not flag:
+                continue
+            if use_non_pair_conv:
+                self.gauss_kernels = None                    # attribute the reference sets for this variant only
+            if pairwise:                                     # one sigma per (encoder tap, decoder tap) pair, owned by the model
+                self.sigmas = nn.Parameter(torch.tensor([dsl_init_sigma] * 4), requires_grad=True)
+                self.kernel_size = kernel_size
+                self.padding = [kernel_size // 2] * 4
+            self.encoder = enc_cls(**enc_kw, **(gauss_kw if enc_cls is EncoderGauss else {}))
+            if dec_gauss:
+                self.decoder = dec_cls(**dec_kw, **gauss_kw)
+            elif dec_cls is DecoderFcm:
+                self.decoder = dec_cls(**dec_kw)
+            elif dec_cls is DecoderFcmGaussSame:
+                self.decoder = dec_cls(**dec_kw, kernel_size=kernel_size, device=device, num_groups=num_groups)
+            else:
+                self.decoder = dec_cls(**dec_kw, kernel_size=kernel_size, device=device)
+            break
 
         self.use_l2_quantizer = use_l2_quantizer
         if use_l2_quantizer:
