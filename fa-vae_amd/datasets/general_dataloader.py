@@ -87,20 +87,19 @@ def to_device_batch(batch, device, non_blocking=True):
 
 
 def load_data(args):
-    train_loader = None
-    test_loader = None
+    """(train_loader, test_loader) for `args.train_file` / `args.test_file` (either may be None), reference :73-86."""
     dn = bool(getattr(args, "device_normalize", False))
     pin = dn and torch.cuda.is_available()
-    if args.train_file is not None:
-        train_set = GeneralDataset(resolution=args.resolution, train=True, val=False, train_file=args.train_file, test_file=None,
-                                   device_normalize=dn)
-        train_loader = torch.utils.data.DataLoader(train_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,
-                                                   pin_memory=pin)
-        print("\nLoaded the train set length {}, dataloader length {}".format(len(train_set), len(train_loader)))
-    if args.test_file is not None:
-        test_set = GeneralDataset(resolution=args.resolution, train=False, val=True, train_file=None, test_file=args.test_file,
-                                  device_normalize=dn)
-        test_loader = torch.utils.data.DataLoader(test_set, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,
-                                                  pin_memory=pin)
-        print("\nLoaded the test set length {}, dataloader length {}".format(len(test_set), len(test_loader)))
-    return train_loader, test_loader
+
+    def make(list_file, is_train):
+        if list_file is None:
+            return None
+        ds = GeneralDataset(resolution=args.resolution, train=is_train, val=not is_train,
+                            train_file=list_file if is_train else None, test_file=None if is_train else list_file,
+                            device_normalize=dn)
+        dl = torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=is_train, num_workers=args.num_workers,
+                                         pin_memory=pin)
+        print("\nLoaded the {} set length {}, dataloader length {}".format("train" if is_train else "test", len(ds), len(dl)))
+        return dl
+
+    return make(args.train_file, True), make(args.test_file, False)
