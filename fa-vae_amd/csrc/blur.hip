@@ -278,13 +278,14 @@ bool blur_ok(int ksize, int N, int H, int W, int C) {
 extern "C" int favae_blur_fwd(const float* x, const float* sigma, int ksize, int N, int H, int W, int C, float* y,
                               favae_stream_t stream) {
     FAVAE_REQUIRE(x && sigma && y && blur_ok(ksize, N, H, W, C));
+    FAVAE_PROF_NOTE(0, 8.0 * N * H * W * C);                               // one read + one write
     if (stream_ok(ksize, N, H, W, C) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
         StreamArgs sa{};
         stream_plan(N, H, W, C, sa);
         sa.x = x; sa.sigma = sigma; sa.y = y;
         const long sgrid = (long)N * sa.segs * sa.strips * sa.cchunks;
         if (sgrid < (1L << 31)) {
-            hipLaunchKernelGGL((blur9_stream_kernel<0, STREAM_COLS>), dim3((unsigned)sgrid), dim3(STREAM_COLS * 8), 0,
+            FAVAE_KLAUNCH((blur9_stream_kernel<0, STREAM_COLS>), dim3((unsigned)sgrid), dim3(STREAM_COLS * 8), 0,
                                (hipStream_t)stream, sa);
             FAVAE_CHECK_LAUNCH();
             return FAVAE_OK;
@@ -306,10 +307,10 @@ extern "C" int favae_blur_fwd(const float* x, const float* sigma, int ksize, int
     if (grid >= (1L << 31)) return FAVAE_ERR_UNSUPPORTED;
     const dim3 g3((unsigned)grid), b3(256);
     hipStream_t s0 = (hipStream_t)stream;
-    if (ksize == 9) hipLaunchKernelGGL((blur_sep_kernel<0, 9>), g3, b3, shm, s0, a);
-    else if (ksize == 5) hipLaunchKernelGGL((blur_sep_kernel<0, 5>), g3, b3, shm, s0, a);
-    else if (ksize == 3) hipLaunchKernelGGL((blur_sep_kernel<0, 3>), g3, b3, shm, s0, a);
-    else hipLaunchKernelGGL((blur_sep_kernel<0, 0>), g3, b3, shm, s0, a);
+    if (ksize == 9) FAVAE_KLAUNCH((blur_sep_kernel<0, 9>), g3, b3, shm, s0, a);
+    else if (ksize == 5) FAVAE_KLAUNCH((blur_sep_kernel<0, 5>), g3, b3, shm, s0, a);
+    else if (ksize == 3) FAVAE_KLAUNCH((blur_sep_kernel<0, 3>), g3, b3, shm, s0, a);
+    else FAVAE_KLAUNCH((blur_sep_kernel<0, 0>), g3, b3, shm, s0, a);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -362,18 +363,19 @@ extern "C" int favae_blur_bwd(const float* x, const float* dy, const float* sigm
     }
     hipStream_t s = (hipStream_t)stream;
     const dim3 g3((unsigned)grid), b3(256);
+    FAVAE_PROF_NOTE(0, 12.0 * N * H * W * C);                              // reads x and dy, writes dx
     if (stream_path) {
         sa.x = x; sa.dy = dy; sa.sigma = sigma; sa.dx = dx; sa.part = a.part;
-        hipLaunchKernelGGL((blur9_stream_kernel<1, STREAM_COLS>), g3, dim3(STREAM_COLS * 8), 0, s, sa);
-    } else if (ksize == 9) hipLaunchKernelGGL((blur_sep_kernel<1, 9>), g3, b3, shm, s, a);
-    else if (ksize == 5) hipLaunchKernelGGL((blur_sep_kernel<1, 5>), g3, b3, shm, s, a);
-    else if (ksize == 3) hipLaunchKernelGGL((blur_sep_kernel<1, 3>), g3, b3, shm, s, a);
-    else hipLaunchKernelGGL((blur_sep_kernel<1, 0>), g3, b3, shm, s, a);
+        FAVAE_KLAUNCH((blur9_stream_kernel<1, STREAM_COLS>), g3, dim3(STREAM_COLS * 8), 0, s, sa);
+    } else if (ksize == 9) FAVAE_KLAUNCH((blur_sep_kernel<1, 9>), g3, b3, shm, s, a);
+    else if (ksize == 5) FAVAE_KLAUNCH((blur_sep_kernel<1, 5>), g3, b3, shm, s, a);
+    else if (ksize == 3) FAVAE_KLAUNCH((blur_sep_kernel<1, 3>), g3, b3, shm, s, a);
+    else FAVAE_KLAUNCH((blur_sep_kernel<1, 0>), g3, b3, shm, s, a);
     FAVAE_CHECK_LAUNCH();
     if (dsigma) {
         int rc = favae_colsum(part, dgv, grid, ksize, 0, nullptr, p2, cws, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(blur_dsigma_kernel, dim3(1), dim3(64), 0, s, (const float*)dgv, sigma, ksize, dsigma);
+        FAVAE_KLAUNCH(blur_dsigma_kernel, dim3(1), dim3(64), 0, s, (const float*)dgv, sigma, ksize, dsigma);
         FAVAE_CHECK_LAUNCH();
     }
     return FAVAE_OK;

@@ -752,7 +752,8 @@ int launch_absmax(const float* x, int64_t n, float* out, hipStream_t s) {
     if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
     long blocks = (n / 4 + 255) / 256;
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (size_t)n, (((uintptr_t)x) & 15) == 0 ? 1 : 0,
+    FAVAE_PROF_NOTE(0, 4.0 * n);
+    FAVAE_KLAUNCH(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (size_t)n, (((uintptr_t)x) & 15) == 0 ? 1 : 0,
                        (unsigned*)out);
     return FAVAE_OK;
 }
@@ -777,13 +778,13 @@ extern "C" int favae_split_weights(const float* in, void* out, int64_t n, int pl
         const int rc = launch_absmax(in, n, (float*)out, s);
         if (rc != FAVAE_OK) return rc;
         if (planes == 2)
-            hipLaunchKernelGGL((split_w_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
+            FAVAE_KLAUNCH((split_w_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
                                (const float*)out);
         else
-            hipLaunchKernelGGL((split_w_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
+            FAVAE_KLAUNCH((split_w_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
                                (const float*)out);
     } else {
-        hipLaunchKernelGGL((split_w_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
+        FAVAE_KLAUNCH((split_w_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
                            (const float*)nullptr);
     }
     FAVAE_CHECK_LAUNCH();
@@ -813,6 +814,10 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
                          favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && x && w && y);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
+    // roofline numerators of this conv: 2*M*Cout*KH*KW*Cin FLOP; one read of x (+ resid), one write of y, the weights
+    FAVAE_PROF_NOTE(2.0 * d->N * d->Hout * d->Wout * d->Cout * d->KH * d->KW * d->Cin,
+                    4.0 * ((double)d->N * d->Hin * d->Win * d->Cin + (double)d->N * d->Hout * d->Wout * d->Cout * (resid ? 2 : 1) +
+                           (double)d->Cout * d->KH * d->KW * d->Cin));
     const bool w6 = wplanes != 0;                            // pre-split weights: records start behind the header
     if (!w6) {
         const int tk = thin_kind(d, scale != nullptr);
@@ -829,7 +834,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
                 const int items = d->N * d->Hin * cdiv(d->Win, t.xb);
                 // persistent workgroups: the 27 x 4 weights of a thread are loaded once per workgroup, not once per item
                 const int blocks = items < 4096 ? items : 4096;
-                hipLaunchKernelGGL((thin_in_kernel<3, false>), dim3(blocks), dim3(256), (size_t)3 * (t.xb + 2) * 3 * sizeof(float), s, t);
+                FAVAE_KLAUNCH((thin_in_kernel<3, false>), dim3(blocks), dim3(256), (size_t)3 * (t.xb + 2) * 3 * sizeof(float), s, t);
             } else {
                 t.Cw = d->Cin;
                 const int PL = 256 / (t.Cw / 4);
@@ -837,10 +842,10 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
                 seg = seg < 4 ? 4 : (seg > 32 ? 32 : seg);
                 t.xb = seg * PL;
                 const int items = d->N * d->Hin * cdiv(d->Win, t.xb);
-                if (xf0 == 0) hipLaunchKernelGGL((thin_out_kernel<3, 0, false>), dim3(items), dim3(256), 0, s, t);
-                else if (xf0 == 1) hipLaunchKernelGGL((thin_out_kernel<3, 1, false>), dim3(items), dim3(256), 0, s, t);
-                else if (xf0 == 2) hipLaunchKernelGGL((thin_out_kernel<3, 2, false>), dim3(items), dim3(256), 0, s, t);
-                else hipLaunchKernelGGL((thin_out_kernel<3, 3, false>), dim3(items), dim3(256), 0, s, t);
+                if (xf0 == 0) FAVAE_KLAUNCH((thin_out_kernel<3, 0, false>), dim3(items), dim3(256), 0, s, t);
+                else if (xf0 == 1) FAVAE_KLAUNCH((thin_out_kernel<3, 1, false>), dim3(items), dim3(256), 0, s, t);
+                else if (xf0 == 2) FAVAE_KLAUNCH((thin_out_kernel<3, 2, false>), dim3(items), dim3(256), 0, s, t);
+                else FAVAE_KLAUNCH((thin_out_kernel<3, 3, false>), dim3(items), dim3(256), 0, s, t);
             }
             FAVAE_CHECK_LAUNCH();
             return FAVAE_OK;
@@ -872,9 +877,9 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     const dim3 grid(a.tiles_m * a.tiles_n), blk(256);
 #define FAVAE_LAUNCH_FWD(G)                                                                                        \
     do {                                                                                                           \
-        if (bn == 128) hipLaunchKernelGGL((conv_fwd_fast_kernel<128, 2, 2, G>), grid, blk, 0, s, a);               \
-        else if (bn == 64) hipLaunchKernelGGL((conv_fwd_fast_kernel<64, 2, 2, G>), grid, blk, 0, s, a);            \
-        else hipLaunchKernelGGL((conv_fwd_fast_kernel<32, 4, 1, G>), grid, blk, 0, s, a);                          \
+        if (bn == 128) FAVAE_KLAUNCH((conv_fwd_fast_kernel<128, 2, 2, G>), grid, blk, 0, s, a);               \
+        else if (bn == 64) FAVAE_KLAUNCH((conv_fwd_fast_kernel<64, 2, 2, G>), grid, blk, 0, s, a);            \
+        else FAVAE_KLAUNCH((conv_fwd_fast_kernel<32, 4, 1, G>), grid, blk, 0, s, a);                          \
     } while (0)
     const size_t xb = (size_t)d->N * a.in_img * d->Cin * 4, wb = (size_t)d->Cout * d->KH * d->KW * d->Cin * 4;
     const size_t ab = (size_t)(d->affine_per_image ? d->N : 1) * d->Cin * 4;
@@ -886,9 +891,9 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     a.w_bytes = (unsigned)(wplanes ? wb / 16 * wrec_bytes(wplanes) : wb);
 #define FAVAE_LAUNCH_BUF(G, X)                                                                                     \
     do {                                                                                                           \
-        if (bn == 128) hipLaunchKernelGGL((conv_fwd_buf_kernel<128, 2, 2, G, X>), grid, blk, 0, s, a);             \
-        else if (bn == 64) hipLaunchKernelGGL((conv_fwd_buf_kernel<64, 2, 2, G, X>), grid, blk, 0, s, a);          \
-        else hipLaunchKernelGGL((conv_fwd_buf_kernel<32, 4, 1, G, X>), grid, blk, 0, s, a);                        \
+        if (bn == 128) FAVAE_KLAUNCH((conv_fwd_buf_kernel<128, 2, 2, G, X>), grid, blk, 0, s, a);             \
+        else if (bn == 64) FAVAE_KLAUNCH((conv_fwd_buf_kernel<64, 2, 2, G, X>), grid, blk, 0, s, a);          \
+        else FAVAE_KLAUNCH((conv_fwd_buf_kernel<32, 4, 1, G, X>), grid, blk, 0, s, a);                        \
     } while (0)
     const bool halo_common = buf_ok && use_b6() && w6 && use_halo() && bn == 128 && d->stride == 1 && d->gather == FAVAE_GATHER_PLAIN &&
                              d->Hout == d->Hin && d->Wout == d->Win && d->Hin % 8 == 0 && d->Win % 16 == 0;
@@ -901,9 +906,9 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         const dim3 hgrid((unsigned)(d->N * (d->Hin / 8) * (d->Win / 16) * a.tiles_n));
 #define FAVAE_LAUNCH_HALO_K(X, KS)                                                                            \
     do {                                                                                                      \
-        if (wplanes == 2) hipLaunchKernelGGL((conv3x3_halo_sp_kernel<X, 2, KS>), hgrid, dim3(512), 0, s, a);  \
-        else if (wplanes == 1) hipLaunchKernelGGL((conv3x3_halo_sp_kernel<X, 1, KS>), hgrid, dim3(512), 0, s, a); \
-        else hipLaunchKernelGGL((conv3x3_halo_sp_kernel<X, 3, KS>), hgrid, dim3(512), 0, s, a);               \
+        if (wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 2, KS>), hgrid, dim3(512), 0, s, a);  \
+        else if (wplanes == 1) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 1, KS>), hgrid, dim3(512), 0, s, a); \
+        else FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 3, KS>), hgrid, dim3(512), 0, s, a);               \
     } while (0)
 #define FAVAE_LAUNCH_HALO(X) FAVAE_LAUNCH_HALO_K(X, 3)
         if (halo2_ok) FAVAE_LAUNCH_HALO_K(0, 2);
@@ -916,14 +921,14 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     } else if (buf_ok && use_b6() && bn == 128) {
 #define FAVAE_LAUNCH_B6(G, X)                                                                     \
     do {                                                                                          \
-        if (wplanes == 2) hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, true, 8, 2>), grid, dim3(512), 0, s, a);        \
-        else if (wplanes == 1) hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, true, 8, 1>), grid, dim3(512), 0, s, a);   \
+        if (wplanes == 2) FAVAE_KLAUNCH((conv_fwd_sp_kernel<G, X, true, 8, 2>), grid, dim3(512), 0, s, a);        \
+        else if (wplanes == 1) FAVAE_KLAUNCH((conv_fwd_sp_kernel<G, X, true, 8, 1>), grid, dim3(512), 0, s, a);   \
         else if (b6_waves() == 8) {                                                               \
-            if (w6) hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, true, 8, 3>), grid, dim3(512), 0, s, a);   \
-            else hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, false, 8, 3>), grid, dim3(512), 0, s, a);     \
+            if (w6) FAVAE_KLAUNCH((conv_fwd_sp_kernel<G, X, true, 8, 3>), grid, dim3(512), 0, s, a);   \
+            else FAVAE_KLAUNCH((conv_fwd_sp_kernel<G, X, false, 8, 3>), grid, dim3(512), 0, s, a);     \
         } else {                                                                                  \
-            if (w6) hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, true, 4, 3>), grid, blk, 0, s, a);  \
-            else hipLaunchKernelGGL((conv_fwd_sp_kernel<G, X, false, 4, 3>), grid, blk, 0, s, a);    \
+            if (w6) FAVAE_KLAUNCH((conv_fwd_sp_kernel<G, X, true, 4, 3>), grid, blk, 0, s, a);  \
+            else FAVAE_KLAUNCH((conv_fwd_sp_kernel<G, X, false, 4, 3>), grid, blk, 0, s, a);    \
         }                                                                                         \
     } while (0)
         if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_B6(FAVAE_GATHER_UPSAMPLE2, 0);
@@ -945,11 +950,11 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         else if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_FWD(FAVAE_GATHER_UPSAMPLE2);
         else FAVAE_LAUNCH_FWD(FAVAE_GATHER_DILATE2);
     } else if (bn == 128) {
-        hipLaunchKernelGGL((conv_fwd_kernel<128, 2, 2>), grid, blk, 0, s, a);
+        FAVAE_KLAUNCH((conv_fwd_kernel<128, 2, 2>), grid, blk, 0, s, a);
     } else if (bn == 64) {
-        hipLaunchKernelGGL((conv_fwd_kernel<64, 2, 2>), grid, blk, 0, s, a);
+        FAVAE_KLAUNCH((conv_fwd_kernel<64, 2, 2>), grid, blk, 0, s, a);
     } else {
-        hipLaunchKernelGGL((conv_fwd_kernel<32, 4, 1>), grid, blk, 0, s, a);
+        FAVAE_KLAUNCH((conv_fwd_kernel<32, 4, 1>), grid, blk, 0, s, a);
     }
 #undef FAVAE_LAUNCH_FWD
 #undef FAVAE_LAUNCH_BUF
@@ -976,6 +981,10 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     const int np = ((cm == 2 || cm == 1) && x_absmax && dy_absmax) ? cm : 3;
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     if (ws_bytes < favae_conv_wgrad_workspace(d)) return FAVAE_ERR_WORKSPACE;
+    // roofline numerators: same FLOPs as the forward conv; one read of x and of dy, one write of dw
+    FAVAE_PROF_NOTE(2.0 * d->N * d->Hout * d->Wout * d->Cout * d->KH * d->KW * d->Cin,
+                    4.0 * ((double)d->N * d->Hin * d->Win * d->Cin + (double)d->N * d->Hout * d->Wout * d->Cout +
+                           (double)d->Cout * d->KH * d->KW * d->Cin));
     {
         const int tk = thin_kind(d, scale != nullptr);
         const int xf0 = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_NONE ? 1 : 3)) : 0;
@@ -994,7 +1003,7 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
                 size_t shm = (size_t)3 * 27 * t.Cw * sizeof(float);
                 const size_t stage_b = (size_t)3 * (t.xb + 2) * 3 * sizeof(float);
                 if (shm < stage_b) shm = stage_b;
-                hipLaunchKernelGGL((thin_in_kernel<3, true>), dim3(blocks), dim3(256), shm, s, t);
+                FAVAE_KLAUNCH((thin_in_kernel<3, true>), dim3(blocks), dim3(256), shm, s, t);
             } else {
                 t.Cw = d->Cin;
                 const int PL = 256 / (t.Cw / 4);
@@ -1004,13 +1013,13 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
                 const int items = d->N * d->Hin * cdiv(d->Win, t.xb);
                 blocks = items < THIN_WGRAD_BLOCKS ? items : THIN_WGRAD_BLOCKS;
                 const size_t shm = (size_t)3 * 27 * t.Cw * sizeof(float);
-                if (xf0 == 0) hipLaunchKernelGGL((thin_out_kernel<3, 0, true>), dim3(blocks), dim3(256), shm, s, t);
-                else if (xf0 == 1) hipLaunchKernelGGL((thin_out_kernel<3, 1, true>), dim3(blocks), dim3(256), shm, s, t);
-                else hipLaunchKernelGGL((thin_out_kernel<3, 2, true>), dim3(blocks), dim3(256), shm, s, t);
+                if (xf0 == 0) FAVAE_KLAUNCH((thin_out_kernel<3, 0, true>), dim3(blocks), dim3(256), shm, s, t);
+                else if (xf0 == 1) FAVAE_KLAUNCH((thin_out_kernel<3, 1, true>), dim3(blocks), dim3(256), shm, s, t);
+                else FAVAE_KLAUNCH((thin_out_kernel<3, 2, true>), dim3(blocks), dim3(256), shm, s, t);
             }
             FAVAE_CHECK_LAUNCH();
             const size_t nw = (size_t)d->Cout * 9 * d->Cin;
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, s, (const float*)ws, dw, nw, blocks, accumulate);
+            FAVAE_KLAUNCH(reduce_slabs_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, s, (const float*)ws, dw, nw, blocks, accumulate);
             FAVAE_CHECK_LAUNCH();
             return FAVAE_OK;
         }
@@ -1042,9 +1051,9 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     dim3 grid(tiles, a.splitk);
 #define FAVAE_LAUNCH_WGRAD(G)                                                                                      \
     do {                                                                                                           \
-        if (bco == 128 && bci == 128) hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 128, 2, 2, G>), grid, dim3(256), 0, s, a); \
-        else if (bco == 32) hipLaunchKernelGGL((conv_wgrad_fast_kernel<32, 128, 1, 4, G>), grid, dim3(256), 0, s, a);            \
-        else hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 32, 4, 1, G>), grid, dim3(256), 0, s, a);                           \
+        if (bco == 128 && bci == 128) FAVAE_KLAUNCH((conv_wgrad_fast_kernel<128, 128, 2, 2, G>), grid, dim3(256), 0, s, a); \
+        else if (bco == 32) FAVAE_KLAUNCH((conv_wgrad_fast_kernel<32, 128, 1, 4, G>), grid, dim3(256), 0, s, a);            \
+        else FAVAE_KLAUNCH((conv_wgrad_fast_kernel<128, 32, 4, 1, G>), grid, dim3(256), 0, s, a);                           \
     } while (0)
     const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, yb = (size_t)d->N * d->Hout * d->Wout * d->Cout * 4;
     const size_t ab = (size_t)(d->affine_per_image ? d->N : 1) * d->Cin * 4;
@@ -1058,9 +1067,9 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
         return FAVAE_ERR_UNSUPPORTED;
 #define FAVAE_LAUNCH_WBUF(X)                                                                                       \
     do {                                                                                                           \
-        if (bco == 128 && bci == 128) hipLaunchKernelGGL((conv_wgrad_buf_kernel<128, 128, 2, 2, X>), grid, dim3(256), 0, s, a); \
-        else if (bco == 32) hipLaunchKernelGGL((conv_wgrad_buf_kernel<32, 128, 1, 4, X>), grid, dim3(256), 0, s, a);            \
-        else hipLaunchKernelGGL((conv_wgrad_buf_kernel<128, 32, 4, 1, X>), grid, dim3(256), 0, s, a);                           \
+        if (bco == 128 && bci == 128) FAVAE_KLAUNCH((conv_wgrad_buf_kernel<128, 128, 2, 2, X>), grid, dim3(256), 0, s, a); \
+        else if (bco == 32) FAVAE_KLAUNCH((conv_wgrad_buf_kernel<32, 128, 1, 4, X>), grid, dim3(256), 0, s, a);            \
+        else FAVAE_KLAUNCH((conv_wgrad_buf_kernel<128, 32, 4, 1, X>), grid, dim3(256), 0, s, a);                           \
     } while (0)
     const bool row3 = !special && buf_ok && use_b6() && use_row3() && bco == 128 && bci == 128 && d->gather == FAVAE_GATHER_PLAIN &&
                       d->KH == 3 && d->KW == 3 && d->pad == 1;
@@ -1072,9 +1081,9 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
         const dim3 g3(tiles3, a.splitk);
 #define FAVAE_LAUNCH_ROW3(X)                                                                              \
     do {                                                                                                  \
-        if (np == 2) hipLaunchKernelGGL((conv_wgrad_row3_sp_kernel<X, 2>), g3, dim3(512), 0, s, a);       \
-        else if (np == 1) hipLaunchKernelGGL((conv_wgrad_row3_sp_kernel<X, 1>), g3, dim3(512), 0, s, a);  \
-        else hipLaunchKernelGGL((conv_wgrad_row3_sp_kernel<X, 3>), g3, dim3(512), 0, s, a);               \
+        if (np == 2) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<X, 2>), g3, dim3(512), 0, s, a);       \
+        else if (np == 1) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<X, 1>), g3, dim3(512), 0, s, a);  \
+        else FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<X, 3>), g3, dim3(512), 0, s, a);               \
     } while (0)
         if (xf == 0) FAVAE_LAUNCH_ROW3(0);
         else if (xf == 1) FAVAE_LAUNCH_ROW3(1);
@@ -1083,9 +1092,9 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     } else if (buf_ok && use_b6() && bco == 128 && bci == 128) {
 #define FAVAE_LAUNCH_WSP(X, U)                                                                            \
     do {                                                                                                  \
-        if (np == 2) hipLaunchKernelGGL((conv_wgrad_sp_kernel<X, U, 2>), grid, dim3(256), 0, s, a);       \
-        else if (np == 1) hipLaunchKernelGGL((conv_wgrad_sp_kernel<X, U, 1>), grid, dim3(256), 0, s, a);  \
-        else hipLaunchKernelGGL((conv_wgrad_sp_kernel<X, U, 3>), grid, dim3(256), 0, s, a);               \
+        if (np == 2) FAVAE_KLAUNCH((conv_wgrad_sp_kernel<X, U, 2>), grid, dim3(256), 0, s, a);       \
+        else if (np == 1) FAVAE_KLAUNCH((conv_wgrad_sp_kernel<X, U, 1>), grid, dim3(256), 0, s, a);  \
+        else FAVAE_KLAUNCH((conv_wgrad_sp_kernel<X, U, 3>), grid, dim3(256), 0, s, a);               \
     } while (0)
         if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_WSP(0, true);
         else if (xf == 0) FAVAE_LAUNCH_WSP(0, false);
@@ -1101,16 +1110,16 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
         else if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_WGRAD(FAVAE_GATHER_UPSAMPLE2);
         else FAVAE_LAUNCH_WGRAD(FAVAE_GATHER_DILATE2);
     } else if (bco == 128 && bci == 128)
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
+        FAVAE_KLAUNCH((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
     else if (bco == 32)
-        hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), grid, dim3(256), 0, s, a);
+        FAVAE_KLAUNCH((conv_wgrad_kernel<32, 128, 1, 4>), grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, a);
+        FAVAE_KLAUNCH((conv_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, a);
 #undef FAVAE_LAUNCH_WGRAD
 #undef FAVAE_LAUNCH_WBUF
     FAVAE_CHECK_LAUNCH();
     const size_t n = (size_t)d->Cout * d->KH * d->KW * d->Cin;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, dw, n, a.splitk, accumulate);
+    FAVAE_KLAUNCH(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, dw, n, a.splitk, accumulate);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -1168,7 +1177,7 @@ __global__ __launch_bounds__(256) void upsample_wgrad_fold_kernel(const float* _
 extern "C" int favae_upsample_weights(const float* w, float* weff, int Cout, int Cin, favae_stream_t stream) {
     FAVAE_REQUIRE(w && weff && Cout > 0 && Cin > 0);
     const size_t n = (size_t)16 * Cout * Cin;
-    hipLaunchKernelGGL(upsample_weights_kernel, dim3((unsigned)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256))), dim3(256), 0,
+    FAVAE_KLAUNCH(upsample_weights_kernel, dim3((unsigned)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256))), dim3(256), 0,
                        (hipStream_t)stream, w, weff, Cout, Cin);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -1177,7 +1186,7 @@ extern "C" int favae_upsample_weights(const float* w, float* weff, int Cout, int
 extern "C" int favae_upsample_wgrad_fold(const float* dweff, float* dw, int Cout, int Cin, int accumulate, favae_stream_t stream) {
     FAVAE_REQUIRE(dweff && dw && Cout > 0 && Cin > 0);
     const size_t n = (size_t)9 * Cout * Cin;
-    hipLaunchKernelGGL(upsample_wgrad_fold_kernel, dim3((unsigned)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256))), dim3(256), 0,
+    FAVAE_KLAUNCH(upsample_wgrad_fold_kernel, dim3((unsigned)(cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256))), dim3(256), 0,
                        (hipStream_t)stream, dweff, dw, Cout, Cin, accumulate);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -1237,13 +1246,13 @@ extern "C" int favae_weight_flip_split(const float* w, void* out, int Cout, int 
     FAVAE_REQUIRE((((uintptr_t)out) & 15) == 0);
     dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), KH * KW);
     if (planes == 2)
-        hipLaunchKernelGGL((weight_flip_split_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, Cout, KH, KW,
+        FAVAE_KLAUNCH((weight_flip_split_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, Cout, KH, KW,
                            Cin, absmax_src);
     else if (planes == 1)
-        hipLaunchKernelGGL((weight_flip_split_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, Cout, KH, KW,
+        FAVAE_KLAUNCH((weight_flip_split_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, Cout, KH, KW,
                            Cin, absmax_src);
     else
-        hipLaunchKernelGGL((weight_flip_split_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, Cout, KH, KW,
+        FAVAE_KLAUNCH((weight_flip_split_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, Cout, KH, KW,
                            Cin, absmax_src);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -1296,13 +1305,13 @@ extern "C" int favae_downsample_dgrad_weights(const float* w, void* out, int Cou
     const size_t total = (size_t)9 * Cin * (Cout / 4);
     const unsigned blocks = (unsigned)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
     if (planes == 2)
-        hipLaunchKernelGGL((downsample_dgrad_weights_kernel<2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
+        FAVAE_KLAUNCH((downsample_dgrad_weights_kernel<2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
                            Cout, Cin, absmax_src);
     else if (planes == 1)
-        hipLaunchKernelGGL((downsample_dgrad_weights_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
+        FAVAE_KLAUNCH((downsample_dgrad_weights_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
                            Cout, Cin, absmax_src);
     else
-        hipLaunchKernelGGL((downsample_dgrad_weights_kernel<3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
+        FAVAE_KLAUNCH((downsample_dgrad_weights_kernel<3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
                            Cout, Cin, absmax_src);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -1311,7 +1320,7 @@ extern "C" int favae_downsample_dgrad_weights(const float* w, void* out, int Cou
 extern "C" int favae_weight_flip(const float* w, float* wt, int Cout, int KH, int KW, int Cin, favae_stream_t stream) {
     FAVAE_REQUIRE(w && wt && Cout > 0 && KH > 0 && KW > 0 && Cin > 0);
     dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), KH * KW);
-    hipLaunchKernelGGL(weight_flip_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt, Cout, KH, KW, Cin);
+    FAVAE_KLAUNCH(weight_flip_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt, Cout, KH, KW, Cin);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -1334,12 +1343,13 @@ extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, int ac
     hipStream_t s = (hipStream_t)stream;
     unsigned* amax = (unsigned*)absmax_out;
     if (amax && hipMemsetAsync(amax, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
+    FAVAE_PROF_NOTE(0, 4.0 * M * C);
     if (C % 4 == 0 && ((((uintptr_t)a) & 15) == 0))
-        hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3(1, nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb, amax);
+        FAVAE_KLAUNCH(colsum_partial_vec_kernel, dim3(1, nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb, amax);
     else
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C, 256), nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb, amax);
+        FAVAE_KLAUNCH(colsum_partial_kernel, dim3(cdiv(C, 256), nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb, amax);
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const float*)ws, out, (size_t)C, nb, accumulate);
+    FAVAE_KLAUNCH(reduce_slabs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const float*)ws, out, (size_t)C, nb, accumulate);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -1348,7 +1358,7 @@ extern "C" int favae_upsample2x_bwd(const float* du, float* dx, int N, int H, in
     FAVAE_REQUIRE(du && dx && N > 0 && H > 0 && W > 0 && C > 0);
     if (C % 4) return FAVAE_ERR_UNSUPPORTED;
     size_t total = (size_t)N * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, du, dx, N, H, W,
+    FAVAE_KLAUNCH(upsample2x_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, du, dx, N, H, W,
                        C / 4);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;

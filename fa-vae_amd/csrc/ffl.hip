@@ -253,7 +253,12 @@ int launch_fft(FftArgs& a, hipStream_t s) {
     const long chunks = (a.inner + a.IC - 1) / a.IC;
     const long blocks = a.outer * chunks;
     if (blocks <= 0 || blocks >= (1L << 31)) return FAVAE_ERR_BAD_ARG;
-    hipLaunchKernelGGL((fft_lines_kernel<IN, OUT>), dim3((unsigned)blocks), dim3(256), shm, s, a);
+    {   // bytes this pass must move: its input lines (two real tensors for IN_DIFF, complex otherwise) + its output lines
+        const double lines = (double)a.outer * a.inner;
+        const double in_b = IN == IN_DIFF ? 8.0 * a.Lin : 8.0 * a.Lin, out_b = (OUT == OUT_REAL ? (a.out2 ? 8.0 : 4.0) : 8.0) * a.Lout;
+        FAVAE_PROF_NOTE(0, lines * (in_b + out_b));
+    }
+    FAVAE_KLAUNCH((fft_lines_kernel<IN, OUT>), dim3((unsigned)blocks), dim3(256), shm, s, a);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -297,10 +302,10 @@ extern "C" int favae_ffl_fwd(const float* pred, const float* target, int N, int 
     const double M = (double)N * H * W * C;                  // elements of the mean (full spectrum)
     int blocks = (int)((total + 255) / 256);
     if (blocks > WEIGHT_BLOCKS) blocks = WEIGHT_BLOCKS;
-    hipLaunchKernelGGL(ffl_weight_kernel, dim3(blocks), dim3(256), 0, s, spec, (const unsigned*)planemax, part, (long)H * Wh * C,
+    FAVAE_KLAUNCH(ffl_weight_kernel, dim3(blocks), dim3(256), 0, s, spec, (const unsigned*)planemax, part, (long)H * Wh * C,
                        C, total, (float)(2.0 * (double)loss_weight / M), Wh, W);
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ffl_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)part, blocks, (double)loss_weight / M, loss);
+    FAVAE_KLAUNCH(ffl_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)part, blocks, (double)loss_weight / M, loss);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }

@@ -212,17 +212,17 @@ extern "C" int favae_bgemm(int ta, int tb, int M, int N, int K, float alpha, con
     a.vecB = aligned16(B) && ldb % 4 == 0 && strideB % 4 == 0 && (tb == 0 ? K % 4 == 0 : N % 4 == 0);
     dim3 grid(cdiv(M, GBM) * cdiv(N, GBN), batch);
     hipStream_t s = (hipStream_t)stream;
-    if (ta == 0 && tb == 0) hipLaunchKernelGGL((bgemm_kernel<0, 0>), grid, dim3(256), 0, s, a);
-    else if (ta == 0 && tb == 1) hipLaunchKernelGGL((bgemm_kernel<0, 1>), grid, dim3(256), 0, s, a);
-    else if (ta == 1 && tb == 0) hipLaunchKernelGGL((bgemm_kernel<1, 0>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((bgemm_kernel<1, 1>), grid, dim3(256), 0, s, a);
+    if (ta == 0 && tb == 0) FAVAE_KLAUNCH((bgemm_kernel<0, 0>), grid, dim3(256), 0, s, a);
+    else if (ta == 0 && tb == 1) FAVAE_KLAUNCH((bgemm_kernel<0, 1>), grid, dim3(256), 0, s, a);
+    else if (ta == 1 && tb == 0) FAVAE_KLAUNCH((bgemm_kernel<1, 0>), grid, dim3(256), 0, s, a);
+    else FAVAE_KLAUNCH((bgemm_kernel<1, 1>), grid, dim3(256), 0, s, a);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
 
 extern "C" int favae_softmax_rows(const float* s, float* p, int64_t rows, int L, favae_stream_t stream) {
     FAVAE_REQUIRE(s && p && rows > 0 && L > 0);
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, s, p, (long)rows, L);
+    FAVAE_KLAUNCH(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, s, p, (long)rows, L);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -230,7 +230,7 @@ extern "C" int favae_softmax_rows(const float* s, float* p, int64_t rows, int L,
 extern "C" int favae_softmax_rows_bwd(const float* p, const float* dp, float* ds, int64_t rows, int L, float alpha,
                                       favae_stream_t stream) {
     FAVAE_REQUIRE(p && dp && ds && rows > 0 && L > 0);
-    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, p, dp, ds, (long)rows,
+    FAVAE_KLAUNCH(softmax_rows_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, p, dp, ds, (long)rows,
                        L, alpha);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;

@@ -200,14 +200,14 @@ extern "C" int favae_lpips_level(const float* a, const float* b, const float* w,
     const int chunks = level_chunks(HW, C);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(N * chunks));
-#define FAVAE_LP(CC) hipLaunchKernelGGL((lpips_level_kernel<CC, 0>), grid, dim3(256), 0, s, a, b, w, (const float*)nullptr, HW, chunks, (double*)ws, (float*)nullptr)
+#define FAVAE_LP(CC) FAVAE_KLAUNCH((lpips_level_kernel<CC, 0>), grid, dim3(256), 0, s, a, b, w, (const float*)nullptr, HW, chunks, (double*)ws, (float*)nullptr)
     if (C == 64) FAVAE_LP(64);
     else if (C == 128) FAVAE_LP(128);
     else if (C == 256) FAVAE_LP(256);
     else FAVAE_LP(512);
 #undef FAVAE_LP
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(lpips_finish_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, (const double*)ws, N, chunks, 1.0 / (double)HW,
+    FAVAE_KLAUNCH(lpips_finish_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, (const double*)ws, N, chunks, 1.0 / (double)HW,
                        accumulate, val);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -219,7 +219,7 @@ extern "C" int favae_lpips_level_bwd(const float* a, const float* b, const float
     const int chunks = level_chunks(HW, C);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(N * chunks));
-#define FAVAE_LP(CC) hipLaunchKernelGGL((lpips_level_kernel<CC, 1>), grid, dim3(256), 0, s, a, b, w, g, HW, chunks, (double*)nullptr, db)
+#define FAVAE_LP(CC) FAVAE_KLAUNCH((lpips_level_kernel<CC, 1>), grid, dim3(256), 0, s, a, b, w, g, HW, chunks, (double*)nullptr, db)
     if (C == 64) FAVAE_LP(64);
     else if (C == 128) FAVAE_LP(128);
     else if (C == 256) FAVAE_LP(256);
@@ -233,7 +233,7 @@ extern "C" int favae_maxpool2(const float* x, int N, int H, int W, int C, float*
     FAVAE_REQUIRE(x && y && N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0);
     const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
     const size_t nb = (total + 255) / 256;
-    hipLaunchKernelGGL((maxpool2_kernel<0>), dim3((unsigned)(nb > 65536 ? 65536 : nb)), dim3(256), 0, (hipStream_t)stream, x,
+    FAVAE_KLAUNCH((maxpool2_kernel<0>), dim3((unsigned)(nb > 65536 ? 65536 : nb)), dim3(256), 0, (hipStream_t)stream, x,
                        (const float*)nullptr, y, H, W, C / 4, total);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -243,7 +243,7 @@ extern "C" int favae_maxpool2_bwd(const float* x, const float* dy, int N, int H,
     FAVAE_REQUIRE(x && dy && dx && N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0);
     const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
     const size_t nb = (total + 255) / 256;
-    hipLaunchKernelGGL((maxpool2_kernel<1>), dim3((unsigned)(nb > 65536 ? 65536 : nb)), dim3(256), 0, (hipStream_t)stream, x, dy,
+    FAVAE_KLAUNCH((maxpool2_kernel<1>), dim3((unsigned)(nb > 65536 ? 65536 : nb)), dim3(256), 0, (hipStream_t)stream, x, dy,
                        dx, H, W, C / 4, total);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -253,7 +253,7 @@ extern "C" int favae_channel_affine(const float* x, const float* shift, const fl
                                     favae_stream_t stream) {
     FAVAE_REQUIRE(x && scale && y && n > 0 && C > 0 && n % C == 0);
     const size_t nb = ((size_t)n + 255) / 256;
-    hipLaunchKernelGGL(channel_affine_kernel, dim3((unsigned)(nb > 65536 ? 65536 : nb)), dim3(256), 0, (hipStream_t)stream, x, shift,
+    FAVAE_KLAUNCH(channel_affine_kernel, dim3((unsigned)(nb > 65536 ? 65536 : nb)), dim3(256), 0, (hipStream_t)stream, x, shift,
                        scale, (size_t)n, C, y);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;

@@ -113,9 +113,9 @@ int diff_sum(const float* a, const float* b, int64_t n, float scale, float* loss
     long nb = (n / 4 + 255) / 256;
     if (nb > RED_BLOCKS) nb = RED_BLOCKS;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL((diff_reduce_kernel<SQ>), dim3((int)nb), dim3(256), 0, s, a, b, (long)n, (double*)ws);
+    FAVAE_KLAUNCH((diff_reduce_kernel<SQ>), dim3((int)nb), dim3(256), 0, s, a, b, (long)n, (double*)ws);
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, (int)nb, (double)scale, loss);
+    FAVAE_KLAUNCH(finish_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, (int)nb, (double)scale, loss);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -207,13 +207,13 @@ extern "C" int favae_u8_to_float_nhwc(const unsigned char* in, float* out, int64
     long done = 0;
     if (C == 3 && ((((uintptr_t)in) & 3) == 0) && ((((uintptr_t)out) & 15) == 0) && pixels >= 4) {
         const long groups = pixels / 4;
-        hipLaunchKernelGGL(u8_norm_rgb_kernel, dim3(ew_blocks(groups)), dim3(256), 0, s, (const unsigned*)in, (float4*)out, groups, p);
+        FAVAE_KLAUNCH(u8_norm_rgb_kernel, dim3(ew_blocks(groups)), dim3(256), 0, s, (const unsigned*)in, (float4*)out, groups, p);
         FAVAE_CHECK_LAUNCH();
         done = groups * 12;
     }
     if (done < n) {
         // the remainder starts at a multiple of 12 elements, so channel phase 0 is preserved
-        hipLaunchKernelGGL(u8_norm_kernel, dim3(ew_blocks(n - done)), dim3(256), 0, s, in + done, out + done, n - done, C, p);
+        FAVAE_KLAUNCH(u8_norm_kernel, dim3(ew_blocks(n - done)), dim3(256), 0, s, in + done, out + done, n - done, C, p);
         FAVAE_CHECK_LAUNCH();
     }
     return FAVAE_OK;
@@ -226,16 +226,16 @@ extern "C" int favae_hinge_mean(const float* x, int64_t n, int mode, float* loss
     long nb = (n + 255) / 256;
     nb = nb > RED_BLOCKS ? RED_BLOCKS : nb;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(hinge_reduce_kernel, dim3((int)nb), dim3(256), 0, s, x, (long)n, mode, (double*)ws);
+    FAVAE_KLAUNCH(hinge_reduce_kernel, dim3((int)nb), dim3(256), 0, s, x, (long)n, mode, (double*)ws);
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, (int)nb, 1.0 / (double)n, loss);
+    FAVAE_KLAUNCH(finish_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, (int)nb, 1.0 / (double)n, loss);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
 
 extern "C" int favae_hinge_mean_bwd(const float* x, const float* g, int64_t n, int mode, float* dx, favae_stream_t stream) {
     FAVAE_REQUIRE(x && g && dx && n > 0 && mode >= 0 && mode <= 2);
-    hipLaunchKernelGGL(hinge_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, g, (float)(1.0 / (double)n),
+    FAVAE_KLAUNCH(hinge_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, g, (float)(1.0 / (double)n),
                        (long)n, mode, dx);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -243,7 +243,7 @@ extern "C" int favae_hinge_mean_bwd(const float* x, const float* g, int64_t n, i
 
 extern "C" int favae_act_bwd(const float* da, const float* x, int act, int64_t n, float* dx, favae_stream_t stream) {
     FAVAE_REQUIRE(da && x && dx && n > 0);
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, da, x, act, (long)n, dx);
+    FAVAE_KLAUNCH(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, da, x, act, (long)n, dx);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -262,7 +262,7 @@ extern "C" int favae_sqdiff_sum(const float* a, const float* b, int64_t n, float
 extern "C" int favae_absdiff_bwd(const float* a, const float* b, const float* g, float scale, int64_t n, const float* out_add,
                                  float* out, favae_stream_t stream) {
     FAVAE_REQUIRE(a && b && g && out && n > 0);
-    hipLaunchKernelGGL((diff_bwd_kernel<0>), dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, g, scale, (long)n,
+    FAVAE_KLAUNCH((diff_bwd_kernel<0>), dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, g, scale, (long)n,
                        out_add, out);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -270,7 +270,7 @@ extern "C" int favae_absdiff_bwd(const float* a, const float* b, const float* g,
 extern "C" int favae_sqdiff_bwd(const float* a, const float* b, const float* g, float scale, int64_t n, const float* out_add,
                                 float* out, favae_stream_t stream) {
     FAVAE_REQUIRE(a && b && g && out && n > 0);
-    hipLaunchKernelGGL((diff_bwd_kernel<1>), dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, g, scale, (long)n,
+    FAVAE_KLAUNCH((diff_bwd_kernel<1>), dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, g, scale, (long)n,
                        out_add, out);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -278,14 +278,14 @@ extern "C" int favae_sqdiff_bwd(const float* a, const float* b, const float* g, 
 
 extern "C" int favae_vq_ste(const float* x, const float* q, float* out, int64_t n, favae_stream_t stream) {
     FAVAE_REQUIRE(x && q && out && n > 0);
-    hipLaunchKernelGGL(ste_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, q, out, (long)n);
+    FAVAE_KLAUNCH(ste_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, q, out, (long)n);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
 
 extern "C" int favae_axpby(const float* x, float alpha, float* y, float beta, int64_t n, favae_stream_t stream) {
     FAVAE_REQUIRE(x && y && n > 0);
-    hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, alpha, y, beta, (long)n);
+    FAVAE_KLAUNCH(axpby_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, alpha, y, beta, (long)n);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -293,7 +293,7 @@ extern "C" int favae_axpby(const float* x, float alpha, float* y, float beta, in
 extern "C" int favae_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, favae_stream_t stream) {
     FAVAE_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0);
     const int rows = C, cols = H * W;     // [C][HW] -> [HW][C]
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32), N), dim3(256), 0, (hipStream_t)stream, x, y, rows,
+    FAVAE_KLAUNCH(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32), N), dim3(256), 0, (hipStream_t)stream, x, y, rows,
                        cols);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -301,7 +301,7 @@ extern "C" int favae_nchw_to_nhwc(const float* x, float* y, int N, int C, int H,
 extern "C" int favae_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, favae_stream_t stream) {
     FAVAE_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0);
     const int rows = H * W, cols = C;     // [HW][C] -> [C][HW]
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32), N), dim3(256), 0, (hipStream_t)stream, x, y, rows,
+    FAVAE_KLAUNCH(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32), N), dim3(256), 0, (hipStream_t)stream, x, y, rows,
                        cols);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -312,7 +312,8 @@ extern "C" int favae_adam_step(float* p, const float* g, float* m, float* v, int
     FAVAE_REQUIRE(p && g && m && v && n > 0 && step >= 1);
     const double bc1 = 1.0 - pow((double)beta1, step);
     const double bc2 = 1.0 - pow((double)beta2, step);
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2,
+    FAVAE_PROF_NOTE(0, 28.0 * n);                                          // reads p, g, m, v; writes p, m, v
+    FAVAE_KLAUNCH(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2,
                        eps, (float)bc1, (float)sqrt(bc2), grad_scale);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;

@@ -361,16 +361,17 @@ void launch_partial(const float* x, const float* da, const float* gamma, const f
                     const float* rstd, double* part, int N, long HW, int C, int G, int act, hipStream_t s) {
     const int S = gn_splits(N, HW);
     const long rpb = (HW + S - 1) / S;
+    FAVAE_PROF_NOTE(0, (MODE == 0 ? 4.0 : 8.0) * N * HW * C);             // one read of x (+ one of da)
     const bool vec = (C % 4 == 0) && ((((uintptr_t)x) & 15) == 0) && (MODE == 0 || (((uintptr_t)da) & 15) == 0);
     if (vec) {
         const int QT = C / 4, Q = QT < 256 ? QT : 256, RL = 256 / Q;
         const size_t shm = (size_t)RL * Q * 8 * sizeof(double);
-        hipLaunchKernelGGL((gn_partial_kernel<MODE, 4>), dim3(S, N), dim3(256), shm, s, x, da, gamma, beta, mean, rstd, part, HW, C,
+        FAVAE_KLAUNCH((gn_partial_kernel<MODE, 4>), dim3(S, N), dim3(256), shm, s, x, da, gamma, beta, mean, rstd, part, HW, C,
                            G, act, rpb);
     } else {
         const int Q = C < 256 ? C : 256, RL = 256 / Q;
         const size_t shm = (size_t)RL * Q * 2 * sizeof(double);
-        hipLaunchKernelGGL((gn_partial_kernel<MODE, 1>), dim3(S, N), dim3(256), shm, s, x, da, gamma, beta, mean, rstd, part, HW, C,
+        FAVAE_KLAUNCH((gn_partial_kernel<MODE, 1>), dim3(S, N), dim3(256), shm, s, x, da, gamma, beta, mean, rstd, part, HW, C,
                            G, act, rpb);
     }
 }
@@ -395,7 +396,7 @@ extern "C" int favae_gn_stats(const float* x, const float* gamma, const float* b
     if (absmax_out && hipMemsetAsync(absmax_out, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
     launch_partial<0>(x, nullptr, gamma, beta, nullptr, nullptr, part, N, (long)HW, C, G, 0, s);
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
+    FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N), dim3(256), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
                        acc, (long)HW, C, G, gn_splits(N, HW), eps, (unsigned*)absmax_out);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -415,31 +416,32 @@ extern "C" int favae_gn_act_bwd(const float* da, const float* x, const float* ga
     float* k2 = k1 + (size_t)N * C;
     launch_partial<1>(x, da, gamma, beta, mean, rstd, part, N, (long)HW, C, G, act, s);
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, s, (const double*)part, gamma, k1, k2, acc, (long)HW, C, G,
+    FAVAE_KLAUNCH(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, s, (const double*)part, gamma, k1, k2, acc, (long)HW, C, G,
                        gn_splits(N, HW));
     FAVAE_CHECK_LAUNCH();
     if (dgamma) {
-        hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)acc, dgamma, dbeta, N, C, accumulate);
+        FAVAE_KLAUNCH(gn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)acc, dgamma, dbeta, N, C, accumulate);
         FAVAE_CHECK_LAUNCH();
     }
     const size_t total = (size_t)N * HW * C;
+    FAVAE_PROF_NOTE(0, (dx_add ? 16.0 : 12.0) * total);                   // reads da, x (+ dx_add), writes dx
     const bool vec = (C % 4 == 0) && (((((uintptr_t)da) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)dx_add)) & 15) == 0);
     if (vec && C / 4 <= 256 && 256 % (C / 4) == 0) {
         long S = (HW + 255) / 256;                           // >= 256 pixels per block, ~2048 blocks in total
         const long cap = (2048 + N - 1) / N;
         S = S > cap ? cap : (S < 1 ? 1 : S);
         const long rpb = (HW + S - 1) / S;
-        hipLaunchKernelGGL(gn_bwd_apply_rows_kernel, dim3((unsigned)S, N), dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2,
+        FAVAE_KLAUNCH(gn_bwd_apply_rows_kernel, dim3((unsigned)S, N), dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2,
                            dx_add, dx, (long)HW, C, G, act, rpb);
     } else if (vec) {
         int blocks = (int)((total / 4 + 255) / 256);
         if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<true>), dim3(blocks), dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2,
+        FAVAE_KLAUNCH((gn_bwd_apply_kernel<true>), dim3(blocks), dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2,
                            dx_add, dx, N, (long)HW, C, G, act);
     } else {
         int blocks = (int)((total + 255) / 256);
         if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<false>), dim3(blocks), dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2,
+        FAVAE_KLAUNCH((gn_bwd_apply_kernel<false>), dim3(blocks), dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2,
                            dx_add, dx, N, (long)HW, C, G, act);
     }
     FAVAE_CHECK_LAUNCH();
@@ -449,7 +451,7 @@ extern "C" int favae_gn_act_bwd(const float* da, const float* x, const float* ga
 extern "C" int favae_bn_update_running(const float* mean, const float* rstd, int C, int64_t count, float eps, float momentum,
                                        float* running_mean, float* running_var, favae_stream_t stream) {
     FAVAE_REQUIRE(mean && rstd && running_mean && running_var && C > 0 && count > 0);
-    hipLaunchKernelGGL(bn_update_running_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, mean, rstd, C,
+    FAVAE_KLAUNCH(bn_update_running_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, mean, rstd, C,
                        (double)count, eps, momentum, running_mean, running_var);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;

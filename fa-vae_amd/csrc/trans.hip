@@ -146,7 +146,7 @@ extern "C" int favae_affine_rows(const float* x, const float* scale, const float
     FAVAE_REQUIRE(x && scale && shift && y && N > 0 && HW > 0 && C > 0);
     if (C % 4 || ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)scale) | ((uintptr_t)shift)) & 15)) return FAVAE_ERR_UNSUPPORTED;
     const long total4 = (long)N * HW * (C / 4);
-    hipLaunchKernelGGL(affine_rows_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+    FAVAE_KLAUNCH(affine_rows_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
                        (const float4*)scale, (const float4*)shift, (float4*)y, total4, (long)HW * (C / 4), C / 4, act);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -158,7 +158,7 @@ extern "C" int favae_layernorm_fwd(const float* x, const float* gamma, const flo
     if (C % 4 || C > 256 * LN_MAXQ || ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15))
         return FAVAE_ERR_UNSUPPORTED;
     const long blocks = (rows + 3) / 4;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, x,
+    FAVAE_KLAUNCH(layernorm_fwd_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, x,
                        gamma, beta, y, mean, rstd, (long)rows, C, eps);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -171,7 +171,7 @@ extern "C" int favae_layernorm_bwd(const float* dy, const float* x, const float*
         ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)dy_xhat) | ((uintptr_t)gamma)) & 15))
         return FAVAE_ERR_UNSUPPORTED;
     const long blocks = (rows + 3) / 4;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, dy, x,
+    FAVAE_KLAUNCH(layernorm_bwd_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, dy, x,
                        gamma, mean, rstd, dx, dy_xhat, (long)rows, C);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -183,7 +183,7 @@ extern "C" int favae_dropout(const float* x, const float* gate, float* y, int64_
     const double t = (double)p * 4294967296.0;
     const unsigned thresh = p > 0.f ? (unsigned)(t > 4294967295.0 ? 4294967295.0 : t) : 0u;
     const float scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-    hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, gate, y, (long)n, thresh, scale, seed);
+    FAVAE_KLAUNCH(dropout_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, gate, y, (long)n, thresh, scale, seed);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }

@@ -180,7 +180,9 @@ __global__ __launch_bounds__(256) void vq_select_kernel(const Top2* part, int T,
         top2_merge(t, u);
     }
     if (lane == 0) {
-        idx[tok] = t.i1;
+        // a token with a NaN component compares false everywhere and keeps the sentinel: torch.argmax treats NaN as the
+        // maximum and returns the first one, i.e. index 0 of an all-NaN score row (the NaN then propagates through zn / the loss)
+        idx[tok] = t.i1 == 0x7fffffff ? 0 : t.i1;
         flag[tok] = (t.v1 - t.v2 < tie_eps) ? 1 : 0;
     }
 }
@@ -217,14 +219,19 @@ __global__ __launch_bounds__(256) void vq_refine_kernel(const float* en, const f
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) idx[tok] = bi[0];
+    if (threadIdx.x == 0) idx[tok] = bi[0] == 0x7fffffff ? 0 : bi[0];
 }
 
-__global__ __launch_bounds__(256) void vq_gather_kernel(const float* embed, const long long* idx, float* zq, int T, int d) {
+__global__ __launch_bounds__(256) void vq_gather_kernel(const float* embed, const long long* idx, float* zq, int T, int d, int C) {
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tok >= T) return;
-    const float* e = embed + (size_t)idx[tok] * d;
+    const long long c = idx[tok];
     float* o = zq + (size_t)tok * d;
+    if (c < 0 || c >= C) {                                   // cannot happen after vq_select / vq_refine; never read out of bounds
+        for (int i = lane; i < d; i += 64) o[i] = __builtin_nanf("");
+        return;
+    }
+    const float* e = embed + (size_t)c * d;
     for (int i = lane; i < d; i += 64) o[i] = e[i];
 }
 
@@ -407,22 +414,22 @@ extern "C" int favae_vq_lookup(const float* z, const float* embed, int T, int d,
     const int tiles_c = cdiv(C, VBM), tiles_t = cdiv(T, VBN);
     Top2* part = (Top2*)ws;
     int* flag = (int*)((char*)ws + (size_t)T * tiles_c * sizeof(Top2));
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, z, zn, T, d);
+    FAVAE_KLAUNCH(l2norm_rows_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, z, zn, T, d);
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, embed, en, C, d);
+    FAVAE_KLAUNCH(l2norm_rows_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, embed, en, C, d);
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vq_dist_top2_kernel, dim3(tiles_c * tiles_t), dim3(256), 0, s, (const float*)en, (const float*)zn, part, C,
+    FAVAE_KLAUNCH(vq_dist_top2_kernel, dim3(tiles_c * tiles_t), dim3(256), 0, s, (const float*)en, (const float*)zn, part, C,
                        T, d, tiles_c);
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vq_select_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, (const Top2*)part, T, tiles_c, tie_eps,
+    FAVAE_KLAUNCH(vq_select_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, (const Top2*)part, T, tiles_c, tie_eps,
                        (long long*)idx, flag);
     FAVAE_CHECK_LAUNCH();
     if (tie_eps > 0.f) {
-        hipLaunchKernelGGL(vq_refine_kernel, dim3(T), dim3(256), (size_t)d * sizeof(float), s, (const float*)en, (const float*)zn,
+        FAVAE_KLAUNCH(vq_refine_kernel, dim3(T), dim3(256), (size_t)d * sizeof(float), s, (const float*)en, (const float*)zn,
                            (const int*)flag, C, d, (long long*)idx);
         FAVAE_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(vq_gather_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, embed, (const long long*)idx, zq, T, d);
+    FAVAE_KLAUNCH(vq_gather_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, embed, (const long long*)idx, zq, T, d, C);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
@@ -445,18 +452,18 @@ extern "C" int favae_vq_segment_sum(const float* zn, const int64_t* idx, int T, 
     if (hipMemsetAsync(count, 0, (size_t)C * sizeof(int), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
     int hb = cdiv(T, 256);
     if (hb > 1024) hb = 1024;
-    hipLaunchKernelGGL(vq_hist_kernel, dim3(hb), dim3(256), 0, s, (const long long*)idx, T, C, count);
+    FAVAE_KLAUNCH(vq_hist_kernel, dim3(hb), dim3(256), 0, s, (const long long*)idx, T, C, count);
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vq_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)count, offs, C);
+    FAVAE_KLAUNCH(vq_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)count, offs, C);
     FAVAE_CHECK_LAUNCH();
     const int G = C < VQ_PLACE_WAVES ? C : VQ_PLACE_WAVES;
-    hipLaunchKernelGGL(vq_place_kernel, dim3(G), dim3(64), (size_t)cdiv(C, G) * sizeof(int), s, (const long long*)idx, T, C,
+    FAVAE_KLAUNCH(vq_place_kernel, dim3(G), dim3(64), (size_t)cdiv(C, G) * sizeof(int), s, (const long long*)idx, T, C,
                        (const int*)offs, list);
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vq_long_partial_kernel, dim3(cdiv(cdiv(T, VQ_LONG), 4)), dim3(256), 0, s, zn, (const long long*)idx,
+    FAVAE_KLAUNCH(vq_long_partial_kernel, dim3(cdiv(cdiv(T, VQ_LONG), 4)), dim3(256), 0, s, zn, (const long long*)idx,
                        (const int*)list, (const int*)offs, (const int*)count, C, d, part);
     FAVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vq_segment_sum_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, zn, (const int*)list, (const int*)offs,
+    FAVAE_KLAUNCH(vq_segment_sum_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, zn, (const int*)list, (const int*)offs,
                        (const int*)count, (const float*)part, d, C, bins, embed_sum);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -465,7 +472,7 @@ extern "C" int favae_vq_segment_sum(const float* zn, const int64_t* idx, int T, 
 extern "C" int favae_vq_ema_update(float* embed, float* cluster_size, const float* en, const float* bins, const float* embed_sum,
                                    int C, int d, float decay, favae_stream_t stream) {
     FAVAE_REQUIRE(embed && cluster_size && en && bins && embed_sum && C > 0 && d > 0);
-    hipLaunchKernelGGL(vq_ema_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, embed, cluster_size, en, bins,
+    FAVAE_KLAUNCH(vq_ema_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, embed, cluster_size, en, bins,
                        embed_sum, C, d, decay);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;

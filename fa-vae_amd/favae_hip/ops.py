@@ -201,7 +201,13 @@ _SUBPIXEL_DGRAD = os.environ.get("FAVAE_SUBPIXEL_DGRAD", "1") != "0"     # Downs
 # independent of the chain  dgrad -> GroupNorm backward -> next layer: it is launched on a side stream, right after the data
 # gradient, and overlaps with the HBM-bound kernels of that chain (GroupNorm passes, bias gradients, blur / FFT backward).
 # FAVAE_WGRAD_STREAM=0 disables it (A/B switch).
-_SIDE = {"stream": None, "used": False, "on": os.environ.get("FAVAE_WGRAD_STREAM", "1") != "0"}
+# Operand lifetime: the autograd engine accumulates IN PLACE into a gradient tensor it holds the last reference to (e.g. the
+# second consumer of the `g` that _AddFn.backward hands to both inputs, or a `dres = dy` alias), and the caching allocator hands a
+# freed block out again in main-stream order -- neither is ordered against the side stream.  So every tensor a side-stream launch
+# reads stays referenced in _SIDE["pending"] until an event recorded behind that launch has completed (or the main stream has
+# waited for the side stream): a live reference forces the engine's out-of-place add and keeps the block out of the allocator.
+# _SIDE["delay"] > 0 (tests only) puts a busy-wait of that many cycles in front of every side-stream launch.
+_SIDE = {"stream": None, "used": False, "on": os.environ.get("FAVAE_WGRAD_STREAM", "1") != "0", "pending": [], "delay": 0}
 
 
 def _side_stream():
@@ -217,6 +223,27 @@ def sync_side_stream():
     if _SIDE["used"]:
         torch.cuda.current_stream().wait_stream(_SIDE["stream"])
         _SIDE["used"] = False
+    _SIDE["pending"].clear()               # later main-stream work is ordered behind the side stream now
+
+
+def _side_launch(fn, operands):
+    """Run fn() (kernel launches) on the side stream after everything queued on the current stream, keep `operands` alive until the
+    side stream is past these launches, and make the end of the running backward pass wait for them."""
+    side = _side_stream()
+    pend = _SIDE["pending"]
+    while pend and pend[0][0].query():                     # retire launches the side stream has finished
+        pend.pop(0)
+    side.wait_stream(torch.cuda.current_stream())          # operands (dy, its range from the bias-gradient pass) are ready
+    with torch.cuda.stream(side):
+        if _SIDE["delay"]:
+            torch.cuda._sleep(int(_SIDE["delay"]))
+        fn()
+        ev = torch.cuda.Event()
+        ev.record(side)
+    pend.append((ev, [t for t in operands if t is not None]))
+    if not _SIDE["used"]:
+        _SIDE["used"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(sync_side_stream)
 
 
 _GRAD_ONLY = None          # None | "data" | "param"  (see grad_only)
@@ -435,17 +462,9 @@ class FusedConvFn(torch.autograd.Function):
                 wd, wws, wtgt = d, ws, tgt
 
                 def side_wgrad():
-                    side = _side_stream()
-                    side.wait_stream(torch.cuda.current_stream())     # operands (dy, its range from the bias-gradient pass) are ready
-                    with torch.cuda.stream(side):
-                        call("favae_conv_wgrad", byref(wd), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(wtgt), 1,
-                             ptr(wws), wws.numel())
-                    for t in (x, dy, scale, shift, xb, dyb, wws):
-                        if t is not None:
-                            t.record_stream(side)             # the caching allocator must not hand these out again too early
-                    if not _SIDE["used"]:
-                        _SIDE["used"] = True
-                        torch.autograd.Variable._execution_engine.queue_callback(sync_side_stream)
+                    _side_launch(lambda: call("favae_conv_wgrad", byref(wd), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb),
+                                              ptr(dyb), ptr(wtgt), 1, ptr(wws), wws.numel()),
+                                 (x, dy, scale, shift, xb, dyb, wws))
                 # launched AFTER this conv's data gradient (below): the side stream then starts it next to the HBM-bound
                 # GroupNorm-backward / bias-gradient kernels that follow instead of next to the other matrix-bound kernel
                 # (measured: 204 -> 196 ms/step; launching it before the data gradient only gave 208 -> 204)
@@ -601,16 +620,7 @@ class UpsampleConvFn(torch.autograd.Function):
                      1 if tgt is not None else 0)
             if tgt is not None and _SIDE["on"]:
                 def late():
-                    side = _side_stream()
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        wgrad()
-                    for t in (x, dy, xb, dyb, wss, dweff):
-                        if t is not None:
-                            t.record_stream(side)
-                    if not _SIDE["used"]:
-                        _SIDE["used"] = True
-                        torch.autograd.Variable._execution_engine.queue_callback(sync_side_stream)
+                    _side_launch(wgrad, (x, dy, xb, dyb, wss, dweff))
             else:
                 wgrad()
                 if dwk is not None:

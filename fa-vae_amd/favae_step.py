@@ -40,6 +40,77 @@ def _flatten(params, dev):
     return pflat, gflat, mflat, vflat
 
 
+class _GradMark(torch.autograd.Function):
+    """Identity whose backward runs a callback: placed on a module input, it fires once the gradient with respect to that input is
+    being formed, i.e. after every autograd node downstream of it in the forward pass has run its backward -- the point at which
+    all weight gradients of those modules have been launched."""
+
+    @staticmethod
+    def forward(ctx, x, cb):
+        ctx.cb = cb
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.cb()
+        return g, None
+
+
+class GradExchange:
+    """Bucketed gradient all-reduce overlapped with the backward pass (what DDP's reducer does for the reference,
+    favae_scripts/train_favae.py:344-347), over contiguous slices of ONE flat gradient buffer.
+
+    `segments` lists, in the order they become final during backward, the [a, b) ranges of the flat buffer each exchange step
+    covers; together they must tile the buffer exactly.  fire(i) queues the SUM all-reduce of segment i (asynchronously, behind
+    everything queued so far on the compute streams); finish() queues whatever has not been fired and makes the current stream
+    wait for all of them.  RCCL ("nccl" backend) on the GPU; works unchanged on CPU tensors over gloo (tests)."""
+
+    def __init__(self, gflat, segments, side_stream=None):
+        cover = sorted(r for seg in segments for r in seg if r[1] > r[0])
+        pos = 0
+        for a, b in cover:
+            if a != pos:
+                raise ValueError("gradient segments must tile the flat buffer: gap or overlap at %d (next range starts at %d)" % (pos, a))
+            pos = b
+        if pos != gflat.numel():
+            raise ValueError("gradient segments end at %d, the flat buffer has %d elements" % (pos, gflat.numel()))
+        self.gflat, self.segments = gflat, [[r for r in seg if r[1] > r[0]] for seg in segments]
+        self.cuda = gflat.is_cuda
+        self.comm = torch.cuda.Stream() if self.cuda else None
+        self.side_stream = side_stream          # callable -> the stream that carries the weight gradients (or None)
+        self.fired = [False] * len(self.segments)
+        self.works = []
+
+    def reset(self):
+        self.fired = [False] * len(self.segments)
+        self.works = []
+
+    def fire(self, i):
+        if self.fired[i]:
+            return
+        self.fired[i] = True
+        if not self.segments[i]:
+            return
+        if self.cuda:
+            self.comm.wait_stream(torch.cuda.current_stream())
+            side = self.side_stream() if self.side_stream is not None else None
+            if side is not None:
+                self.comm.wait_stream(side)
+            with torch.cuda.stream(self.comm):
+                for a, b in self.segments[i]:
+                    self.works.append(dist.all_reduce(self.gflat[a:b], async_op=True))
+        else:
+            for a, b in self.segments[i]:
+                self.works.append(dist.all_reduce(self.gflat[a:b], async_op=True))
+
+    def finish(self):
+        for i in range(len(self.segments)):
+            self.fire(i)
+        for w in self.works:
+            w.wait()                              # GPU: the current stream waits for the collective; CPU: blocks
+        self.works = []
+
+
 class TrainStep:
     def __init__(self, model, lr, betas=(0.5, 0.9), eps=1e-8, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01,
                  sigma_lr=2.0e-7, distributed=False, train_disc=False, disc_weight=0.75, lpips=None, perceptual_weight=1.0,
@@ -57,7 +128,8 @@ class TrainStep:
         self.sl_kernel, self.sl_sigma = gaussian_kernel, gaussian_sigma
         self.distributed = distributed and dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.distributed else 1
-        self.t = 0
+        self.t = 0                     # opt_g steps taken
+        self.t_d = 0                   # opt_d steps taken (its own count: the reference's opt_d only starts at disc_start_epochs)
         # opt_g parameter set: encoder + decoder + quantizer (+ pair-wise model.sigmas at its own lr)
         main = list(model.encoder.parameters()) + list(model.decoder.parameters()) + list(model.quantizer.parameters())
         extra = [model.sigmas] if hasattr(model, "sigmas") else []
@@ -69,6 +141,79 @@ class TrainStep:
         if train_disc:                 # opt_d (train_favae.py:304-305)
             self.dparams = list(model.discriminator.parameters())
             self.dpflat, self.dgflat, self.dmflat, self.dvflat = _flatten(self.dparams, dev)
+        self.exchange = None
+        if self.distributed:
+            self._broadcast_initial_state()
+            self._setup_overlapped_exchange()
+
+    # ------------------------------------------------------------------------------------------------------------
+    # data parallelism: one process per GPU, each on its own slice of the global batch
+    # ------------------------------------------------------------------------------------------------------------
+    def _broadcast_initial_state(self):
+        """Rank 0's parameters and buffers to every rank, once (what DDP does when accelerate.prepare wraps the model,
+        train_favae.py:344): ranks then stay identical because every update is computed from all-reduced quantities."""
+        dist.broadcast(self.pflat, 0)
+        if self.train_disc:
+            dist.broadcast(self.dpflat, 0)
+        flat = set(id(p) for p in self.params) | (set(id(p) for p in self.dparams) if self.train_disc else set())
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            if id(t) not in flat and t.is_floating_point():
+                dist.broadcast(t.data, 0)
+
+    def _setup_overlapped_exchange(self):
+        """Cut the flat gradient buffer where backward finishes whole module groups and start each group's all-reduce right there
+        (FAVAE_OVERLAP_COMM=0: one all-reduce after backward).  Flat layout = registration order: encoder [.. mid, final, (sigmas)],
+        decoder [(sigmas), fcm_1, conv_in, fcm_2, mid, fcm_3 | up, fcm_4, final], quantizer, model.sigmas; backward finishes
+        decoder.up..final first, then the rest of the decoder and the quantizer, then encoder.mid..final, then the encoder's
+        down path."""
+        import os
+        total = self.gflat.numel()
+        if os.environ.get("FAVAE_OVERLAP_COMM", "1") == "0":
+            return
+        off = {}
+        pos = 0
+        for p in self.params:
+            off[id(p)] = pos
+            pos += p.numel()
+        enc, dec = self.model.encoder, self.model.decoder
+
+        def first_off(mod):
+            ps = list(mod.parameters())
+            return off[id(ps[0])] if ps else None
+        n_enc = sum(p.numel() for p in enc.parameters())
+        n_dec = sum(p.numel() for p in dec.parameters())
+        o_up, o_mid = first_off(dec.up) if hasattr(dec, "up") else None, first_off(enc.mid) if hasattr(enc, "mid") else None
+        if o_up is None or o_mid is None:
+            return
+        segs = [[(o_up, n_enc + n_dec)],                       # decoder.up, fcm_4, final
+                [(n_enc, o_up), (n_enc + n_dec, total)],       # decoder head, quantizer, pair-wise sigmas
+                [(o_mid, n_enc)],                              # encoder.mid, final, own sigmas
+                [(0, o_mid)]]                                  # encoder.conv_in, down
+        self.exchange = GradExchange(self.gflat, segs, side_stream=lambda: K._SIDE["stream"])
+        self._armed = False
+
+        def mark(i):
+            def cb():
+                if self._armed:
+                    self.exchange.fire(i)
+            return cb
+
+        def pre_hook(i):
+            def hook(mod, args):
+                x = args[0]
+                if torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
+                    return (_GradMark.apply(x, mark(i)),) + tuple(args[1:])
+                return None
+            return hook
+
+        def enc_out_hook(mod, args, out):
+            h = out[0]
+            if torch.is_grad_enabled() and h.requires_grad:
+                return (_GradMark.apply(h, mark(1)),) + tuple(out[1:])
+            return None
+        dec.up.register_forward_pre_hook(pre_hook(0))
+        enc.register_forward_hook(enc_out_hook)
+        enc.mid.register_forward_pre_hook(pre_hook(2))
 
     # ------------------------------------------------------------------------------------------------------------
     # checkpoint wire format of the reference (train_favae.py:366-379): {"model", "opt_g", "opt_d", "epoch", "step", "loss_recon"}
@@ -121,7 +266,7 @@ class TrainStep:
     def opt_d_state_dict(self):
         if not self.train_disc:              # the reference creates (and saves) opt_d even when it never steps: empty state
             return self._adam_state_dict([(list(self.model.discriminator.parameters()), self.lr)], None, None, 0)
-        return self._adam_state_dict([(self.dparams, self.lr)], self.dmflat, self.dvflat, self.t)
+        return self._adam_state_dict([(self.dparams, self.lr)], self.dmflat, self.dvflat, self.t_d)
 
     def load_opt_state_dicts(self, opt_g=None, opt_d=None):
         """Resume the optimizer moments and step count from torch.optim.Adam state dicts (the reference saves them but only
@@ -129,7 +274,7 @@ class TrainStep:
         if opt_g is not None:
             self.t = self._load_adam_state(opt_g, self.params, self.mflat, self.vflat)
         if opt_d is not None and self.train_disc:
-            self.t = max(self.t, self._load_adam_state(opt_d, self.dparams, self.dmflat, self.dvflat))
+            self.t_d = self._load_adam_state(opt_d, self.dparams, self.dmflat, self.dvflat)
 
     def checkpoint(self, epoch, step, loss_recon=None):
         """the dict the reference hands to utils.save_model (train_favae.py:366-374)"""
@@ -150,27 +295,30 @@ class TrainStep:
             out["loss_perceptual"] = self.lpips(x, x_recon).mean()
             loss_recon = loss_recon + self.pw * out["loss_perceptual"]
         out["loss_recon"] = loss_recon
-        loss_g = loss_recon + self.cw * loss_q
+        rest = self.cw * loss_q                              # every term of loss_g whose graph does not pass through loss_recon
+        loss_g = loss_recon + rest
         if self.ffl is not None:
             out["loss_ffl"] = recon_ffl_loss(self.ffl, x, x_recon)
-            loss_g = loss_g + out["loss_ffl"]
+            loss_g, rest = loss_g + out["loss_ffl"], rest + out["loss_ffl"]
         if self.dsl is not None:
             out["loss_dsl"], out["loss_dsl_levels"] = recon_ffl_features_loss(self.dsl, enc_feats, dec_feats, x.device)
-            loss_g = loss_g + out["loss_dsl"]
+            loss_g, rest = loss_g + out["loss_dsl"], rest + out["loss_dsl"]
         if self.sl is not None:                              # reverses dec_feats in place once more, like the reference
             out["loss_sl"], out["loss_sl_levels"] = recon_sl_gaussian_features_loss(self.sl, self.sl_kernel, self.sl_sigma,
                                                                                     enc_feats, dec_feats, x.device)
-            loss_g = loss_g + out["loss_sl"]
+            loss_g, rest = loss_g + out["loss_sl"], rest + out["loss_sl"]
         if self.train_disc:                                  # train_favae.py:82-88
             out["loss_disc"] = hinge_g_loss(_logits_fake)
             out["weight_d"], g_recon, g_disc = self.adaptive_weight(loss_recon, out["loss_disc"], x_recon)
             # loss_g.backward() would walk the LPIPS stack and the discriminator a second time to reach x_recon; their
             # gradients at x_recon are already known from the adaptive weight, so step() back-propagates
-            #   rest = loss_g - loss_recon - w_d * disc_weight * loss_disc      (everything else, through the graph)
+            #   rest = cw * loss_q + loss_ffl + loss_dsl [+ loss_sl]            (everything else, through the graph; assembled
+            #                                                                    from those terms, NOT as loss_g - loss_recon:
+            #                                                                    autograd would walk loss_recon's graph with zeros)
             #   x_recon <- g_recon + w_d * disc_weight * g_disc                 (handed in at x_recon)
             # -- the same total gradient for encoder / decoder / quantizer.  The discriminator's own stage-0 gradients, which
             # the reference computes here and discards at opt_d.zero_grad() (train_favae.py:109), are not computed at all.
-            out["_bwd"] = (loss_g - loss_recon, x_recon, g_recon + (out["weight_d"] * self.disc_weight) * g_disc)
+            out["_bwd"] = (rest, x_recon, g_recon + (out["weight_d"] * self.disc_weight) * g_disc)
             loss_g = loss_g + out["weight_d"] * self.disc_weight * out["loss_disc"]
         out["logits_fake"] = _logits_fake
         out["loss_g"] = loss_g
@@ -199,11 +347,18 @@ class TrainStep:
         """loss_g.backward() of train_favae.py:105 on the dict losses() returned.  With discriminator training the gradients of
         loss_recon and loss_disc at x_recon were already computed for the adaptive weight and are handed in there (see losses())."""
         bwd = out.pop("_bwd", None)
-        if bwd is None:
-            out["loss_g"].sum().backward()
-        else:
-            rest, x_recon, g_x = bwd
-            torch.autograd.backward([rest.sum(), x_recon], [None, g_x])
+        if self.exchange is not None:           # the gradient marks start their all-reduces only inside THIS backward pass
+            self.exchange.reset()               # (not in the partial passes of adaptive_weight)
+            self._armed = True
+        try:
+            if bwd is None:
+                out["loss_g"].sum().backward()
+            else:
+                rest, x_recon, g_x = bwd
+                torch.autograd.backward([rest.sum(), x_recon], [None, g_x])
+        finally:
+            if self.exchange is not None:
+                self._armed = False
 
     def disc_step(self, x):
         """Stage 1 (train_favae.py:108-116): discriminator update on (x, x_recon.detach()); model(x, stage=1) recomputes the
@@ -215,7 +370,8 @@ class TrainStep:
         K.sync_side_stream()
         if self.distributed:
             dist.all_reduce(self.dgflat)
-        K.adam_step(self.dpflat, self.dgflat, self.dmflat, self.dvflat, self.t, self.lr, self.betas, self.eps, 1.0 / self.world)
+        self.t_d += 1
+        K.adam_step(self.dpflat, self.dgflat, self.dmflat, self.dvflat, self.t_d, self.lr, self.betas, self.eps, 1.0 / self.world)
         return {"loss_d": loss_d, "logits_real": logits_real, "logits_fake_d": logits_fake}
 
     def step(self, x):
@@ -225,8 +381,10 @@ class TrainStep:
         out = self.losses(x)
         self.backward(out)
         K.sync_side_stream()                                 # weight gradients run on a second stream (ops._SIDE)
-        if self.distributed:
-            dist.all_reduce(self.gflat)                      # RCCL over xGMI; averaged inside the Adam kernel
+        if self.exchange is not None:
+            self.exchange.finish()                           # segments not yet started + wait for all (RCCL over xGMI)
+        elif self.distributed:
+            dist.all_reduce(self.gflat)                      # one RCCL all-reduce; averaged inside the Adam kernel
         self.t += 1
         gs = 1.0 / self.world
         nm = self.n_main

@@ -42,7 +42,7 @@ def test_adam_state_dict_loads_into_torch_optim(tmp_path):
     for extra, train_disc in ((dict(use_gauss_resblock=True), True), (dict(use_non_pair_conv=True), False)):
         model = _model(**extra)
         ts = TrainStep(model, lr=1e-4, train_disc=train_disc)
-        ts.t = 3
+        ts.t, ts.t_d = 3, 2                     # opt_d keeps its own step count (it starts later: disc_start_epochs)
         _fill(ts, 1)
         # the optimizers exactly as the reference builds them (train_favae.py:292-305)
         g_params = list(model.encoder.parameters()) + list(model.decoder.parameters()) + list(model.quantizer.parameters())
@@ -70,7 +70,7 @@ def test_adam_state_dict_loads_into_torch_optim(tmp_path):
             assert torch.equal(st["exp_avg_sq"].reshape(-1), ts.vflat[off:off + n].as_strided(p.shape, p.stride()).reshape(-1))
             off += n
         if train_disc:
-            assert all(float(opt_d.state[p]["step"]) == 3.0 for p in model.discriminator.parameters())
+            assert all(float(opt_d.state[p]["step"]) == 2.0 for p in model.discriminator.parameters())
         else:
             assert len(opt_d.state) == 0
         # and back: a fresh TrainStep resumes from torch's own state dicts
@@ -78,7 +78,7 @@ def test_adam_state_dict_loads_into_torch_optim(tmp_path):
         model2.load_state_dict(ck["model"], strict=True)
         ts2 = TrainStep(model2, lr=1e-4, train_disc=train_disc)
         ts2.load_opt_state_dicts(opt_g.state_dict(), opt_d.state_dict())
-        assert ts2.t == 3
+        assert ts2.t == 3 and ts2.t_d == (2 if train_disc else 0)
         assert torch.equal(ts2.mflat, ts.mflat) and torch.equal(ts2.vflat, ts.vflat)
         if train_disc:
             assert torch.equal(ts2.dmflat, ts.dmflat) and torch.equal(ts2.dvflat, ts.dvflat)

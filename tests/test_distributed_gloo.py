@@ -10,6 +10,7 @@ checked in test_trainstep_flat_views."""
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -102,3 +103,121 @@ def test_trainstep_flat_views():
     assert m.sigmas.data_ptr() == ts.pflat.data_ptr() + 4 * ts.n_main
     ts.gflat.fill_(1.0)
     assert float(m.encoder.conv_in.weight.grad.sum()) == m.encoder.conv_in.weight.numel()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Host logic of the PRODUCT TrainStep at world_size 2 (gloo, CPU): initial broadcast, gradient marks, bucketed overlapped
+# all-reduce (favae_step.GradExchange).  The HIP kernels cannot run here, so the model is a stand-in with the same module
+# skeleton (encoder.{down,mid,final}, decoder.{head,up,final}, quantizer) made of nn.Linear layers; everything that is exercised --
+# flat buffers, segment tiling, hook placement, firing order, collectives -- is the product code.
+# ---------------------------------------------------------------------------------------------------------------------------
+class _ToyEnc(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.down = torch.nn.Linear(6, 8)
+        self.mid = torch.nn.Linear(8, 8)
+        self.final = torch.nn.Linear(8, 4)
+
+    def forward(self, x):
+        h = self.final(torch.tanh(self.mid(torch.tanh(self.down(x)))))
+        return h, [h]
+
+
+class _ToyDec(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.head = torch.nn.Linear(4, 8)
+        self.up = torch.nn.Linear(8, 8)
+        self.final = torch.nn.Linear(8, 6)
+
+    def forward(self, z):
+        return self.final(torch.tanh(self.up(torch.tanh(self.head(z)))))
+
+
+class _ToyModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.encoder, self.decoder = _ToyEnc(), _ToyDec()
+        self.quantizer = torch.nn.Linear(4, 4)
+        self.register_buffer("codebook", torch.randn(5, 4))
+
+    def forward(self, x):
+        h, _ = self.encoder(x)
+        return self.decoder(self.quantizer(h))
+
+
+def _exchange_worker(rank, world, port, q, overlap):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      FAVAE_OVERLAP_COMM="1" if overlap else "0")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from favae_step import TrainStep
+    torch.manual_seed(100 + rank)                            # ranks start DIFFERENT: the initial broadcast must fix that
+    model = _ToyModel()
+    ts = TrainStep(model, lr=1e-3, distributed=True, ffl_weight=0.0, dsl_weight=0.0)
+    state0 = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}      # numpy: pickled by value through the queue
+    order = []
+    if overlap:
+        assert ts.exchange is not None
+        fire0 = ts.exchange.fire
+        ts.exchange.fire = lambda i: (order.append(i) if not ts.exchange.fired[i] else None, fire0(i))[1]
+    xs = torch.randn(4, 6, generator=torch.Generator().manual_seed(7))
+    x = xs[2 * rank:2 * rank + 2]
+    ts.gflat.zero_()
+    loss = ((model(x) - x) ** 2).mean()
+    ts.backward({"loss_g": loss})
+    local = ts.gflat.clone() if not overlap else None
+    if ts.exchange is not None:
+        ts.exchange.finish()
+    else:
+        dist.all_reduce(ts.gflat)
+    q.put((rank, {"state0": state0, "g": ts.gflat.clone().numpy(), "order": order, "segments": ts.exchange.segments if overlap else None}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_trainstep_host_logic_two_ranks(overlap):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q, overlap)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # (1) the initial broadcast made every rank start from rank 0's parameters and buffers
+    torch.manual_seed(100)
+    ref_model = _ToyModel()
+    for k, v in ref_model.state_dict().items():
+        assert np.array_equal(got[0]["state0"][k], v.numpy()) and np.array_equal(got[1]["state0"][k], v.numpy()), k
+    # (2) the exchanged flat gradient = sum over ranks of the local gradients = world x the global-batch gradient
+    xs = torch.randn(4, 6, generator=torch.Generator().manual_seed(7))
+    loss = ((ref_model(xs) - xs) ** 2).mean()
+    loss.backward()
+    main = list(ref_model.encoder.parameters()) + list(ref_model.decoder.parameters()) + list(ref_model.quantizer.parameters())
+    gref = torch.cat([p.grad.reshape(-1) for p in main]) * world           # mean over 4 samples vs sum of two means over 2
+    for r in range(world):
+        assert float((torch.from_numpy(got[r]["g"]) - gref).abs().max()) < 1e-5 * float(gref.abs().max())
+    if overlap:
+        # (3) segments tile the buffer, and the marks fired them in backward order: decoder tail, decoder head + quantizer,
+        # encoder mid/final, then finish() fires the encoder's down path
+        assert got[0]["order"] == [0, 1, 2, 3]
+        segs = got[0]["segments"]
+        n = gref.numel()
+        assert sorted(r for s in segs for r in s)[0][0] == 0 and sorted(r for s in segs for r in s)[-1][1] == n
+
+
+def test_grad_exchange_rejects_bad_tilings():
+    from favae_step import GradExchange
+    g = torch.zeros(10)
+    with pytest.raises(ValueError):
+        GradExchange(g, [[(0, 4)], [(5, 10)]])
+    with pytest.raises(ValueError):
+        GradExchange(g, [[(0, 6)], [(4, 10)]])
+    with pytest.raises(ValueError):
+        GradExchange(g, [[(0, 9)]])
+    GradExchange(g, [[(4, 10)], [(0, 4), (10, 10)]])

@@ -21,6 +21,15 @@ MODEL_KW = {
     "cfg1_k3": (dict(codebook_size=1024, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
                      use_l2_quantizer=True, kernel_size=3, dsl_init_sigma=3.0, use_gauss_resblock=True),
                 dict(codebook_size=1024, variant="gauss_resblock", kernel_size=3)),
+    # BASELINE configs[1] wiring at its codebook size
+    "cfg2": (dict(codebook_size=16384, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
+                  use_l2_quantizer=True, kernel_size=9, dsl_init_sigma=3.0, use_gauss_resblock=True),
+             dict(codebook_size=16384, variant="gauss_resblock", kernel_size=9)),
+    # BASELINE configs[3] model: f=4, embed_dim 3 -> codebook_dim 256, codebook 8192, conv FCM with one sigma per pair, k=9
+    "f4_full": (dict(codebook_size=8192, n_embed=3, ch_mult=(1, 2, 4), attn_resolutions=[], use_cosine_sim=True, codebook_dim=256,
+                     use_l2_quantizer=True, kernel_size=9, dsl_init_sigma=3.0, use_same_conv_gauss=True, num_groups=3),
+                dict(codebook_size=8192, n_embed=3, ch_mult=(1, 2, 4), attn_resolutions=(), codebook_dim=256, kernel_size=9,
+                     variant="same_conv_gauss", num_groups=3)),
     "f4_same_conv": (dict(codebook_size=512, n_embed=3, ch_mult=(1, 2, 4), attn_resolutions=[], use_cosine_sim=True,
                           codebook_dim=32, use_l2_quantizer=True, kernel_size=3, dsl_init_sigma=3.0, use_same_conv_gauss=True,
                           num_groups=3),
@@ -113,7 +122,7 @@ def _golden_step(g, gtag, mtag, grad_tol=5e-3):
     model, cfg, _ = build(mtag)
     B, H, W, seed = [int(v) for v in g[gtag + ".shape"]]
     x = O.det_input(B, H, W, seed).to(DEV)
-    ts = TrainStep(model, lr=4.5e-6 * 2, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01)
+    ts = TrainStep(model, lr=4.5e-6 * B, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01)
     model.train()
     ts.gflat.zero_()
     out = ts.losses(x)
@@ -181,6 +190,115 @@ def test_train_step_cfg1_256_against_reference_golden(golden_dir):
     for k in ("encoder.conv_in.weight", "decoder.final.2.weight", "encoder.sigmas", "decoder.sigmas"):
         got = named[k].detach().cpu().contiguous().reshape(-1)[:16]
         close(got, g[f"cfg1_256.adam.{k}.head"], 1e-6, "adam." + k)
+
+
+@pytest.mark.parametrize("gtag,mtag", [("cfg2_256", "cfg2"), ("f4_256", "f4_full")])
+def test_train_step_at_baseline_sizes_against_reference_golden(golden_dir, gtag, mtag):
+    """The sizes that distinguish the BASELINE configs, one full reference step each (forward, every loss, backward, Adam):
+    cfg2_256 = configs[1] wiring at codebook 16384 (256x256, batch 2 of the 32); f4_256 = the configs[3] model at 256x256 (batch 1
+    of the 16): f=4, gaussian_kernel 9, num_groups 3, codebook 8192 behind Linear(3,256), 4096 tokens, the two L=4096 / d=512
+    AttnBlocks of the mid stages (models/codec.py:87-102), 9-tap blurs on 64^2..256^2 maps."""
+    g = np.load(os.path.join(golden_dir, gtag + ".npz"))
+    model, ts, out = _golden_step(g, gtag, mtag)
+    B, H, W, seed = [int(v) for v in g[gtag + ".shape"]]
+    with torch.no_grad():
+        m2, _, _ = build(mtag)
+        m2.train()
+        _, _, ind, _ = m2.encode(O.det_input(B, H, W, seed).to(DEV))
+    gap = g[gtag + ".index_gap"]
+    flips = check_indices(ind.cpu().numpy(), g[gtag + ".indices"], gap, gtag)
+    print(f"\n[{gtag}] tokens {gap.size}, reference gaps < 1e-6: {int((gap < 1e-6).sum())}, flips: {flips}")
+    assert flips == 0
+    lf = out["logits_fake"].detach().double().abs().sum()
+    assert abs(float(lf) - float(g[gtag + ".logits_fake_abs"])) < 1e-4 * float(g[gtag + ".logits_fake_abs"]), "logits_fake"
+    close(model.discriminator.features[3].running_mean, g[gtag + ".bn_running_mean"], 1e-4, "disc BN running mean")
+    assert abs(float(model.quantizer._codebook.embed.double().abs().sum()) - float(g[gtag + ".embed_after_abs"])) < 1e-5 * float(g[gtag + ".embed_after_abs"])
+    close(model.quantizer._codebook.cluster_size, g[gtag + ".cluster_after"], 1e-6, "cluster sizes")
+    from favae_hip import ops as K
+    ts.t += 1
+    nm = ts.n_main
+    K.adam_step(ts.pflat[:nm], ts.gflat[:nm], ts.mflat[:nm], ts.vflat[:nm], 1, ts.lr, ts.betas, ts.eps, 1.0)
+    if ts.pflat.numel() > nm:
+        K.adam_step(ts.pflat[nm:], ts.gflat[nm:], ts.mflat[nm:], ts.vflat[nm:], 1, ts.sigma_lr, ts.betas, ts.eps, 1.0)
+    named = dict(model.named_parameters())
+    n = 0
+    for k in ("encoder.conv_in.weight", "decoder.final.2.weight", "encoder.sigmas", "decoder.sigmas", "sigmas"):
+        if f"{gtag}.adam.{k}.head" in g.files:
+            close(named[k].detach().cpu().contiguous().reshape(-1)[:16], g[f"{gtag}.adam.{k}.head"], 1e-6, "adam." + k)
+            n += 1
+    assert n >= 3
+
+
+@pytest.mark.parametrize("mtag,hw", [("nonpair_conv", 64), ("cfg1_k3", 64), ("f4_same_conv", 32)])
+def test_side_stream_weight_gradients_are_race_free(mtag, hw):
+    """Weight gradients run on a second HIP stream and read dy / x there.  The autograd engine may accumulate IN PLACE into a
+    gradient tensor it holds the last reference to (the `g` that an add hands to both of its inputs; a `dres = dy` alias), on the
+    main stream, with no ordering against the side stream.  With an artificially slow side stream (a busy-wait in front of every
+    side launch) any such write would land before the weight-gradient kernel has read its operand: gradients must stay bit-identical
+    to the single-stream run."""
+    from favae_hip import ops as K
+    from favae_step import TrainStep
+    x = O.det_input(2, hw, hw, 31).to(DEV)
+
+    def grads(side_on, delay):
+        model, _, _ = build(mtag)
+        ts = TrainStep(model, lr=1e-4)
+        model.train()
+        prev = K._SIDE["on"], K._SIDE["delay"]
+        K._SIDE["on"], K._SIDE["delay"] = side_on, delay
+        try:
+            ts.gflat.zero_()
+            out = ts.losses(x)
+            ts.backward(out)
+            K.sync_side_stream()
+            torch.cuda.synchronize()
+        finally:
+            K._SIDE["on"], K._SIDE["delay"] = prev
+        assert not K._SIDE["pending"]
+        return ts.gflat.clone()
+    ref = grads(False, 0)
+    assert torch.isfinite(ref).all() and float(ref.abs().sum()) > 0
+    got = grads(True, 400000)                    # ~0.2 ms in front of each of the ~150 side-stream launches
+    assert torch.equal(got, ref), "two-stream gradients differ from the single-stream run: %g" % float((got - ref).abs().max())
+
+
+def test_gan_stage1_discriminator_alone_against_reference_golden(golden_dir):
+    """Stage 1 of train() without the chaotic generator step in front of it: the discriminator on (x, the reference's own stage-1
+    reconstruction stored in the fixture): logits, hinge_d and every discriminator gradient against the reference, tight."""
+    from models.vqgan_fcm import VQGANFCM
+    from favae_step import TrainStep
+    from losses.hinge import hinge_d_loss
+    g = np.load(os.path.join(golden_dir, "gan_128.npz"))
+    B, H, W, seed = [int(v) for v in g["gan_128.shape"]]
+    mk = dict(codebook_size=512, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
+              use_l2_quantizer=True, kernel_size=9, dsl_init_sigma=3.0, use_same_conv_gauss=True, num_groups=32)
+    cfg = O.OracleConfig(codebook_size=512, variant="same_conv_gauss", kernel_size=9, num_groups=32)
+    model = VQGANFCM(**mk, device=DEV)
+    model.load_state_dict(O.det_state(cfg, with_disc=True), strict=True)
+    model = model.to(DEV).train()
+    ts = TrainStep(model, lr=1e-5, train_disc=True)
+    ts.dgflat.zero_()
+    x = O.det_input(B, H, W, seed).to(DEV)
+    xr = torch.from_numpy(g["gan_128.x_recon_d"]).to(DEV)
+    logits_real = model.discriminator(x)
+    logits_fake = model.discriminator(xr)
+    loss_d = hinge_d_loss(logits_real, logits_fake)
+    loss_d.backward()
+    torch.cuda.synchronize()
+    close(logits_real, g["gan_128.logits_real"], 1e-4, "logits_real")
+    close(logits_fake, g["gan_128.logits_fake_d"], 1e-4, "logits_fake_d")
+    close(loss_d.reshape(-1), g["gan_128.loss_d"], 1e-4, "loss_d")
+    named = dict(model.named_parameters())
+    n = 0
+    for k, p in named.items():
+        if "gan_128.dg." + k + ".head" in g.files:
+            gr = p.grad.detach().cpu().contiguous()
+            ref_abs = float(g["gan_128.dg." + k + ".abs"])
+            assert abs(float(gr.double().abs().sum()) - ref_abs) < 2e-3 * ref_abs, f"dgabs.{k}"
+            if "gan_128.dgfull." + k in g.files:
+                close(gr, g["gan_128.dgfull." + k], 2e-3, "dgfull." + k)
+            n += 1
+    assert n == 9
 
 
 # --------------------------------------------------------------------------------------------------------------

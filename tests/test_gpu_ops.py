@@ -392,6 +392,67 @@ def test_vq_against_reference_golden(K, golden_dir, case):
     check(zq[:, :8, :2, :2], torch.from_numpy(g[f"{tag}.entry_slice"]), 1e-6, "entry")
 
 
+VQ_LARGE = [("c16384", 256, None, 16384), ("c8192p", 3, 256, 8192)]
+
+
+@pytest.mark.parametrize("case", VQ_LARGE, ids=[c[0] for c in VQ_LARGE])
+def test_vq_at_baseline_sizes_against_reference_golden(K, golden_dir, case):
+    """CosineSimCodebook / VectorQuantize (l2_quantize.py:391-444, 533-596) at the sizes the BASELINE configs name: 16384 codes x
+    8192 tokens (configs[1..2]: batch 32 of 16x16 latents) and 8192 codes x 65536 tokens behind Linear(3,256) (configs[3]: batch
+    16 of 64x64 latents), against the reference's outputs.  Indices must be bit-identical wherever the reference's own top-2 gap
+    exceeds 1e-6; flips inside that band are counted (the reference decides those by fp32 summation order) and must be 0 here."""
+    from models.l2_quantize import VectorQuantize
+    g = np.load(os.path.join(golden_dir, "vq_large.npz"))
+    tag, dim, cdim, C = case
+    shp = tuple(int(v) for v in g[f"{tag}.shape"])
+    vq = VectorQuantize(codebook_size=C, dim=dim, accept_image_fmap=True, use_cosine_sim=True, codebook_dim=cdim,
+                        sync_codebook=False, commitment_weight=1.0)
+    vq.load_state_dict({k: O.det_value("quantizer." + k, tuple(v.shape)) for k, v in vq.state_dict().items()}, strict=True)
+    vq.to(dev()).train()
+    n = int(np.prod(shp))
+    z = (1.5 * (2 * O._hash_uniform(n, int(g[f"{tag}.zseed"])).reshape(shp) - 1)).float().to(dev()).requires_grad_(True)
+    gq = rnd(shp, 8).to(dev())
+    q, ind, loss = vq(z)
+    ((q * gq).sum() + 3.0 * loss.sum()).backward()
+    ref_ind, gap = g[f"{tag}.ind"].astype(np.int64), g[f"{tag}.gap"]
+    got = ind.cpu().numpy()
+    mism = got != ref_ind
+    assert not (mism & (gap > 1e-6)).any(), "index mismatch outside flagged near-ties"
+    print(f"\n[vq {tag}] tokens {got.size}, reference gaps < 1e-6: {int((gap < 1e-6).sum())}, flips: {int(mism.sum())}")
+    assert mism.sum() == 0, f"{mism.sum()} near-tie index flips (gaps {gap[mism]})"
+    check(loss, torch.from_numpy(g[f"{tag}.loss"]), 1e-5, "loss")
+    check(q[:, :8, :2, :2], torch.from_numpy(g[f"{tag}.q_slice"]), 1e-6, "q")
+    assert abs(float(q.double().abs().sum()) - float(g[f"{tag}.q_abs"])) < 1e-6 * float(g[f"{tag}.q_abs"])
+    check(z.grad[:, :8, :2, :2], torch.from_numpy(g[f"{tag}.gz_slice"]), 1e-5, "gz")
+    assert abs(float(z.grad.double().abs().sum()) - float(g[f"{tag}.gz_abs"])) < 1e-5 * float(g[f"{tag}.gz_abs"])
+    E = vq._codebook.embed
+    check(E[0, :16, :8], torch.from_numpy(g[f"{tag}.embed_slice"]), 1e-6, "embed")
+    assert abs(float(E.double().abs().sum()) - float(g[f"{tag}.embed_abs"])) < 1e-6 * float(g[f"{tag}.embed_abs"])
+    wgt = torch.arange(1, C + 1, dtype=torch.float64, device=E.device).reshape(1, C, 1) / C
+    assert abs(float((E.double().abs() * wgt).sum()) - float(g[f"{tag}.embed_wsum"])) < 1e-6 * float(g[f"{tag}.embed_wsum"])
+    assert np.array_equal(vq._codebook.cluster_size.cpu().numpy(), g[f"{tag}.cluster"]), "cluster sizes (index histogram)"
+    for k, p in vq.named_parameters():
+        check(p.grad, torch.from_numpy(g[f"{tag}.g.{k}"]), 2e-4, "g." + k)
+
+
+def test_vq_nan_token_does_not_fault(K):
+    """A token containing NaN: every comparison of the arg-max is false.  The reference's argmax still returns a valid index and the
+    NaN propagates into the loss; the lookup must do the same instead of gathering through its sentinel index."""
+    d = dev()
+    emb = F.normalize(rnd((64, 32), 53), dim=-1).contiguous().to(d)
+    tok = rnd((16, 32), 54)
+    tok[5, 3] = float("nan")
+    idx, zq, zn, en = K.vq_lookup(tok.to(d), emb)
+    torch.cuda.synchronize()
+    assert 0 <= int(idx.min()) and int(idx.max()) < 64
+    assert torch.isnan(zn[5]).all()
+    ref = (F.normalize(tok, dim=-1) @ F.normalize(emb.cpu(), dim=-1).t()).argmax(-1)     # NaN row -> 0 (first NaN wins)
+    assert int(ref[5]) == 0 and torch.equal(idx.cpu(), ref)
+    bins, esum = K.vq_segment_sum(zn, idx, 64)
+    torch.cuda.synchronize()
+    assert float(bins.sum()) == 16.0
+
+
 def test_vq_exact_ties_pick_first_index(K):
     """duplicate codebook rows -> exact ties -> torch.argmax semantics = lowest index."""
     d = dev()

@@ -167,7 +167,11 @@ def _check_model_case(g, tag, cfg, with_disc=False):
     r["loss_g"].sum().backward()
     out = r["out"]
     p = tag + "."
-    assert np.array_equal(out["indices"].numpy(), g[p + "indices"]), "codebook indices must be bit-exact"
+    ind = out["indices"].numpy().reshape(g[p + "indices"].shape)
+    mism = ind != g[p + "indices"]
+    # bit-exact wherever the reference's own top-2 gap exceeds 1e-6 (inside that band fp32 summation order decides: another host
+    # CPU may legitimately flip such a token); every fixture so far has zero flips on the generating host
+    assert not (mism & (g[p + "index_gap"] > 1e-6)).any(), "codebook indices must be bit-exact outside near-ties"
     xr = out["x_recon"]
     close(xr[:, :, ::max(1, xr.shape[2] // 8), ::max(1, xr.shape[3] // 8)], g[p + "x_recon_slice"], rtol=1e-4, name="x_recon")
     close(xr.double().abs().sum(), g[p + "x_recon_abs"], rtol=1e-5, name="x_recon_abs")
@@ -240,6 +244,64 @@ def test_cfg1_full_256(golden_dir):
             close(P[k].reshape(-1)[:16], g[f"cfg1_256.adam.{k}.head"], rtol=1e-6, name="adam." + k)
 
 
+FULL_CFGS = {
+    # BASELINE configs[1] wiring at its codebook size (batch 2 of the 32)
+    "cfg2_256": dict(codebook_size=16384, variant="gauss_resblock", kernel_size=9),
+    # BASELINE configs[3] model at full resolution (batch 1 of the 16): L=4096 attention, 9-tap blurs, 8192 codes x 4096 tokens
+    "f4_256": dict(codebook_size=8192, n_embed=3, ch_mult=(1, 2, 4), attn_resolutions=(), codebook_dim=256, kernel_size=9,
+                   variant="same_conv_gauss", num_groups=3),
+}
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("tag", list(FULL_CFGS))
+def test_full_size_cases(golden_dir, tag):
+    """One full-size reference step at the sizes that distinguish BASELINE configs[1] (codebook 16384) and configs[3] (f=4 at
+    256x256, k=9, codebook 8192): losses, reconstruction, indices, gradients, post-Adam parameters."""
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    cfg = O.OracleConfig(**FULL_CFGS[tag])
+    P, r = _check_model_case(g, tag, cfg, with_disc=True)
+    close(r["out"]["logits_fake"].double().abs().sum(), g[tag + ".logits_fake_abs"], rtol=1e-5, name="logits_fake")
+    B = int(g[tag + ".shape"][0])
+    with torch.no_grad():
+        for k in ("encoder.conv_in.weight", "decoder.final.2.weight", "encoder.sigmas", "decoder.sigmas", "sigmas"):
+            if f"{tag}.adam.{k}.head" in g.files:
+                m = torch.zeros_like(P[k]); v = torch.zeros_like(P[k])
+                O.adam_update(P[k], P[k].grad, m, v, 1, 2.0e-7 if k == "sigmas" else 4.5e-6 * B, (0.5, 0.9), 1e-8)
+                close(P[k].reshape(-1)[:16], g[f"{tag}.adam.{k}.head"], rtol=1e-6, name="adam." + k)
+
+
+VQ_LARGE = {"c16384": (256, None, 16384), "c8192p": (3, 256, 8192)}
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("tag", list(VQ_LARGE))
+def test_vq_at_baseline_sizes(golden_dir, tag):
+    """The quantizer at 16384 codes x 8192 tokens (configs[1..2]) and 8192 codes x 65536 tokens behind Linear(3,256) (configs[3])."""
+    g = np.load(os.path.join(golden_dir, "vq_large.npz"))
+    dim, cdim, C = VQ_LARGE[tag]
+    shp = tuple(int(v) for v in g[f"{tag}.shape"])
+    cfg = O.OracleConfig(codebook_size=C, n_embed=dim, codebook_dim=cdim, commitment_weight=1.0)
+    shapes = {k: s for k, s in O.param_shapes(cfg).items() if k.startswith("quantizer.")}
+    P = leafify({k: O.det_value(k, s) for k, s in shapes.items()})
+    z = (1.5 * (2 * O._hash_uniform(int(np.prod(shp)), int(g[f"{tag}.zseed"])).reshape(shp) - 1)).float().requires_grad_(True)
+    q, ind, loss, aux = O.vector_quantize_forward(P, z, cfg, training=True)
+    gq = (2 * O._hash_uniform(q.numel(), 8).reshape(q.shape) - 1).float()
+    ((q * gq).sum() + 3.0 * loss.sum()).backward()
+    mism = ind.numpy() != g[f"{tag}.ind"]
+    assert not (mism & (g[f"{tag}.gap"] > 1e-6)).any(), "index mismatch outside near-ties"
+    close(loss, g[f"{tag}.loss"], 1e-6, "loss")
+    close(q[:, :8, :2, :2], g[f"{tag}.q_slice"], 1e-6, "q")
+    close(q.double().abs().sum(), g[f"{tag}.q_abs"], 1e-6, "q_abs")
+    close(z.grad.double().abs().sum(), g[f"{tag}.gz_abs"], 1e-5, "gz_abs")
+    E = P["quantizer._codebook.embed"]
+    close(E.double().abs().sum(), g[f"{tag}.embed_abs"], 1e-6, "embed_abs")
+    wgt = torch.arange(1, C + 1, dtype=torch.float64).reshape(1, C, 1) / C
+    close((E.double().abs() * wgt).sum(), g[f"{tag}.embed_wsum"], 1e-6, "embed_wsum")
+    if not mism.any():
+        assert np.array_equal(P["quantizer._codebook.cluster_size"].numpy(), g[f"{tag}.cluster"])
+
+
 GAN_CFG = dict(codebook_size=512, variant="same_conv_gauss", kernel_size=9, num_groups=32)
 
 
@@ -297,6 +359,32 @@ def test_gan_iteration(golden_dir):
     assert np.array_equal(r["out"]["indices"].numpy(), g["gan_128.indices"])
     r["logits_fake"] = r["out"]["logits_fake"]
     check_gan_golden(g, r, tr.P, lr)
+
+
+def test_gan_stage1_discriminator_alone(golden_dir):
+    """Stage 1 without the chaotic generator step in front of it: the discriminator on (x, the reference's own stage-1
+    reconstruction stored in the fixture) -- hinge_d, logits and every discriminator gradient against the reference, tight."""
+    g = np.load(os.path.join(golden_dir, "gan_128.npz"))
+    B, H, W, seed = [int(v) for v in g["gan_128.shape"]]
+    cfg = O.OracleConfig(**GAN_CFG)
+    P = leafify({k: O.det_value(k, shp) for k, shp in O.param_shapes(cfg, with_disc=True).items() if k.startswith("discriminator.")})
+    x = O.det_input(B, H, W, seed)
+    lr_ = O.discriminator_forward(P, x, True)
+    lf_ = O.discriminator_forward(P, T(g["gan_128.x_recon_d"]), True)
+    loss_d = O.hinge_d_loss(lr_, lf_)
+    loss_d.backward()
+    close(lr_, g["gan_128.logits_real"], 1e-5, "logits_real")
+    close(lf_, g["gan_128.logits_fake_d"], 1e-5, "logits_fake_d")
+    close(loss_d.reshape(-1), g["gan_128.loss_d"], 1e-5, "loss_d")
+    n = 0
+    for k in P:
+        if "gan_128.dg." + k + ".head" in g.files:
+            close(P[k].grad.reshape(-1)[:16], g["gan_128.dg." + k + ".head"], 1e-4, "dg." + k)
+            close(P[k].grad.double().abs().sum(), g["gan_128.dg." + k + ".abs"], 1e-4, "dgabs." + k)
+            n += 1
+        if "gan_128.dgfull." + k in g.files:
+            close(P[k].grad, g["gan_128.dgfull." + k], 1e-4, "dgfull." + k)
+    assert n == 9
 
 
 # --------------------------------------------------------------------------------------------
