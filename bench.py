@@ -7,45 +7,57 @@ synthetic 256x256x3 batches of 32 images per GPU, fp32, random-init weights.  A 
 step (forward incl. the always-executed discriminator forward, all losses, backward, [RCCL gradient all-reduce],
 fused Adam) with the batch already resident in HBM.
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU; it starts N ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`, one per GPU, RCCL over xGMI), relays rank 0's JSON line
+and exits with the children's status.  Under torchrun (WORLD_SIZE set) it is one of the ranks.
+
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement"):
   value      whole-job images/s  (sum over ranks / max-over-ranks time, barrier + synchronize on both sides)
-  roofline   dominant kernel = the conv3x3_halo_sp_kernel<xform, planes, kernel size> instantiation with the largest time share (3x3
-             forward / data-gradient conv on the split-precision matrix path): algorithmic FLOPs (2*M*Cout*KH*KW*Cin per
-             launch) / launch durations measured with HIP events on the launch stream inside the timed region;
+  roofline   the kernel with the largest time share of the timed region among the matrix-bound kernels (conv forward, data
+             gradient AND weight gradient families): algorithmic FLOPs (2*M*Cout*KH*KW*Cin per launch) / launch durations, both
+             recorded by the library's launch profiler (csrc/prof.hip): two HIP events around every such launch, on the stream the
+             kernel is launched on (the weight gradients run on a second stream), inside the timed region;
              peak = 2500 TFLOP/s dense 16-bit MFMA / products per fp32 multiply-add (3 with two fp16 planes, 6 with three bf16)
+  kernel_table  every kernel of one extra (untimed) step, same profiler at "all launches": per-kernel time, achieved TB/s or TFLOP/s
   cpu_baseline  the CPU oracle (kind "port": pure-PyTorch restatement of the reference step, oracle/) timed on this
              host's cores on a bounded sample of the same workload (rank 0, N=1 only)
 """
 import argparse
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (os.path.join(ROOT, "fa-vae_amd"), os.path.join(ROOT, "oracle")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+PKG = os.path.join(ROOT, "fa-vae_amd")
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)                # the product package only; oracle/ is added by cpu_baseline() alone
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
 PEAK_16BIT_MFMA_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
-SPLIT_PRODUCTS = {1: 1, 2: 3, 3: 6}        # 16-bit MFMA products issued per fp32 multiply-add: planes -> products (conv_split.h)
+PEAK_HBM_TBS = 8.0                    # HBM3E (MI355X_MICROARCH.md)
+SPLIT_PRODUCTS = {0: None, 1: 1, 2: 3, 3: 6}   # 16-bit MFMA products per fp32 multiply-add: planes -> products (conv_split.h)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
 
-
-# name -> (description, codebook, n_embed, model kwargs, oracle config kwargs, default batch per GPU)
+# name -> (description, codebook, n_embed, model kwargs, oracle config kwargs, default batch per GPU,
+#          algorithmic TFLOP and GB per image of the stage-0 step (SURVEY 8d; None where the survey gives none))
 CONFIGS = {
     "celeba_f16": ("BASELINE configs[1]: FA-VAE f=16 CelebA-HQ config, codebook %d, embed_dim 256, residual FCM + non-pairwise DSL "
                    "(k=9, sigma0=3)", 16384, 256,
                    dict(ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_gauss_resblock=True),
-                   dict(variant="gauss_resblock"), 32),
+                   dict(variant="gauss_resblock"), 32, (1.316, 8.1)),
     "imagenet_f4": ("BASELINE configs[3]: FA-VAE f=4 ImageNet config, codebook %d, embed_dim 3 projected to codebook_dim 256, "
                     "ch_mult (1,2,4), conv FCM with one sigma per pair (use_same_conv_gauss, num_groups 3, k=9, sigma0=3)", 8192, 3,
                     dict(ch_mult=(1, 2, 4), attn_resolutions=[], codebook_dim=256, use_same_conv_gauss=True, num_groups=3),
-                    dict(n_embed=3, ch_mult=(1, 2, 4), attn_resolutions=(), codebook_dim=256, variant="same_conv_gauss", num_groups=3), 16),
+                    dict(n_embed=3, ch_mult=(1, 2, 4), attn_resolutions=(), codebook_dim=256, variant="same_conv_gauss", num_groups=3), 16,
+                    (3.436, 11.3)),
     "ffhq_f16": ("model of BASELINE configs[4]: FA-VAE f=16 FFHQ config, codebook %d, embed_dim 256, conv FCM with one sigma per pair "
                  "(use_same_conv_gauss, num_groups 32, k=9, sigma0=3), fp32", 2048, 256,
                  dict(ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_same_conv_gauss=True, num_groups=32),
-                 dict(variant="same_conv_gauss", num_groups=32), 32),
+                 dict(variant="same_conv_gauss", num_groups=32), 32, None),
 }
 
 
@@ -58,6 +70,8 @@ def parse():
     ap.add_argument("--codebook", type=int, default=None, help="codebook size (default: the config's)")
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extra passes (single-stream rates, all-kernel table, with-LPIPS figure)")
     ap.add_argument("--gan", action="store_true",
                     help="also train the discriminator (BASELINE config-5 wiring: hinge terms, adaptive weight, stage 1; perceptual "
                          "term off) -- not the headline workload, reported under config.workload")
@@ -72,64 +86,116 @@ def parse():
                          "mixed-precision mode asked for by BASELINE configs[4] (conv operands rounded to ONE scaled fp16 plane, fp32 "
                          "accumulation, everything else fp32; like the reference under accelerate mixed precision) -- not the "
                          "headline workload, reported as dtype f16 and under config.workload")
-    ap.add_argument("--cpu-batch", type=int, default=8, help="images in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-batch", type=int, default=8, help="images per step of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="timed steps of the bounded CPU-baseline sample")
     args = ap.parse_args()
-    desc, cb, n_embed, mk, ok, batch = CONFIGS[args.config]
+    desc, cb, n_embed, mk, ok, batch, _ = CONFIGS[args.config]
     args.codebook = args.codebook or cb
     args.batch = args.batch or batch
     return args
 
 
-class ConvEventHook:
-    """Brackets every launch of the implicit-GEMM forward/data-gradient kernel family with HIP events (torch.cuda.Event
-    records on the current stream, which is the stream favae_hip launches on).  Launches are keyed by the template
-    instantiation they dispatch to, so each key corresponds to exactly one kernel name in a rocprofv3 trace."""
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks (this process never initialises a GPU)
+# ------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n):
+    import torch                                    # device_count() does not initialise the GPU on this image
+    have = torch.cuda.device_count()
+    if have < n:
+        print("[bench] --gpus %d but only %d GPU(s) are visible on this node" % (n, have), file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout:
+        if ln.startswith("{"):
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if rc != 0 or line is None:
+        print("[bench] the %d-rank launch failed (exit code %s)" % (n, rc), file=sys.stderr)
+        return rc or 1
+    print(line, flush=True)
+    return 0
 
-    def __init__(self, torch):
-        self.torch = torch
-        self.recs = {}          # kernel name -> list of (start, end, flops)
-        self.enabled = False
 
-    @staticmethod
-    def kernel_name(name, d, has_affine, planes):
-        """kernel instantiation a favae_conv_fwd_split call dispatches to (mirrors conv_fwd_impl in csrc/conv.hip)"""
-        if name != "favae_conv_fwd_split" or d.Cin % 16 or d.Cout <= 64:
-            return None                                    # narrow tiles / fp32-MFMA fallbacks: not the dominant family
-        xf = 0 if not has_affine else {0: 1, 1: 2, 2: 3, 3: 3}[d.act]
-        halo = (d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1 and d.gather == 0 and d.Hout == d.Hin and
-                d.Wout == d.Win and d.Hin % 8 == 0 and d.Win % 16 == 0)
-        if halo and d.lat_step != 2 and d.pad_dw == 0:
-            return "conv3x3_halo_sp_kernel<%d, %d, 3>" % (xf, planes)
-        halo2 = (d.KH == 2 and d.KW == 2 and d.stride == 1 and d.gather == 0 and d.lat_step == 2 and d.Hout == d.Hin and
-                 d.Wout == d.Win and d.Hin % 8 == 0 and d.Win % 16 == 0 and xf == 0 and os.environ.get("FAVAE_CONV_HALO2", "1") != "0")
-        if halo2:
-            return "conv3x3_halo_sp_kernel<0, %d, 2>" % planes      # 2x2 phase convs (Upsample, Downsample data gradient)
-        return "conv_fwd_sp_kernel<%d, %d, true, 8, %d>" % (d.gather, xf, planes)
+# ------------------------------------------------------------------------------------------------------------------
+# launch profiler of the library (csrc/prof.hip)
+# ------------------------------------------------------------------------------------------------------------------
+class Prof:
+    """level 1: launches that carry >= 1 GFLOP of algorithmic work (the matrix-bound conv kernels), 2: every launch."""
 
-    def __call__(self, name, args, launch):
-        if not self.enabled or name != "favae_conv_fwd_split":
-            return launch()
-        d = args[0]._obj                                   # (desc, x, wsplit, planes, x_absmax, bias, resid, scale, shift, y)
-        kn = self.kernel_name(name, d, args[7] is not None, args[3])
-        if kn is None:
-            return launch()
-        flops = 2.0 * d.N * d.Hout * d.Wout * d.Cout * d.KH * d.KW * d.Cin
-        s = self.torch.cuda.Event(enable_timing=True)
-        e = self.torch.cuda.Event(enable_timing=True)
-        s.record()
-        launch()
-        e.record()
-        self.recs.setdefault(kn, []).append((s, e, flops))
+    def __init__(self, favae_hip):
+        self.lib = favae_hip.load()                  # argtypes / restypes come from favae_hip.SIGNATURES
 
-    def summary(self):
+    def start(self, level):
+        self.lib.favae_prof_reset()
+        self.lib.favae_prof_enable(level)
+
+    def stop(self):
+        """-> {kernel name: dict(launches, total_us, min_us, max_us, flops, bytes)} of everything recorded since start()"""
+        self.lib.favae_prof_enable(0)
+        n = self.lib.favae_prof_report(None, 0)
+        buf = ctypes.create_string_buffer(int(n) + 16)
+        self.lib.favae_prof_report(buf, len(buf))
+        self.lib.favae_prof_reset()
         out = {}
-        for kn, recs in self.recs.items():
-            ms = [s.elapsed_time(e) for s, e, _ in recs]
-            fl = [f for _, _, f in recs]
-            tot_ms, tot_fl = sum(ms), sum(fl)
-            out[kn] = {"launches": len(ms), "avg_us": 1e3 * tot_ms / len(ms), "avg_gflop": 1e-9 * tot_fl / len(ms),
-                       "tflops": 1e-12 * tot_fl / (1e-3 * tot_ms), "total_ms": tot_ms}
+        for ln in buf.value.decode().splitlines():
+            name, cnt, tot, mn, mx, fl, by = ln.split("\t")
+            out[name] = dict(launches=int(cnt), total_us=float(tot), min_us=float(mn), max_us=float(mx), flops=float(fl),
+                             bytes=float(by))
         return out
+
+
+def kernel_planes(name):
+    """operand planes of a split-precision conv kernel from its instantiation name (None: not a split kernel)"""
+    if not name.endswith(">"):
+        return None
+    args = [a.strip() for a in name[name.index("<") + 1:-1].split(",")]
+    try:
+        if name.startswith("conv3x3_halo_sp_kernel") or name.startswith("conv_wgrad_row3_sp_kernel"):
+            return int(args[1])
+        if name.startswith("conv_fwd_sp_kernel") or name.startswith("conv_wgrad_sp_kernel"):
+            return int(args[-1])
+    except ValueError:
+        pass
+    return None
+
+
+def roofline_entry(name, r, step_us, traffic, excl=None):
+    planes = kernel_planes(name)
+    avg_us = r["total_us"] / r["launches"]
+    e = {"kernel": name, "launches": r["launches"], "avg_launch_us": avg_us, "share_of_step_time": r["total_us"] / step_us}
+    if r["flops"] > 0 and not name.startswith("thin_"):          # thin_*: 3-channel ends, vector-ALU kernels priced against HBM
+        ach = 1e-12 * r["flops"] / (1e-6 * r["total_us"])
+        peak = PEAK_16BIT_MFMA_TFLOPS / SPLIT_PRODUCTS[planes] if planes else PEAK_F32_MFMA_TFLOPS
+        e.update({"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                  "vs_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
+                  "avg_algorithmic_gflop_per_launch": 1e-9 * r["flops"] / r["launches"]})
+    elif r["bytes"] > 0:
+        ach = 1e-12 * r["bytes"] / (1e-6 * r["total_us"])
+        e.update({"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_TBS, "unit": "TB/s", "frac": ach / PEAK_HBM_TBS})
+    if r["bytes"] > 0:
+        e["algorithmic_bytes_per_launch"] = r["bytes"] / r["launches"]
+    t = (traffic.get(name) or traffic.get(name.split("(")[0]) or {}).get("hbm_bytes_per_launch_corrected")
+    e["traffic"] = t
+    if t and r["bytes"] > 0:
+        e["traffic_over_algorithmic"] = t / (r["bytes"] / r["launches"])
+    if excl and name in excl and "achieved" in e:
+        x = excl[name]
+        num = x["flops"] if r["flops"] > 0 else x["bytes"]
+        e["achieved_single_stream"] = 1e-12 * num / (1e-6 * x["total_us"])
+        e["frac_single_stream"] = e["achieved_single_stream"] / e["peak"]
+        e["avg_launch_us_single_stream"] = x["total_us"] / x["launches"]
+    return e
 
 
 def usable_cores(torch):
@@ -148,6 +214,8 @@ def usable_cores(torch):
 
 
 def cpu_baseline(args, torch):
+    """The oracle as the checker-side CPU port of the same step (the only place bench.py touches oracle/)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import favae_oracle as O
     ncores = usable_cores(torch)
     torch.set_num_threads(ncores)
@@ -155,17 +223,24 @@ def cpu_baseline(args, torch):
     sc = O.StepConfig(lr=4.5e-6 * args.batch, with_disc_forward=True)
     tr = O.OracleTrainer(cfg, sc)
     B = args.cpu_batch
-    tr.step(O.det_input(1, args.res, args.res, 1234))      # untimed batch-1 step: thread-pool / allocator warm-up
-    t0 = time.perf_counter()
-    tr.step(O.det_input(B, args.res, args.res, 1235))
-    dt = time.perf_counter() - t0
-    return {"value": B / dt, "unit": "images/s", "cores": ncores, "kind": "port",
-            "sample": f"1 timed training step (after 1 warm-up step) of the same {args.config} config at batch {B}, "
+    tr.step(O.det_input(min(B, 2), args.res, args.res, 1234))      # untimed warm-up step: thread pool, allocator, oneDNN primitives
+    dts = []
+    for i in range(max(1, args.cpu_steps)):
+        t0 = time.perf_counter()
+        tr.step(O.det_input(B, args.res, args.res, 1235 + i))
+        dts.append(time.perf_counter() - t0)
+    dt = sum(dts)
+    return {"value": B * len(dts) / dt, "unit": "images/s", "cores": ncores, "kind": "port",
+            "per_step_images_per_s": [B / d for d in dts],
+            "sample": f"{len(dts)} timed training steps (after 1 warm-up step) of the same {args.config} config at batch {B} "
+                      f"(the GPU leg runs batch {args.batch}: 288 GB of HBM hold it, this host's cores would need minutes per step), "
                       f"oracle/favae_oracle.py on torch {torch.__version__} CPU, {dt:.1f} s"}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     import torch
     import torch.distributed as dist
 
@@ -181,79 +256,109 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")           # RCCL on ROCm
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))           # RCCL on ROCm
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     import favae_hip
+    from favae_hip import ops as K
     from favae_step import TrainStep
-    from utils import synthetic_batch              # the GPU leg never touches oracle/ (only cpu_baseline() below does)
+    from utils import synthetic_batch              # the GPU leg never touches oracle/ (only cpu_baseline() does)
     from models.vqgan_fcm import VQGANFCM
 
     favae_hip.load()
     if args.precision == "fp16":
-        from favae_hip import ops as _Kp
-        _Kp.set_conv_mode("h1")
-    torch.manual_seed(0)                           # favae_scripts/train_favae.py:235
-    desc, _, n_embed, mk, _, _ = CONFIGS[args.config]
-    model = VQGANFCM(args.codebook, n_embed, use_cosine_sim=True, use_l2_quantizer=True, sync_codebook=use_dist,
-                     commitment_weight=1.0, kernel_size=9, dsl_init_sigma=3.0, device=dev, **mk).to(dev)
-    lr = 4.5e-6 * args.batch * world               # train_favae.py:250-251
-    lpips = None
-    if args.lpips:
-        from losses.lpips import LPIPS
-        lpips = LPIPS(pretrained=False)            # random-init VGG16 / lin weights (vgg16_lpips.pt is not available offline)
-        lpips = lpips.to(dev).eval()               # train_favae.py:308
-    ts = TrainStep(model, lr=lr, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, distributed=use_dist, train_disc=args.gan,
-                   lpips=lpips, perceptual_weight=1.0)
-    xs = [synthetic_batch(args.batch, args.res, args.res, 1234 + 17 * rank + i).to(dev) for i in range(2)]
+        K.set_conv_mode("h1")
+    torch.manual_seed(0)                           # favae_scripts/train_favae.py:235 (ranks are synchronised by TrainStep's broadcast)
+    desc, _, n_embed, mk, _, _, work = CONFIGS[args.config]
 
-    hook = ConvEventHook(torch)
-    favae_hip.set_call_hook(hook)
+    def build(with_lpips):
+        model = VQGANFCM(args.codebook, n_embed, use_cosine_sim=True, use_l2_quantizer=True, sync_codebook=use_dist,
+                         commitment_weight=1.0, kernel_size=9, dsl_init_sigma=3.0, device=dev, **mk).to(dev)
+        lpips = None
+        if with_lpips:
+            from losses.lpips import LPIPS
+            lpips = LPIPS(pretrained=False).to(dev).eval()        # random-init VGG16 / lin weights; .eval(): train_favae.py:308
+        lr = 4.5e-6 * args.batch * world               # train_favae.py:250-251
+        return TrainStep(model, lr=lr, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, distributed=use_dist,
+                         train_disc=args.gan, lpips=lpips, perceptual_weight=1.0)
+    ts = build(args.lpips)
+    exchange_desc = ("overlapped bucketed RCCL all-reduce (%d segments, started from gradient marks inside backward)" % len(ts.exchange.segments)
+                     if ts.exchange is not None else ("one RCCL all-reduce after backward" if use_dist else "none (1 GPU)"))
+    xs = [synthetic_batch(args.batch, args.res, args.res, 1234 + 17 * rank + i).to(dev) for i in range(2)]
+    prof = Prof(favae_hip)
 
     def sync():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(step_obj, steps, level):
+        sync()
+        prof.start(level)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            o = step_obj.step(xs[i % 2])
+        sync()
+        t = time.perf_counter() - t0
+        return t, prof.stop(), o
+
     for i in range(args.warmup):
         ts.step(xs[i % 2])
-    sync()
-    hook.enabled = True
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = ts.step(xs[i % 2])
-    sync()
-    dt = time.perf_counter() - t0
-    hook.enabled = False
-    # Untimed extra: the same launches with the second HIP stream off.  In the timed region the weight-gradient kernels run
-    # concurrently with the data-gradient kernels of the next layer, so the per-launch durations of the latter include time
-    # in which they share the CUs; the stand-alone rate of the kernel is reported next to the in-step figure.
-    from favae_hip import ops as _K                        # (every rank: the steps contain the gradient all-reduce)
-    side_on = _K._SIDE["on"]
-    _K._SIDE["on"] = False
-    timed_recs, hook.recs = hook.recs, {}
-    hook.enabled = True
-    for i in range(2):
-        ts.step(xs[i % 2])
-    sync()
-    hook.enabled = False
-    excl = hook.summary()
-    hook.recs = timed_recs
-    _K._SIDE["on"] = side_on
+    dt_local, timed_recs, out = timed(ts, args.steps, 1)
+    dt = dt_local
+    per_rank = [args.batch * args.steps / dt_local]
     if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(allt, t)
+        per_rank = [args.batch * args.steps / float(v.item()) for v in allt]
+        dt = max(float(v.item()) for v in allt)
     loss = float(out["loss_g"].reshape(-1)[0])
 
+    # ---- untimed extras (every rank: the steps contain collectives) ------------------------------------------------
+    extras = {}
+    if not args.no_extras:
+        # (a) profiler overhead: the same steps with the profiler off
+        t_off, _, _ = timed(ts, 2, 0)
+        extras["ms_per_step_profiler_off"] = 1e3 * t_off / 2
+        # (b) every launch of two steps (two-stream, as in the timed region)
+        t_all, all_recs, _ = timed(ts, 2, 2)
+        # (c) the same with the weight-gradient stream off: exclusive kernel durations
+        side_on = K._SIDE["on"]
+        K._SIDE["on"] = False
+        ts.step(xs[0])
+        t_excl, excl_recs, _ = timed(ts, 2, 2)
+        K._SIDE["on"] = side_on
+        extras.update({"all": all_recs, "t_all": t_all, "excl": excl_recs, "t_excl": t_excl})
+        # (d) the reference's unconditional perceptual term (train_favae.py:77-79) on top of the headline workload
+        if not args.lpips and args.config == "celeba_f16" and not args.gan:
+            del ts
+            torch.cuda.empty_cache()
+            ts_lp = build(True)
+            ts_lp.step(xs[0])
+            n_lp = min(args.steps, 4)
+            t_lp, _, _ = timed(ts_lp, n_lp, 0)
+            if use_dist:
+                t = torch.tensor([t_lp], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                t_lp = float(t.item())
+            extras["with_lpips"] = {"value": args.batch * world * n_lp / t_lp, "unit": "images/s", "ms_per_step": 1e3 * t_lp / n_lp,
+                                    "steps": n_lp,
+                                    "note": "same workload + perceptual_weight * lpips(x, x_recon).mean() every step, as the reference's "
+                                            "train() computes it (train_favae.py:77-79); VGG16 / lin weights random-init (vgg16_lpips.pt "
+                                            "is not available offline): timing only"}
+
     if rank == 0:
-        conv = hook.summary()
+        step_us = 1e6 * dt
         res = {
             "metric": "images/sec (256x256, f=16 FA-VAE train step)" if args.config == "celeba_f16" else "images/sec (%dx%d FA-VAE train step, config %s)" % (args.res, args.res, args.config),
             "value": args.batch * world * args.steps / dt,
             "unit": "images/s",
             "n_gpus": world,
+            "rccl_world_size": dist.get_world_size() if use_dist else 1,
+            "per_rank_images_per_s": per_rank,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
@@ -263,46 +368,63 @@ def main():
             "dtype": "f32" if args.precision == "fp32" else "f16",
             "data": "synthetic",
             "config": {"workload": (desc % args.codebook) + ", FFL 1.0 + DSL 0.01, %dx%d, batch %d per GPU, stage-0 step "
-                                   "(LPIPS/disc training off, disc forward on)" % (args.res, args.res, args.batch)
+                                   "(no LPIPS term, no discriminator training; discriminator forward on)" % (args.res, args.res, args.batch)
                                    + (" + discriminator training (hinge, adaptive weight, stage 1)" if args.gan else "")
                                    + (" + LPIPS perceptual term (random-init weights: timing only)" if args.lpips else "")
                                    + (" -- MIXED PRECISION: conv operands in one scaled fp16 plane (FAVAE_CONV_MODE=h1), fp32 "
                                       "accumulation; not fp32-grade, not the headline" if args.precision == "fp16" else ""),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss_g_last": loss},
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss_g_last": loss,
+                       "gradient_exchange": exchange_desc},
         }
-        if conv:
-            def entry(kn, c):
-                planes = int(kn.rstrip(">").split(",")[1 if kn.startswith("conv3x3_halo") else -1])
-                peak = PEAK_16BIT_MFMA_TFLOPS / SPLIT_PRODUCTS[planes]
-                e = excl.get(kn)
-                return {"bound": "mfma", "achieved": c["tflops"], "peak": peak, "unit": "TFLOP/s",
-                        "frac": c["tflops"] / peak, "vs_fp32_mfma_peak": c["tflops"] / PEAK_F32_MFMA_TFLOPS,
-                        "achieved_single_stream": e["tflops"] if e else None,
-                        "frac_single_stream": e["tflops"] / peak if e else None,
-                        "traffic": (traffic.get(kn) or {}).get("hbm_bytes_per_launch_corrected"), "kernel": kn,
-                        "launches": c["launches"], "avg_launch_us": c["avg_us"],
-                        "avg_algorithmic_gflop_per_launch": c["avg_gflop"], "share_of_step_time": c["total_ms"] / (1e3 * dt)}
-            traffic = {}
-            try:                                            # per-launch HBM bytes from the committed PMC passes (profiles/)
-                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-            except Exception:
-                pass
-            ranked = sorted(conv.items(), key=lambda kv: -kv[1]["total_ms"])
-            res["roofline"] = entry(*ranked[0])            # dominant instantiation (largest share of the timed region)
-            res["roofline"]["note"] = ("fp32 3x3 conv on the 16-bit matrix pipe by operand splitting (conv_split.h): planes=2 -> two "
-                                       "scaled fp16 planes, 3 v_mfma_f32_32x32x16_f16 products per fp32 multiply-add, peak = 2500/3 "
-                                       "TFLOP/s; planes=3 -> three bf16 planes, 6 products, peak = 2500/6; achieved = algorithmic "
-                                       "fp32 FLOPs / launch time; template args = <fused input transform (0 plain: data gradients "
-                                       "and un-normalised convs, 2 GroupNorm+SiLU), planes, kernel size (3: the 3x3 convs, 2: 2x2 phase convs)>")
-            res["roofline"]["stream_note"] = ("achieved/frac: launch durations inside the timed region, where weight-gradient kernels "
-                                              "run concurrently on a second HIP stream (data-gradient launches share the CUs with "
-                                              "them); *_single_stream: the same launches in 2 untimed steps with that stream off")
-            res["roofline"]["traffic_note"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the launches of one "
-                                               "step, separate rocprofv3 --pmc passes (gfx950 FETCH_SIZE x2 correction of "
-                                               "MI355X_MICROARCH.md; fabric-side counter, includes Infinity-Cache hits)")
-            res["roofline_others"] = [entry(kn, c) for kn, c in ranked[1:]]
-        if world == 1 and not args.no_cpu_baseline:
-            favae_hip.set_call_hook(None)
+        traffic = {}
+        try:                                            # per-launch HBM bytes from the committed PMC passes (profiles/)
+            traffic = json.load(open(TRAFFIC_FILE))
+        except Exception:
+            pass
+        excl = extras.get("excl")
+        ranked = sorted(timed_recs.items(), key=lambda kv: -kv[1]["total_us"])
+        if ranked:
+            res["roofline"] = roofline_entry(ranked[0][0], ranked[0][1], step_us, traffic, excl)
+            res["roofline"]["note"] = (
+                "dominant kernel of the timed region by total time among all matrix-bound launches (conv forward, data-gradient and "
+                "weight-gradient kernels; the latter run on a second HIP stream). fp32 conv on the 16-bit matrix pipe by operand "
+                "splitting (conv_split.h): planes=2 -> two scaled fp16 planes, 3 v_mfma_f32_32x32x16_f16 products per fp32 "
+                "multiply-add, peak = 2500/3 TFLOP/s; planes=3 -> three bf16 planes, 6 products, peak = 2500/6. achieved = algorithmic "
+                "fp32 FLOPs / launch durations from two HIP events around every launch on its own stream (csrc/prof.hip). "
+                "Template args: halo<input transform (0 plain: data gradients, 2 GroupNorm+SiLU), planes, kernel size>, "
+                "wgrad_row3<input transform, planes>")
+            res["roofline"]["stream_note"] = ("achieved/frac: launch durations inside the timed region, where the main-stream kernels and the "
+                                              "weight-gradient kernels of the second stream share the CUs; *_single_stream: the same "
+                                              "launches in 2 untimed steps with that stream off")
+            res["roofline"]["traffic_note"] = ("traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch averaged over the launches of one "
+                                               "step, separate rocprofv3 --pmc passes (gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md; "
+                                               "fabric-side counter, includes Infinity-Cache hits), from " + os.path.relpath(TRAFFIC_FILE, ROOT))
+            res["roofline_others"] = [roofline_entry(kn, c, step_us, traffic, excl) for kn, c in ranked[1:]]
+        if work is not None and not args.gan and not args.lpips:
+            tf, gb = work
+            a_f = tf * args.batch * args.steps / dt                                  # per GPU
+            a_b = gb * 1e-3 * args.batch * args.steps / dt
+            planes = {"fp32": 2, "fp16": 1}[args.precision]
+            peak = PEAK_16BIT_MFMA_TFLOPS / SPLIT_PRODUCTS[planes]
+            res["roofline_step"] = {"algorithmic_tflop_per_image": tf, "algorithmic_gb_per_image": gb,
+                                    "mfma": {"achieved": a_f, "peak": peak, "unit": "TFLOP/s", "frac": a_f / peak,
+                                             "vs_fp32_mfma_peak": a_f / PEAK_F32_MFMA_TFLOPS},
+                                    "hbm": {"achieved": a_b, "peak": PEAK_HBM_TBS, "unit": "TB/s", "frac": a_b / PEAK_HBM_TBS},
+                                    "note": "whole step per GPU against SURVEY 8(d)'s per-image work (conv + attention + VQ FLOPs; "
+                                            "fused-ideal fp32 bytes); the binding ceiling is the matrix one"}
+        if "all" in extras:
+            res["ms_per_step_profiler_off"] = extras["ms_per_step_profiler_off"]
+            su = 1e6 * extras["t_all"]
+            tab = sorted(extras["all"].items(), key=lambda kv: -kv[1]["total_us"])[:24]
+            res["kernel_table"] = {"note": "every kernel launch of 2 untimed steps (two-stream), sorted by total time; per-launch duration "
+                                           "from HIP events on the launch stream; *_single_stream from 2 more steps with the weight-gradient "
+                                           "stream off (exclusive durations)",
+                                   "ms_per_step": 1e3 * extras["t_all"] / 2,
+                                   "ms_per_step_single_stream": 1e3 * extras["t_excl"] / 2,
+                                   "kernels": [roofline_entry(kn, c, su, traffic, excl) for kn, c in tab]}
+        if "with_lpips" in extras:
+            res["with_lpips"] = extras["with_lpips"]
+        if world == 1 and not use_dist and not args.no_cpu_baseline:
             print("[bench] GPU part done: %.2f images/s; timing the CPU baseline sample..." % res["value"], file=sys.stderr, flush=True)
             res["cpu_baseline"] = cpu_baseline(args, torch)
         print(json.dumps(res), flush=True)

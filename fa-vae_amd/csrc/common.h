@@ -13,18 +13,16 @@
 
 // ---- launch profiler (prof.hip): FAVAE_KLAUNCH == hipLaunchKernelGGL, plus two events on the launch stream when enabled --------
 extern int favae_prof_level_;
-void* favae_prof_begin_(const char* pretty, hipStream_t s);
+void* favae_prof_begin_(const void* host_fn, hipStream_t s);
 void favae_prof_end_(void* rec, hipStream_t s);
 void favae_prof_note_(double flops, double bytes);      // algorithmic work of the NEXT launch of this thread (roofline numerator)
-template <auto K>
-static const char* favae_kname() { return __PRETTY_FUNCTION__; }
 #define FAVAE_PROF_NOTE(flops, bytes)                          \
     do {                                                       \
         if (favae_prof_level_) favae_prof_note_((double)(flops), (double)(bytes)); \
     } while (0)
 #define FAVAE_KLAUNCH(kern, grid, block, shm, s, ...)                                                   \
     do {                                                                                                \
-        void* pr__ = favae_prof_level_ ? favae_prof_begin_(favae_kname<kern>(), (s)) : nullptr;         \
+        void* pr__ = favae_prof_level_ ? favae_prof_begin_((const void*)(kern), (s)) : nullptr;         \
         hipLaunchKernelGGL(kern, grid, block, shm, s, __VA_ARGS__);                                     \
         if (pr__) favae_prof_end_(pr__, (s));                                                           \
     } while (0)

@@ -10,6 +10,8 @@
 #include <map>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
+#include <cxxabi.h>
 
 #include "common.h"
 
@@ -17,7 +19,7 @@ int favae_prof_level_ = 0;
 
 namespace {
 struct Rec {
-    const char* pretty;
+    const void* fn;                 // host-side kernel function: its device symbol is the name rocprofv3 reports
     hipEvent_t a, b;
     double flops, bytes;
 };
@@ -38,15 +40,25 @@ hipEvent_t get_event() {
     return e;
 }
 
-// "const char *favae_kname() [K = &(anonymous namespace)::conv_wgrad_row3_sp_kernel<2, 2>]" -> "conv_wgrad_row3_sp_kernel<2, 2>"
-std::string short_name(const char* pretty) {
-    std::string s(pretty);
-    size_t p = s.find("K = ");
-    if (p != std::string::npos) s = s.substr(p + 4);
-    if (!s.empty() && s.back() == ']') s.pop_back();
-    if (!s.empty() && s[0] == '&') s = s.substr(1);
+// device symbol of the kernel, demangled and cut down to "name<template args>" -- the form tools/rocpd_stats.py gives the kernel
+// names of a rocprofv3 trace: "void (anonymous namespace)::conv_wgrad_row3_sp_kernel<2, 2>((anonymous namespace)::WgradArgs)"
+// -> "conv_wgrad_row3_sp_kernel<2, 2>"
+std::string short_name(const void* fn) {
+    const char* mangled = hipKernelNameRefByPtr(fn, nullptr);
+    if (!mangled) return "?";
+    int st = 0;
+    char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &st);
+    std::string s(st == 0 && dem ? dem : mangled);
+    free(dem);
     const char* anon = "(anonymous namespace)::";
     for (size_t q; (q = s.find(anon)) != std::string::npos;) s.erase(q, strlen(anon));
+    if (s.compare(0, 5, "void ") == 0) s = s.substr(5);
+    int depth = 0;
+    for (size_t i = 0; i < s.size(); ++i) {
+        if (s[i] == '<') ++depth;
+        else if (s[i] == '>') --depth;
+        else if (s[i] == '(' && depth == 0) { s.resize(i); break; }
+    }
     return s;
 }
 }  // namespace
@@ -57,13 +69,13 @@ void favae_prof_note_(double flops, double bytes) {
     t_note = true;
 }
 
-void* favae_prof_begin_(const char* pretty, hipStream_t s) {
+void* favae_prof_begin_(const void* host_fn, hipStream_t s) {
     const bool noted = t_note;
     const double fl = noted ? t_flops : 0.0, by = noted ? t_bytes : 0.0;
     t_note = false;
-    if (favae_prof_level_ < 2 && !noted) return nullptr;             // level 1: only launches that carry a work annotation
+    if (favae_prof_level_ < 2 && !(noted && fl >= 1e9)) return nullptr;   // level 1: the matrix-bound launches (>= 1 GFLOP) only
     std::lock_guard<std::mutex> lk(g_mu);
-    Rec r{pretty, get_event(), get_event(), fl, by};
+    Rec r{host_fn, get_event(), get_event(), fl, by};
     if (!r.a || !r.b) return nullptr;
     (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);
@@ -97,11 +109,14 @@ extern "C" int64_t favae_prof_report(char* buf, int64_t cap) {
     std::lock_guard<std::mutex> lk(g_mu);
     struct Agg { long n = 0; double us = 0, mn = 1e30, mx = 0, flops = 0, bytes = 0; };
     std::map<std::string, Agg> agg;
+    std::map<const void*, std::string> names;
     for (auto& r : g_recs) {
         if (hipEventSynchronize(r.b) != hipSuccess) continue;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
-        Agg& a = agg[short_name(r.pretty)];
+        auto it = names.find(r.fn);
+        if (it == names.end()) it = names.emplace(r.fn, short_name(r.fn)).first;
+        Agg& a = agg[it->second];
         const double us = 1e3 * ms;
         a.n += 1; a.us += us; a.flops += r.flops; a.bytes += r.bytes;
         if (us < a.mn) a.mn = us;

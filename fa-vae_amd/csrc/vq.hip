@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* x, float*
     float s = 0.f;
     for (int i = lane; i < d; i += 64) s = fmaf(p[i], p[i], s);
     s = wave_sum(s);
-    const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);                 // F.normalize eps
+    const float nrm = sqrtf(s);
+    const float inv = 1.0f / (nrm < 1e-12f ? 1e-12f : nrm);           // F.normalize: x / norm.clamp_min(eps); a NaN norm stays NaN
     float* o = out + (size_t)row * d;
     for (int i = lane; i < d; i += 64) o[i] = p[i] * inv;
 }
@@ -375,14 +376,15 @@ __global__ __launch_bounds__(256) void vq_segment_sum_kernel(const float* zn, co
 }
 
 __global__ __launch_bounds__(256) void vq_ema_kernel(float* embed, float* cluster, const float* en, const float* bins,
-                                                     const float* esum, int C, int d, float decay) {
+                                                     const float* esum, int C, int d, float decay, float alpha) {
     const int code = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (code >= C) return;
     const float b = bins[code];
-    if (lane == 0) cluster[code] = cluster[code] * decay + (1.f - decay) * b;
+    // mul_(decay) rounds, then add_(new, alpha) is one fused multiply-add (ATen's vectorised add kernel: fmadd(new, alpha, self))
+    if (lane == 0) cluster[code] = fmaf(alpha, b, cluster[code] * decay);
     float* e = embed + (size_t)code * d;
     if (b == 0.f) {
-        for (int k = lane; k < d; k += 64) e[k] = e[k] * decay + (1.f - decay) * en[(size_t)code * d + k];
+        for (int k = lane; k < d; k += 64) e[k] = fmaf(alpha, en[(size_t)code * d + k], e[k] * decay);
     } else {
         float s = 0.f;
         for (int k = lane; k < d; k += 64) {
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256) void vq_ema_kernel(float* embed, float* cluste
         const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
         for (int k = lane; k < d; k += 64) {
             const float v = (esum[(size_t)code * d + k] / b) * inv;
-            e[k] = e[k] * decay + (1.f - decay) * v;
+            e[k] = fmaf(alpha, v, e[k] * decay);
         }
     }
 }
@@ -470,10 +472,10 @@ extern "C" int favae_vq_segment_sum(const float* zn, const int64_t* idx, int T, 
 }
 
 extern "C" int favae_vq_ema_update(float* embed, float* cluster_size, const float* en, const float* bins, const float* embed_sum,
-                                   int C, int d, float decay, favae_stream_t stream) {
+                                   int C, int d, double decay, favae_stream_t stream) {
     FAVAE_REQUIRE(embed && cluster_size && en && bins && embed_sum && C > 0 && d > 0);
     FAVAE_KLAUNCH(vq_ema_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, embed, cluster_size, en, bins,
-                       embed_sum, C, d, decay);
+                       embed_sum, C, d, (float)decay, (float)(1.0 - decay));
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }

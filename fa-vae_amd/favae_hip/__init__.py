@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfavae_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02, ACT_RELU = 0, 1, 2, 3
@@ -70,7 +70,7 @@ SIGNATURES = {
     "favae_vq_lookup": (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_size_t, _S]),
     "favae_vq_segment_workspace": (c_size_t, [c_int, c_int]),
     "favae_vq_segment_sum": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _S]),
-    "favae_vq_ema_update": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _S]),
+    "favae_vq_ema_update": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, ctypes.c_double, _S]),
     "favae_vq_ste": (c_int, [_P, _P, _P, c_int64, _S]),
     "favae_hinge_mean": (c_int, [_P, c_int64, c_int, _P, _P, c_size_t, _S]),
     "favae_hinge_mean_bwd": (c_int, [_P, _P, c_int64, c_int, _P, _S]),
@@ -95,6 +95,9 @@ SIGNATURES = {
     "favae_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     "favae_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     "favae_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _S]),
+    "favae_prof_enable": (c_int, [c_int]),
+    "favae_prof_reset": (c_int, []),
+    "favae_prof_report": (c_int64, [ctypes.c_char_p, c_int64]),
 }
 
 _lib = None

@@ -8,7 +8,9 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise; the caller owns all memory (PyTorch's
- *     allocator in practice); the library never allocates, keeps no global state and is re-entrant per stream;
+ *     allocator in practice); the library never allocates device memory and is re-entrant per stream.  Process-global state is
+ *     limited to two explicit switches: the conv arithmetic mode (favae_set_conv_mode, default from FAVAE_CONV_MODE) and the
+ *     launch profiler (favae_prof_*, off by default);
  *   - activations are NHWC ("channels last": N, H, W, C with C fastest); conv weights are OHWI
  *     ([Cout][KH][KW][Cin], i.e. a torch (Cout,Cin,KH,KW) tensor in channels_last memory format);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
@@ -39,7 +41,10 @@ enum {
 int favae_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Convolution family (implicit GEMM on v_mfma_f32_32x32x2_f32, exact fp32).
+ * Convolution family: implicit GEMM, fp32-grade.  Default arithmetic: the operands are split into two scaled fp16 planes and the
+ * fp32 product is formed from 3 v_mfma_f32_32x32x16_f16 products with fp32 accumulation ("h3");
+ * favae_set_conv_mode selects three bf16 planes / 6 products ("b6"), the exact fp32 MFMA v_mfma_f32_32x32x2_f32 ("fp32", also the
+ * fallback for shapes the split tiles do not cover), or ONE fp16 plane ("h1": 16-bit mixed precision, not fp32-grade).
  * Replaces: nn.Conv2d 3x3/1x1 inside ResnetBlock / NonResnetBlock (models/codec.py:38-46,50,65-73,77), conv_in /
  * final (:140,170-175,447-450), Downsample = F.pad(0,1,0,1)+conv s2 (:26-29), Upsample = nearest x2 + conv (:17-18),
  * the packed in/out projections of nn.MultiheadAttention (:92), the 4x4 convs of the Discriminator
@@ -224,10 +229,12 @@ int favae_vq_lookup(const float* z, const float* embed, int T, int d, int C, flo
 size_t favae_vq_segment_workspace(int T, int C);
 int favae_vq_segment_sum(const float* zn, const int64_t* idx, int T, int d, int C, float* bins, float* embed_sum, void* ws,
                          size_t ws_bytes, favae_stream_t stream);
-/* EMA (l2_quantize.py:421-438): cluster_size = decay*cluster_size + (1-decay)*bins;
- * embed = decay*embed + (1-decay)*(bins==0 ? en : l2norm(embed_sum/bins)) */
+/* EMA (l2_quantize.py:421-438, ema_inplace :45-46 = moving_avg.mul_(decay).add_(new, alpha=1 - decay)):
+ * cluster_size = decay*cluster_size + (1-decay)*bins; embed = decay*embed + (1-decay)*(bins==0 ? en : l2norm(embed_sum/bins)).
+ * `decay` is a double like the Python float of the reference: the two fp32 factors are (float)decay and (float)(1.0 - decay), the
+ * values torch rounds its scalar arguments to (1.f - (float)decay differs from that by one ulp for decay = 0.8). */
 int favae_vq_ema_update(float* embed, float* cluster_size, const float* en, const float* bins, const float* embed_sum,
-                        int C, int d, float decay, favae_stream_t stream);
+                        int C, int d, double decay, favae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Discriminator training terms (BASELINE config 5): hinge losses (losses/hinge.py:5-14) and the backward of an
@@ -318,6 +325,19 @@ int favae_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, fav
 /* torch.optim.Adam (no weight decay / amsgrad) over one flat buffer: favae_scripts/train_favae.py:297-305 */
 int favae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     int step, float grad_scale, favae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Launch profiler (measurement only; no reference counterpart -- the reference is timed from outside by its caller).
+ * level 0: off (default).  level 1: every launch that carries >= 1 GFLOP of algorithmic work (the matrix-bound conv forward /
+ * data-gradient / weight-gradient kernels) is bracketed by two HIP events recorded on ITS launch stream; level 2: every launch of
+ * the library.  favae_prof_report() waits for the recorded launches and writes one line per kernel instantiation:
+ *   name \t launches \t total_us \t min_us \t max_us \t algorithmic FLOPs \t algorithmic bytes      (sums over the launches)
+ * into buf (NUL-terminated, truncated to cap) and returns the size needed; favae_prof_reset() drops the records.
+ * bench.py computes its `roofline` object from this, inside the timed region.
+ * ---------------------------------------------------------------------------------------------------------- */
+int favae_prof_enable(int level);
+int favae_prof_reset(void);
+int64_t favae_prof_report(char* buf, int64_t cap);
 
 #ifdef __cplusplus
 }

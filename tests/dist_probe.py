@@ -1,0 +1,104 @@
+"""Child of tests/test_gpu_dist.py (run under torch.distributed.run, one rank per GPU, backend nccl = RCCL): the PRODUCT
+TrainStep(distributed=True) -- initial broadcast, codebook all-reduces inside the quantizer forward, gradient marks + overlapped
+bucketed all-reduce -- on each rank's slice of a global batch, against ONE non-distributed TrainStep on the whole batch
+(favae_scripts/train_favae.py:239-259,344-347: what DDP + sync_codebook give the reference).  Checked: identical codebooks on every
+rank and equal to the global-batch EMA; all-reduced gradients / world == global-batch gradients; after a full step() the
+parameters of all ranks are identical.  world_size 1 (the single-GPU box) must be bit-identical to the non-distributed step."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "fa-vae_amd"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import torch
+import torch.distributed as dist
+
+import favae_oracle as O
+from favae_hip import ops as K
+from favae_step import TrainStep
+from models.vqgan_fcm import VQGANFCM
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+dist.init_process_group("nccl", device_id=dev)
+VARIANT = os.environ.get("FAVAE_PROBE_VARIANT", "gauss_resblock")
+flag = {"gauss_resblock": "use_gauss_resblock", "same_conv_gauss": "use_same_conv_gauss"}[VARIANT]
+mk = dict(codebook_size=256, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True, use_l2_quantizer=True,
+          kernel_size=3, dsl_init_sigma=3.0, **{flag: True})
+cfg = O.OracleConfig(codebook_size=256, variant=VARIANT, kernel_size=3)
+state = O.det_state(cfg, with_disc=True)
+PER = 2
+xg = O.det_input(PER * world, 64, 64, 5)
+
+
+def make(distributed, perturb):
+    model = VQGANFCM(**mk, sync_codebook=distributed, device=dev)
+    sd = {k: v.clone() for k, v in state.items()}
+    if perturb:                                 # ranks > 0 start from different weights: the initial broadcast must repair it
+        for k in sd:
+            if sd[k].is_floating_point():
+                sd[k] = sd[k] + 0.01
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    return model, TrainStep(model, lr=1e-4, distributed=distributed)
+
+
+def grads(ts, x):
+    ts.model.train()
+    ts.gflat.zero_()
+    out = ts.losses(x)
+    ts.backward(out)
+    K.sync_side_stream()
+    if ts.exchange is not None:
+        ts.exchange.finish()
+    elif ts.distributed:
+        dist.all_reduce(ts.gflat)
+    torch.cuda.synchronize()
+    return out
+
+
+model, ts = make(True, perturb=rank > 0)
+assert ts.distributed and ts.world == world
+expect_overlap = os.environ.get("FAVAE_OVERLAP_COMM", "1") != "0"
+assert (ts.exchange is not None) == expect_overlap
+x = xg[PER * rank:PER * (rank + 1)].to(dev)
+out = grads(ts, x)
+if ts.exchange is not None:
+    assert all(ts.exchange.fired), ts.exchange.fired
+g_dist = ts.gflat.clone() / world
+embed = model.quantizer._codebook.embed.clone()
+cluster = model.quantizer._codebook.cluster_size.clone()
+
+# every rank holds the same exchanged gradients and codebook
+for t, name in ((g_dist, "gradients"), (embed, "codebook"), (cluster, "cluster sizes")):
+    ref = t.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(ref, t), "rank %d: %s differ from rank 0" % (rank, name)
+
+# one non-distributed step on the whole batch (every rank computes it: no collectives inside)
+model1, ts1 = make(False, perturb=False)
+grads(ts1, xg.to(dev))
+scale = float(ts1.gflat.abs().max())
+err = float((g_dist - ts1.gflat).abs().max()) / scale
+e_err = float((embed - model1.quantizer._codebook.embed).abs().max())
+if world == 1:
+    assert torch.equal(g_dist, ts1.gflat), "world 1: distributed step is not bit-identical (%g)" % err
+    assert torch.equal(embed, model1.quantizer._codebook.embed)
+else:
+    # per-sample-mean losses: sum over ranks / world == global-batch gradient up to fp32 summation order
+    assert err < 2e-5, "all-reduced gradients differ from the global-batch gradients: %g of the max" % err
+    assert e_err < 1e-6, "codebook differs from the global-batch EMA update: %g" % e_err
+    assert torch.equal(cluster, model1.quantizer._codebook.cluster_size)
+
+# a full step() (exchange + Adam) keeps the ranks identical
+ts.step(x)
+torch.cuda.synchronize()
+p0 = ts.pflat.clone()
+dist.broadcast(p0, 0)
+assert torch.equal(p0, ts.pflat), "rank %d: parameters diverged after step()" % rank
+dist.barrier()
+if rank == 0:
+    print("DIST PROBE OK world=%d variant=%s overlap=%s grad_err=%.2e embed_err=%.2e" % (world, VARIANT, expect_overlap, err, e_err))
+dist.destroy_process_group()

@@ -55,3 +55,26 @@ def test_dropin_surface_and_state_dict_keys():
     assert {k: tuple(v.shape) for k, v in m2.state_dict().items()} == {k: tuple(v) for k, v in shapes2.items()}
     with pytest.raises(ValueError):
         m.forward(torch.zeros(1), stage=2)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` with fewer than N GPUs visible exits 2 before any GPU call (here: no GPU at all); the N-rank
+    launch itself is covered on the GPU box (tests/test_gpu_dist.py)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node has GPUs: covered by tests/test_gpu_dist.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "--gpus 2 but only" in out.stderr, out.stderr[-500:]
+
+
+def test_launch_profiler_reports_empty_without_launches():
+    lib = favae_hip.load()
+    assert lib.favae_prof_enable(3) != 0 and lib.favae_prof_enable(0) == 0
+    import ctypes
+    n = lib.favae_prof_report(None, 0)
+    buf = ctypes.create_string_buffer(int(n) + 8)
+    lib.favae_prof_report(buf, len(buf))
+    assert buf.value == b""

@@ -34,3 +34,47 @@ def test_model_under_torch_ddp():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ddp_probe.py")], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
     assert "DDP PROBE OK" in out.stdout
+
+
+def _run_probe(world, variant, overlap, port):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FAVAE_PROBE_VARIANT=variant, FAVAE_OVERLAP_COMM="1" if overlap else "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_probe.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "DIST PROBE OK world=%d" % world in out.stdout
+    return out.stdout
+
+
+@pytest.mark.parametrize("variant,overlap", [("gauss_resblock", True), ("same_conv_gauss", True), ("gauss_resblock", False)])
+def test_product_trainstep_distributed_world1(variant, overlap):
+    """TrainStep(distributed=True) through RCCL at world size 1 (what this box has): initial broadcast, codebook all-reduces,
+    gradient marks and the overlapped bucketed all-reduce all run, and the result is bit-identical to the non-distributed step."""
+    _run_probe(1, variant, overlap, 29561)
+
+
+@pytest.mark.parametrize("variant", ["gauss_resblock", "same_conv_gauss"])
+def test_product_trainstep_two_ranks_equal_global_batch(variant):
+    """Two ranks on two GPUs against one rank on the concatenated batch: codebooks identical, gradients within 2e-5."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs on the node (this box has %d)" % torch.cuda.device_count())
+    _run_probe(2, variant, True, 29563)
+
+
+def test_bench_gpus_flag_launches_ranks():
+    """`python bench.py --gpus N` without a launcher starts N ranks itself; with more ranks than GPUs it refuses (exit 2) before
+    touching a GPU.  N = the number of GPUs of the node (1 here: the in-process path) and N = that + 1 (the refusal)."""
+    import torch
+    n = torch.cuda.device_count()
+    bench = os.path.join(ROOT, "bench.py")
+    small = ["--steps", "1", "--warmup", "1", "--batch", "2", "--codebook", "256", "--res", "64", "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, bench, "--gpus", str(n + 1)] + small, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "only %d GPU" % n in out.stderr
+    if n >= 2:
+        out = subprocess.run([sys.executable, bench, "--gpus", str(n)] + small, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert res["n_gpus"] == n and res["rccl_world_size"] == n and len(res["per_rank_images_per_s"]) == n

@@ -198,6 +198,61 @@ def test_conv_other_modes(mode):
     assert "PROBE OK" in r.stdout
 
 
+def test_split_precision_is_fp32_grade_against_fp64(K):
+    """The claim behind dtype "f32": the default conv arithmetic h3 (two scaled fp16 planes, 3 MFMA products per multiply-add) is at
+    least as accurate as the exact fp32 MFMA kernels.  Forward (GroupNorm+SiLU fused), plain forward, data gradient and weight
+    gradient of the deep-K layer 512->512 @ 16x16 (K = 4608) and of 128->128 @ 64x64, each in h3 / fp32-MFMA / b6, against an fp64
+    CPU convolution: rms(h3) <= rms(fp32-MFMA) (5 % slack for the noise of an rms over 0.26-1 M elements).  The table goes to
+    gpurun_out/r02_precision.txt (copied to profiles/)."""
+    torch.manual_seed(0)
+    d = dev()
+    rows, prev = [], K.get_conv_mode()
+
+    def rms(a, r):
+        return float((a.double().cpu() - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt())
+    try:
+        for (N, C, Co, H) in [(2, 512, 512, 16), (2, 128, 128, 64)]:
+            x = torch.randn(N, C, H, H)
+            gy = torch.randn(N, Co, H, H) * 1e-4
+            w = torch.randn(Co, C, 3, 3) * math.sqrt(1.0 / (C * 9))
+            b = torch.randn(Co) * 0.1
+            gw, gb = 1 + 0.2 * torch.randn(C), 0.2 * torch.randn(C)
+            xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+            ref_gn = F.conv2d(F.silu(F.group_norm(xd, 32, gw.double(), gb.double())), wd, b.double(), padding=1).detach()
+            ref_pl = F.conv2d(xd, wd, b.double(), padding=1)
+            ref_dx, ref_dw = torch.autograd.grad(ref_pl, (xd, wd), gy.double())
+            ref_pl = ref_pl.detach()
+            xf, wf = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            cpu_pl = F.conv2d(xf, wf, b, padding=1)
+            cpu_dx, cpu_dw = torch.autograd.grad(cpu_pl, (xf, wf), gy)
+            cpu_gn = F.conv2d(F.silu(F.group_norm(x, 32, gw, gb)), w, b, padding=1)
+            errs = {"torch-cpu-fp32": (rms(cpu_gn, ref_gn), rms(cpu_pl.detach(), ref_pl), rms(cpu_dx, ref_dx), rms(cpu_dw, ref_dw))}
+            cfg = K.ConvCfg(3, 3, 1, 1)
+            for mode in ("h3", "fp32", "b6"):
+                K.set_conv_mode(mode)
+                xg, wg = x.to(d).requires_grad_(True), w.to(d).requires_grad_(True)
+                y_gn = K.fused_conv(xg, wg, b.to(d), gw.to(d), gb.to(d), None, cfg)
+                y_pl = K.fused_conv(xg, wg, b.to(d), None, None, None, cfg)
+                dx, dw = torch.autograd.grad(y_pl, (xg, wg), gy.to(d))
+                K.sync_side_stream()
+                torch.cuda.synchronize()
+                errs[mode] = (rms(y_gn.detach(), ref_gn), rms(y_pl.detach(), ref_pl), rms(dx, ref_dx), rms(dw, ref_dw))
+            for mode, e in errs.items():
+                rows.append("%4d->%-4d @%3dx%-3d K=%-5d %-15s gn+silu fwd %.3e  plain fwd %.3e  dgrad %.3e  wgrad %.3e" %
+                            ((C, Co, H, H, 9 * C, mode) + e))
+            for i, what in enumerate(("gn+silu fwd", "plain fwd", "dgrad", "wgrad")):
+                assert errs["h3"][i] <= 1.05 * errs["fp32"][i], \
+                    "h3 less accurate than the fp32 MFMA kernels on %s of %d->%d: %.3e vs %.3e" % (what, C, Co, errs["h3"][i], errs["fp32"][i])
+                assert errs["h3"][i] < 2e-6 and errs["b6"][i] < 2e-6
+    finally:
+        K.set_conv_mode(prev)
+    text = "rms error relative to rms(reference), reference = fp64 CPU convolution\n" + "\n".join(rows)
+    print("\n" + text)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        open(os.path.join(out, "r02_precision.txt"), "w").write(text + "\n")
+
+
 BLOCK_DIMS = {"res_same": ("res", (64, 64)), "res_short": ("res", (32, 96)), "nonres": ("nonres", (64, 64)),
               "nonres_g4": ("nonres4", (8, 8)), "attn": ("attn", (64,)), "down": ("down", (32,)), "down_odd": ("down", (32,)),
               "up": ("up", (32,))}
