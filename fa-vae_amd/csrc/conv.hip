@@ -103,6 +103,11 @@ struct ConvArgs {
     int pad_w;
     int in_step, in_row, in_img, in_off;
     int out_step, out_row, out_img, out_off;
+    // conv3x3_halo_sp_kernel<., 2, 3> only: when set, the kernel also stores the transformed + split operand T(x) it stages
+    // (two scaled fp16 planes, one 16-byte record {hi[4], lo[4]} per 4 channels = the bytes of the fp32 tensor) for the
+    // weight-gradient kernel, which then loads its operands without any transform / split arithmetic
+    void* planes_out;
+    unsigned planes_bytes;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -318,6 +323,8 @@ struct WgradArgs {
     const float* dy_amax;
     int pad_w;                              // conv_wgrad_sp_kernel only: left padding, dy on a sub-grid (see ConvArgs)
     int dy_step, dy_row, dy_img, dy_off;
+    const void* x_planes;                   // conv_wgrad_row3_sp_kernel<., 2, PRE>: pre-split operands (ConvArgs::planes_out)
+    const void* dy_planes;
 };
 
 template <int BCO, int BCI, int WAVES_O, int WAVES_I>
@@ -793,12 +800,12 @@ extern "C" int favae_split_weights(const float* in, void* out, int64_t n, int pl
 
 static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                          const float* scale, const float* shift, float* y, int wplanes, const float* x_amax,
-                         favae_stream_t stream);
+                         favae_stream_t stream, void* planes_out);
 
 extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const float* w, const float* bias,
                               const float* resid, const float* scale, const float* shift, float* y,
                               favae_stream_t stream) {
-    return conv_fwd_impl(d, x, w, bias, resid, scale, shift, y, 0, nullptr, stream);
+    return conv_fwd_impl(d, x, w, bias, resid, scale, shift, y, 0, nullptr, stream, nullptr);
 }
 
 extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, const void* wsplit, int planes,
@@ -806,12 +813,35 @@ extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, co
                                     const float* shift, float* y, favae_stream_t stream) {
     if (!sp_fwd_eligible(d, scale != nullptr)) return FAVAE_ERR_UNSUPPORTED;
     FAVAE_REQUIRE(wsplit && (planes == 3 || ((planes == 2 || planes == 1) && x_absmax)));
-    return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream);
+    return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr);
+}
+
+// producer side of the pre-split operand planes: 1 when favae_conv_fwd_split(d, ...) runs the dense 3x3 halo kernel with two fp16
+// planes -- the kernel that can store its staged operand as a by-product (ConvArgs::planes_out)
+static bool planes_producer_ok(const favae_conv_desc* d, bool has_affine) {
+    if (!sp_fwd_eligible(d, has_affine) || conv_mode() != 2 || desc_special(d) || !use_halo()) return false;
+    const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, wb = (size_t)d->Cout * 9 * d->Cin * 4;
+    return d->Cout > 64 && d->Cin % 16 == 0 && d->stride == 1 && d->gather == FAVAE_GATHER_PLAIN && d->KH == 3 && d->KW == 3 &&
+           d->pad == 1 && d->Hout == d->Hin && d->Wout == d->Win && d->Hin % 8 == 0 && d->Win % 16 == 0 && xb < (1u << 31) &&
+           wb < (1u << 31) && (size_t)d->N * d->Hout * d->Wout * d->Cout * 4 < ((size_t)1 << 32);
+}
+
+extern "C" int favae_conv_planes_ok(const favae_conv_desc* d, int has_affine) {
+    return desc_ok(d) && planes_producer_ok(d, has_affine != 0) ? 1 : 0;
+}
+
+extern "C" int favae_conv_fwd_split_planes(const favae_conv_desc* d, const float* x, const void* wsplit, int planes,
+                                           const float* x_absmax, const float* bias, const float* resid, const float* scale,
+                                           const float* shift, float* y, void* planes_out, favae_stream_t stream) {
+    if (!sp_fwd_eligible(d, scale != nullptr)) return FAVAE_ERR_UNSUPPORTED;
+    FAVAE_REQUIRE(wsplit && (planes == 3 || ((planes == 2 || planes == 1) && x_absmax)));
+    if (planes_out && !(planes == 2 && planes_producer_ok(d, scale != nullptr) && al16(planes_out))) return FAVAE_ERR_UNSUPPORTED;
+    return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, planes_out);
 }
 
 static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                          const float* scale, const float* shift, float* y, int wplanes, const float* x_amax,
-                         favae_stream_t stream) {
+                         favae_stream_t stream, void* planes_out) {
     FAVAE_REQUIRE(desc_ok(d) && x && w && y);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     // roofline numerators of this conv: 2*M*Cout*KH*KW*Cin FLOP; one read of x (+ resid), one write of y, the weights
@@ -852,6 +882,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         }
     }
     ConvArgs a;
+    a.planes_out = planes_out;
     a.x_amax = x_amax; a.w_amax = w;
     a.x = x; a.w = w6 ? (const float*)((const char*)w + sp::WHDR + d->w_rec_offset) : w;
     const bool special = desc_special(d);
@@ -888,6 +919,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
                         (size_t)d->N * a.out_img * d->Cout * 4 < ((size_t)1 << 32) && (d->gather == FAVAE_GATHER_PLAIN || xf == 0);
     if (special && !(buf_ok && use_b6() && bn == 128 && w6 && d->gather == FAVAE_GATHER_PLAIN)) return FAVAE_ERR_UNSUPPORTED;
     a.x_bytes = (unsigned)xb; a.aff_bytes = (unsigned)ab;
+    a.planes_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)(wplanes ? wb / 16 * wrec_bytes(wplanes) : wb);
 #define FAVAE_LAUNCH_BUF(G, X)                                                                                     \
     do {                                                                                                           \
@@ -972,9 +1004,45 @@ extern "C" size_t favae_conv_wgrad_workspace(const favae_conv_desc* d) {
     return (size_t)sk * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
 }
 
+static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float* dy, const float* scale, const float* shift,
+                           const float* x_absmax, const float* dy_absmax, const void* x_planes, const void* dy_planes, float* dw,
+                           int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream);
+
 extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const float* dy, const float* scale,
                                 const float* shift, const float* x_absmax, const float* dy_absmax, float* dw, int accumulate,
                                 void* ws, size_t ws_bytes, favae_stream_t stream) {
+    return conv_wgrad_impl(d, x, dy, scale, shift, x_absmax, dy_absmax, nullptr, nullptr, dw, accumulate, ws, ws_bytes, stream);
+}
+
+extern "C" int favae_conv_wgrad_planes(const favae_conv_desc* d, const float* x, const float* dy, const float* scale,
+                                       const float* shift, const float* x_absmax, const float* dy_absmax, const void* x_planes,
+                                       const void* dy_planes, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                                       favae_stream_t stream) {
+    FAVAE_REQUIRE(al16(x_planes) && al16(dy_planes));
+    return conv_wgrad_impl(d, x, dy, scale, shift, x_absmax, dy_absmax, x_planes, dy_planes, dw, accumulate, ws, ws_bytes, stream);
+}
+
+static bool wgrad_row3_ok(const favae_conv_desc* d);
+
+// consumer side: 1 when the weight gradient of `d` runs the three-tap kernel with two fp16 planes, which can take pre-split operands
+extern "C" int favae_conv_wgrad_takes_planes(const favae_conv_desc* d) {
+    return desc_ok(d) && conv_mode() == 2 && wgrad_row3_ok(d) ? 1 : 0;
+}
+
+static bool wgrad_row3_ok(const favae_conv_desc* d) {          // mirrors the `row3` branch of conv_wgrad_impl
+    if (thin_kind(d, false) || thin_kind(d, true) || desc_special(d) || force_generic() || force_nobuf() || !use_b6() || !use_row3())
+        return false;
+    if (d->act != FAVAE_ACT_NONE && d->act != FAVAE_ACT_SILU) return false;
+    int bco, bci;
+    wgrad_tiles(d, &bco, &bci);
+    const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, yb = (size_t)d->N * d->Hout * d->Wout * d->Cout * 4;
+    return bco == 128 && bci == 128 && d->Cin % 4 == 0 && d->Cout % 4 == 0 && d->gather == FAVAE_GATHER_PLAIN && d->stride == 1 &&
+           d->Wout % 16 == 0 && xb < (1u << 31) && yb < (1u << 31) && d->KH == 3 && d->KW == 3 && d->pad == 1;
+}
+
+static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float* dy, const float* scale, const float* shift,
+                           const float* x_absmax, const float* dy_absmax, const void* x_planes, const void* dy_planes, float* dw,
+                           int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && x && dy && dw && ws);
     // fp16 planes need both operand maxima; without them the bf16 scheme (no range restrictions) runs
     const int cm = conv_mode();
@@ -1028,6 +1096,7 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
     wgrad_tiles(d, &bco, &bci);
     WgradArgs a;
     a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.part = (float*)ws;
+    a.x_planes = x_planes; a.dy_planes = dy_planes;
     a.x_amax = x_absmax; a.dy_amax = dy_absmax;
     const bool special = desc_special(d);
     a.pad_w = d->pad + d->pad_dw;
@@ -1085,7 +1154,13 @@ extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const 
         else if (np == 1) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<X, 1>), g3, dim3(512), 0, s, a);  \
         else FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<X, 3>), g3, dim3(512), 0, s, a);               \
     } while (0)
-        if (xf == 0) FAVAE_LAUNCH_ROW3(0);
+        const int pre = np == 2 ? ((dy_planes ? 1 : 0) | (x_planes ? 2 : 0)) : 0;
+        if (pre == 3) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<0, 2, 3>), g3, dim3(512), 0, s, a);
+        else if (pre == 2) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<0, 2, 2>), g3, dim3(512), 0, s, a);
+        else if (pre == 1 && xf == 0) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<0, 2, 1>), g3, dim3(512), 0, s, a);
+        else if (pre == 1 && xf == 1) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<1, 2, 1>), g3, dim3(512), 0, s, a);
+        else if (pre == 1) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<2, 2, 1>), g3, dim3(512), 0, s, a);
+        else if (xf == 0) FAVAE_LAUNCH_ROW3(0);
         else if (xf == 1) FAVAE_LAUNCH_ROW3(1);
         else FAVAE_LAUNCH_ROW3(2);
 #undef FAVAE_LAUNCH_ROW3

@@ -539,13 +539,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
     const auto rw = make_rsrc(a.w, a.w_bytes);
     const auto rsc_d = make_rsrc(XFORM ? a.scale : a.x, XFORM ? a.aff_bytes : 0u);
     const auto rsh_d = make_rsrc(XFORM ? a.shift : a.x, XFORM ? a.aff_bytes : 0u);
+    const auto rpl = make_rsrc(a.planes_out ? a.planes_out : (const void*)a.x, (a.planes_out && tn == 0) ? a.planes_bytes : 0u);
 
     // halo staging slots of this thread (720 float4 over 512 threads): constant offsets.  The fused-transform operands
     // (scale, shift) depend on (image, channel quad) only: one load per K chunk serves both slots; padding pixels must
     // stay exactly zero after the transform, so they are masked with a select instead of zeroed operands.
     unsigned vh[2];
     int hoff[2];
-    bool hok[2];
+    bool hok[2], hin[2];
+    // planes_out (dense 3x3 convs, two planes): the workgroups of output-channel tile 0 store the interior pixels of their halo
+    const bool wr_planes = NP == 2 && KS == 3;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i = tid + 512 * j;
@@ -553,6 +556,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
         const int hy = hrow / HW, hx = hrow - hy * HW;
         hoff[j] = hy * HPITCH + hx * S::ROWB;
         const int y = ty0 - a.pad + hy, x = tx0 - a.pad_w + hx;
+        hin[j] = wr_planes && hrow < HROWS && hy >= a.pad && hy < a.pad + TH && hx >= a.pad_w && hx < a.pad_w + TW;
         hok[j] = hrow < HROWS && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
         vh[j] = hok[j] ? (unsigned)(((n * a.in_img + y * a.in_step * a.in_row + x * a.in_step + a.in_off) * a.Cin + q4 * 4) * 4) : FAVAE_OOB;
     }
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
             rsh = bload(rsh_d, vs, sk);
         }
     };
-    auto store_halo = [&](int buf) {
+    auto store_halo = [&](int buf, int kc) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && tid >= HROWS * 4 - 512) continue;
@@ -583,6 +587,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
             if (XFORM && !hok[j]) t = make_float4(0.f, 0.f, 0.f, 0.f);
             S::split4(t, Sa, p);
             sp::store_planes<NP>(Hs + buf * HALO_B + hoff[j] + q4 * 8, 32, p);
+        }
+    };
+    // planes_out: the staged planes of chunk kc are read back from the LDS halo (where they sit in final form) and stored to HBM
+    // while few registers are live (tap 1 of the chunk), instead of from store_halo, whose operands are the kernel's register peak.
+    // The record of (pixel, channel quad) goes to the byte offset of the fp32 quad it was made from; non-interior slots (and every
+    // slot when no planes were asked for: zero-sized resource) are dropped by the buffer range check.
+    auto flush_planes = [&](int buf, int kc) {
+        if constexpr (NP == 2 && KS == 3) {
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j == 1 && tid >= HROWS * 4 - 512) continue;
+                const unsigned char* src = Hs + buf * HALO_B + hoff[j] + q4 * 8;
+                const uint2 p0 = *reinterpret_cast<const uint2*>(src), p1 = *reinterpret_cast<const uint2*>(src + 32);
+                const u32x4_t rec = {p0.x, p0.y, p1.x, p1.y};
+                __builtin_amdgcn_raw_buffer_store_b128(rec, rpl, hin[j] ? vh[j] : FAVAE_OOB, (unsigned)(kc * 64), 0);
+            }
         }
     };
     auto load_b = [&](int kc, int tap) { sp::load_wrec<NP>(rw, vb, (unsigned)((tap * a.Cin + kc * 16) / 4 * S::WREC), rbp); };
@@ -603,7 +624,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
     const int KC = a.Cin / 16;
     load_halo(0);
     load_b(0, 0);
-    store_halo(0);
+    store_halo(0, 0);
     store_b(0);
     __syncthreads();
     int it = 0;
@@ -616,6 +637,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
             if (!last_tap) load_b(kc, tap + 1);
             else if (more_kc) load_b(kc + 1, 0);
             if (tap == TAPS / 2 && more_kc) load_halo(kc + 1);           // in flight over the second half of the taps
+            if (tap == 1 && a.planes_out) flush_planes(hb, kc);
             const int kh = tap / KS, kw = tap - kh * KS;
             const unsigned char* Ab = Afr + hb * HALO_B + kh * HPITCH + kw * S::ROWB;
             const unsigned char* Bb = Bfr + cur * BT_B;
@@ -629,7 +651,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
 #pragma unroll
             for (int j = 0; j < 2; ++j) S::mma(af, bf[j], acc[j]);
             if (!last_tap || more_kc) store_b(cur ^ 1);
-            if (last_tap && more_kc) store_halo(hb ^ 1);
+            if (last_tap && more_kc) store_halo(hb ^ 1, kc + 1);
             __syncthreads();
         }
     }
@@ -662,7 +684,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
 // LDS stores per MFMA than the tap-per-workgroup conv_wgrad_sp_kernel.  8 waves (4 co x 2 ci, 32 x 64 each, 3 taps).
 // Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, Wout % 16 == 0, channels % 4 == 0, operands < 2 GiB.
 // ---------------------------------------------------------------------------------------------------------------
-template <int XFORM, int NP>
+template <int XFORM, int NP, int PRE = 0>
 __global__ __launch_bounds__(512) void conv_wgrad_row3_sp_kernel(WgradArgs a) {
     using S = sp::Scheme<NP>;
     constexpr int OPL = 16 * sp::RSB, IPL = 18 * sp::RSB;           // bytes per plane (dy: 16 px, x: 18 px)
@@ -683,8 +705,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_sp_kernel(WgradArgs a) {
     const int T = (p_end > p_begin) ? (p_end - p_begin + 15) / 16 : 0;
     const float So = S::SCALED ? sp::pow2_scale(a.dy_amax) : 1.f, Si = S::SCALED ? sp::pow2_scale(a.x_amax) : 1.f;
 
-    const auto rx = make_rsrc(a.x, a.x_bytes);
-    const auto rdy = make_rsrc(a.dy, (unsigned)p_end * (unsigned)a.Cout * 4u);
+    // PRE bit 0: dy arrives as pre-split plane records (WgradArgs::dy_planes), bit 1: the transformed x does (x_planes) --
+    // records sit at the byte offsets of the fp32 quads, so the addressing is unchanged and out-of-range reads are zero planes
+    const auto rx = make_rsrc((PRE & 2) ? (const float*)a.x_planes : a.x, a.x_bytes);
+    const auto rdy = make_rsrc((PRE & 1) ? (const float*)a.dy_planes : a.dy, (unsigned)p_end * (unsigned)a.Cout * 4u);
     const auto rsc_d = make_rsrc(XFORM ? a.scale : a.x, XFORM ? a.aff_bytes : 0u);
     const auto rsh_d = make_rsrc(XFORM ? a.shift : a.x, XFORM ? a.aff_bytes : 0u);
 
@@ -732,12 +756,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_sp_kernel(WgradArgs a) {
     };
     auto store_tiles = [&](int buf) {
         uint2 p[NP];
-        S::split4(ro, So, p);
+        if constexpr ((PRE & 1) && NP == 2) {     // {hi[4], lo[4]} record -> the two planes
+            p[0] = make_uint2(__float_as_uint(ro.x), __float_as_uint(ro.y));
+            p[1] = make_uint2(__float_as_uint(ro.z), __float_as_uint(ro.w));
+        } else S::split4(ro, So, p);
         sp::store_planes<NP>(Os + buf * OB + spx * sp::RSB + sq * 2, OPL, p);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && !two) continue;
-            S::split4(xform4_t<XFORM>(ri[j], rsc[j], rsh[j], a.act), Si, p);
+            if constexpr ((PRE & 2) && NP == 2) {
+                p[0] = make_uint2(__float_as_uint(ri[j].x), __float_as_uint(ri[j].y));
+                p[1] = make_uint2(__float_as_uint(ri[j].z), __float_as_uint(ri[j].w));
+            } else S::split4(xform4_t<XFORM>(ri[j], rsc[j], rsh[j], a.act), Si, p);
             sp::store_planes<NP>(Is + buf * IB + (spx + 16 * j) * sp::RSB + sq * 2, IPL, p);
         }
     };

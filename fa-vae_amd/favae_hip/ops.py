@@ -315,7 +315,15 @@ class ConvCfg:
         return Ho, Wo
 
 
-def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=None):
+# FAVAE_WGRAD_PLANES=1: the forward / data-gradient 3x3 convs store their staged operands as pre-split fp16 planes and the
+# weight-gradient kernel loads them without any transform / split arithmetic (include/favae_hip.h, favae_conv_*_planes).  Same
+# bits, weight-gradient kernel alone 284 -> 352 TFLOP/s -- but OFF by default: in the training step the weight gradients are
+# already hidden on the second stream, while the plane stores cost the un-overlapped forward kernel 8 % (same-box A/B, batch 32:
+# 180.8 ms/step off, 182.5 on).
+_PLANES = os.environ.get("FAVAE_WGRAD_PLANES", "0") == "1"
+
+
+def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=None, planes_out=None):
     """conv forward / data gradient.  When the library runs this shape on the split-precision matrix path the weights are
     pre-split once per call (instead of once per tile in the K loop); the fp16 scheme (2 planes) also needs the operand
     range: `x_bound` = device scalar >= max|T(x)| (computed here for an un-transformed operand when not supplied).
@@ -342,9 +350,15 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
             if scale is not None:
                 raise RuntimeError("a transformed conv operand needs its range bound (gn_stats(with_bound=True))")
             x_bound = absmax(x)
-        call("favae_conv_fwd_split", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
-             ptr(shift), ptr(y))
+        if planes_out is not None:
+            call("favae_conv_fwd_split_planes", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
+                 ptr(shift), ptr(y), ptr(planes_out))
+        else:
+            call("favae_conv_fwd_split", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
+                 ptr(shift), ptr(y))
     else:
+        if planes_out is not None:
+            raise RuntimeError("pre-split planes were requested for a conv that does not run on the split matrix path")
         if w_ohwi is None:
             w_ohwi = _flipped(flip_of)
         call("favae_conv_fwd", byref(d), ptr(x), ptr(w_ohwi), ptr(b), ptr(resid), ptr(scale), ptr(shift), ptr(y))
@@ -398,7 +412,13 @@ class FusedConvFn(torch.autograd.Function):
                            per_image)
         if xb is None and query("favae_conv_wants_split_weights", byref(d), 0) in (1, 2):
             xb = absmax(x)
-        w_amax = _conv_launch(d, x, wk, b, resid, scale, shift, y, xb)
+        # T(x) as the two scaled fp16 planes the weight gradient needs, stored by the forward kernel as a by-product (saved for
+        # backward next to x: +4 bytes per input element, which 288 GB of HBM have room for)
+        xs = None
+        if (_PLANES and ctx.needs_input_grad[1] and query("favae_conv_planes_ok", byref(d), 0 if scale is None else 1)
+                and query("favae_conv_wgrad_takes_planes", byref(d))):
+            xs = torch.empty((N, Hin, Win, Cin), dtype=torch.float32, device=dev)
+        w_amax = _conv_launch(d, x, wk, b, resid, scale, shift, y, xb, planes_out=xs)
         ctx.cfg = cfg
         ctx.has_b = b is not None
         ctx.has_gn = gn_w is not None
@@ -407,14 +427,14 @@ class FusedConvFn(torch.autograd.Function):
         ctx.has_res = resid is not None
         ctx.w_dim = w.dim()
         ctx.params = (w, b, gn_w, gn_b)           # to reach pre-assigned flat-buffer gradients (see _direct_grad)
-        ctx.save_for_backward(x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb, w_amax)
+        ctx.save_for_backward(x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb, w_amax, xs)
         if pass_input:
             return y, x
         return y
 
     @staticmethod
     def backward(ctx, dy, dskip=None):
-        x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb, w_amax = ctx.saved_tensors
+        x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb, w_amax, xs = ctx.saved_tensors
         if dskip is not None:
             dskip = to_cl(dskip)
         cfg = ctx.cfg
@@ -430,7 +450,6 @@ class FusedConvFn(torch.autograd.Function):
         elif _GRAD_ONLY == "param":
             need_x = has_gn = False
         dx = dw = db = dgw = dgb = None
-        late_wgrad = None
         gather = GATHER_UPSAMPLE2 if cfg.upsample else GATHER_PLAIN
         act = cfg.act if ctx.has_xform else ACT_NONE
         p_w, p_b, p_gw, p_gb = ctx.params
@@ -447,34 +466,40 @@ class FusedConvFn(torch.autograd.Function):
                  ws.numel())
         elif want_range:
             call("favae_absmax", ptr(dy), dy.numel(), ptr(dyb))
+        # The weight gradient runs AFTER this conv's data gradient: the data-gradient kernel stores dy as pre-split planes on its
+        # way (dys), the forward kernel stored T(x) (xs), and the weight-gradient kernel then loads both without any arithmetic.
+        run_wgrad = None
+        use_planes = False
         if need_w:
             d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad, gather, act, ctx.per_image)
             ws = workspace(query("favae_conv_wgrad_workspace", byref(d)), dev)
             tgt = _direct_grad(p_w)
+            use_planes = _PLANES and bool(query("favae_conv_wgrad_takes_planes", byref(d)))
+            dwk = None
             if tgt is None:
                 dwk = torch.empty((Cout, cfg.kh, cfg.kw, Cin), dtype=torch.float32, device=dev)
-                call("favae_conv_wgrad", byref(d), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(dwk), 0,
-                     ptr(ws), ws.numel())
                 dw = dwk.permute(0, 3, 1, 2)                  # (Cout,Cin,KH,KW) view with channels-last strides
                 if ctx.w_dim == 2:
                     dw = dwk.view(Cout, Cin)
-            elif _SIDE["on"]:                                 # flat gradient buffer, side stream (see _SIDE)
-                wd, wws, wtgt = d, ws, tgt
+            wd, wws, wtgt = d, ws, (tgt if tgt is not None else dwk)
+            acc = 1 if tgt is not None else 0
 
-                def side_wgrad():
-                    _side_launch(lambda: call("favae_conv_wgrad", byref(wd), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb),
-                                              ptr(dyb), ptr(wtgt), 1, ptr(wws), wws.numel()),
-                                 (x, dy, scale, shift, xb, dyb, wws))
+            def launch_wgrad(dys):
+                if use_planes and (xs is not None or dys is not None):
+                    call("favae_conv_wgrad_planes", byref(wd), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(xs),
+                         ptr(dys), ptr(wtgt), acc, ptr(wws), wws.numel())
+                else:
+                    call("favae_conv_wgrad", byref(wd), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(wtgt), acc,
+                         ptr(wws), wws.numel())
+
+            if tgt is not None and _SIDE["on"]:               # flat gradient buffer, side stream (see _SIDE)
                 # launched AFTER this conv's data gradient (below): the side stream then starts it next to the HBM-bound
                 # GroupNorm-backward / bias-gradient kernels that follow instead of next to the other matrix-bound kernel
                 # (measured: 204 -> 196 ms/step; launching it before the data gradient only gave 208 -> 204)
-                if need_x or has_gn:
-                    late_wgrad = side_wgrad
-                else:
-                    side_wgrad()
-            else:                                             # accumulate straight into the flat gradient buffer
-                call("favae_conv_wgrad", byref(d), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(tgt), 1,
-                     ptr(ws), ws.numel())
+                def run_wgrad(dys):
+                    _side_launch(lambda: launch_wgrad(dys), (x, dy, scale, shift, xb, dyb, wws, xs, dys))
+            else:
+                run_wgrad = launch_wgrad
         if need_x or has_gn:
             if has_gn and mean is None:
                 raise RuntimeError("gradient through a normalisation with frozen (running) statistics is not implemented")
@@ -499,9 +524,6 @@ class FusedConvFn(torch.autograd.Function):
                     dph = make_conv_desc(N, Ho, Wo, Cout, Ho, Wo, Cin, khn, kwn, 1, ph_pad, GATHER_PLAIN, ACT_NONE, 1,
                                          lattice=(2, 1, ph >> 1, ph & 1), pad_dw=pw_pad - ph_pad, w_rec_offset=off * rec)
                     call("favae_conv_fwd_split", byref(dph), ptr(dy), ptr(wph), planes, ptr(dyb), None, None, None, None, ptr(da))
-                if late_wgrad is not None:
-                    late_wgrad()
-                    late_wgrad = None
             elif cfg.stride == 1:
                 Hv, Wv = (2 * Hin, 2 * Win) if cfg.upsample else (Hin, Win)
                 g2, pad2 = GATHER_PLAIN, cfg.kh - 1 - cfg.pad
@@ -510,12 +532,17 @@ class FusedConvFn(torch.autograd.Function):
                 g2, pad2 = GATHER_DILATE2, cfg.kh - 1 - cfg.pad
             else:
                 raise RuntimeError("unsupported conv geometry for the data gradient")
+            dys = None
             if not phased:
                 da = new_cl(N, Cin, Hv, Wv, dev)
                 d2 = make_conv_desc(N, Ho, Wo, Cout, Hv, Wv, Cin, cfg.kh, cfg.kw, 1, pad2, g2, ACT_NONE, 1)
-                _conv_launch(d2, dy, None, None, None, None, None, da, dyb, flip_of=(wk, Cout, cfg.kh, cfg.kw, Cin, w_amax))
-            if late_wgrad is not None:
-                late_wgrad()
+                if use_planes and query("favae_conv_planes_ok", byref(d2), 0):
+                    dys = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=dev)
+                _conv_launch(d2, dy, None, None, None, None, None, da, dyb, flip_of=(wk, Cout, cfg.kh, cfg.kw, Cin, w_amax),
+                             planes_out=dys)
+            if run_wgrad is not None:
+                run_wgrad(dys)
+                run_wgrad = None
             if cfg.upsample:
                 dlow = new_cl(N, Cin, Hin, Win, dev)
                 call("favae_upsample2x_bwd", ptr(da), ptr(dlow), N, Hin, Win, Cin)
@@ -539,6 +566,8 @@ class FusedConvFn(torch.autograd.Function):
                 call("favae_act_bwd", ptr(da), ptr(x), act, da.numel(), ptr(dx))
             else:
                 dx = da
+        if run_wgrad is not None:                             # no data gradient asked for: nothing to wait for
+            run_wgrad(None)
         if dskip is not None:
             dx = dskip if dx is None else dx + dskip
         dres = dy if ctx.has_res else None

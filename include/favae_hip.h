@@ -327,6 +327,28 @@ int favae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
                     int step, float grad_scale, favae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Pre-split operand planes for the weight gradient (no reference counterpart: the reference's autograd re-reads fp32 tensors).
+ * In the default arithmetic the weight-gradient kernel of a 3x3 conv spends a third of its time turning its two fp32 operands into
+ * scaled fp16 planes (and re-applying GroupNorm+SiLU to x).  The kernels that ALREADY stage exactly these values -- the forward conv
+ * (T(x)) and the data-gradient conv (dy) -- can store them as a by-product: one 16-byte record {hi[4 fp16], lo[4 fp16]} per four
+ * channels, at the byte offset of the fp32 quad, i.e. a buffer of the tensor's own size.  Values are bit-identical to what the
+ * weight-gradient kernel would compute itself, so results do not change.
+ *   favae_conv_planes_ok(d, has_affine)   1 when favae_conv_fwd_split(d, ...) runs the kernel that can store planes
+ *   favae_conv_wgrad_takes_planes(d)      1 when the weight gradient of d runs the kernel that can load them
+ *   favae_conv_fwd_split_planes           favae_conv_fwd_split + planes_out (N*Hin*Win*Cin*4 bytes, 16-byte aligned; may be NULL)
+ *   favae_conv_wgrad_planes               favae_conv_wgrad + x_planes / dy_planes (either may be NULL: that operand is then split
+ *                                         on the fly from the fp32 tensor, which must always be passed)
+ * ---------------------------------------------------------------------------------------------------------- */
+int favae_conv_planes_ok(const favae_conv_desc* d, int has_affine);
+int favae_conv_wgrad_takes_planes(const favae_conv_desc* d);
+int favae_conv_fwd_split_planes(const favae_conv_desc* d, const float* x, const void* wsplit, int planes, const float* x_absmax,
+                                const float* bias, const float* resid, const float* scale, const float* shift, float* y,
+                                void* planes_out, favae_stream_t stream);
+int favae_conv_wgrad_planes(const favae_conv_desc* d, const float* x, const float* dy, const float* scale, const float* shift,
+                            const float* x_absmax, const float* dy_absmax, const void* x_planes, const void* dy_planes, float* dw,
+                            int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Launch profiler (measurement only; no reference counterpart -- the reference is timed from outside by its caller).
  * level 0: off (default).  level 1: every launch that carries >= 1 GFLOP of algorithmic work (the matrix-bound conv forward /
  * data-gradient / weight-gradient kernels) is bracketed by two HIP events recorded on ITS launch stream; level 2: every launch of

@@ -260,6 +260,15 @@ def test_side_stream_weight_gradients_are_race_free(mtag, hw):
     assert torch.isfinite(ref).all() and float(ref.abs().sum()) > 0
     got = grads(True, 400000)                    # ~0.2 ms in front of each of the ~150 side-stream launches
     assert torch.equal(got, ref), "two-stream gradients differ from the single-stream run: %g" % float((got - ref).abs().max())
+    # pre-split operand planes (FAVAE_WGRAD_PLANES=1: forward / data-gradient kernels store their staged operands, the
+    # weight-gradient kernel loads them): the same bits, so the same gradients
+    prev = K._PLANES
+    K._PLANES = True
+    try:
+        got = grads(True, 400000)
+    finally:
+        K._PLANES = prev
+    assert torch.equal(got, ref), "gradients with pre-split planes differ: %g" % float((got - ref).abs().max())
 
 
 def test_gan_stage1_discriminator_alone_against_reference_golden(golden_dir):

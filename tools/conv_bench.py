@@ -28,6 +28,8 @@ def timeit(fn, n=5):
 for cin, cout, hw, k in SHAPES:
     x = torch.randn(B, cin, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(cout, cin, k, k, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    if os.environ.get("CONV_BENCH_ZEROS") == "1":          # power experiment: all-zero operands (no data toggling in the matrix pipe)
+        x.zero_(); w.zero_()
     b = torch.zeros(cout, device=dev)
     gw, gb = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
     mean, rstd, scale, shift, xb = K.gn_stats(x, gw, gb, 32, with_bound=True)
