@@ -821,6 +821,7 @@ extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, co
 static bool planes_producer_ok(const favae_conv_desc* d, bool has_affine) {
     if (!sp_fwd_eligible(d, has_affine) || conv_mode() != 2 || desc_special(d) || !use_halo()) return false;
     const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, wb = (size_t)d->Cout * 9 * d->Cin * 4;
+    if (has_affine && d->act != FAVAE_ACT_NONE && d->act != FAVAE_ACT_SILU) return false;
     return d->Cout > 64 && d->Cin % 16 == 0 && d->stride == 1 && d->gather == FAVAE_GATHER_PLAIN && d->KH == 3 && d->KW == 3 &&
            d->pad == 1 && d->Hout == d->Hin && d->Wout == d->Win && d->Hin % 8 == 0 && d->Win % 16 == 0 && xb < (1u << 31) &&
            wb < (1u << 31) && (size_t)d->N * d->Hout * d->Wout * d->Cout * 4 < ((size_t)1 << 32);
@@ -943,7 +944,11 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         else FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 3, KS>), hgrid, dim3(512), 0, s, a);               \
     } while (0)
 #define FAVAE_LAUNCH_HALO(X) FAVAE_LAUNCH_HALO_K(X, 3)
-        if (halo2_ok) FAVAE_LAUNCH_HALO_K(0, 2);
+        if (planes_out && !(halo_ok && wplanes == 2 && xf != 3)) return FAVAE_ERR_UNSUPPORTED;
+        if (planes_out && xf == 0) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, true>), hgrid, dim3(512), 0, s, a);
+        else if (planes_out && xf == 1) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<1, 2, 3, true>), hgrid, dim3(512), 0, s, a);
+        else if (planes_out) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 2, 3, true>), hgrid, dim3(512), 0, s, a);
+        else if (halo2_ok) FAVAE_LAUNCH_HALO_K(0, 2);
         else if (xf == 0) FAVAE_LAUNCH_HALO(0);
         else if (xf == 1) FAVAE_LAUNCH_HALO(1);
         else if (xf == 2) FAVAE_LAUNCH_HALO(2);

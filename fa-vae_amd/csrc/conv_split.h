@@ -18,104 +18,9 @@
 // pre-split the weights once per call into per-4-float records.
 #pragma once
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-typedef short s16x8_t __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+#include "split_planes.h"
 
 namespace sp {
-constexpr unsigned TOP = 0xFFFF0000u;
-constexpr int WHDR = 256;                  // bytes of header in front of the weight records (float[0] = |max| of the weights)
-
-// S = 2^(14 - floor(log2 amax)) from a device-side maximum (1 for zero / non-finite maxima)
-__device__ __forceinline__ float pow2_scale(const float* amax) {
-    const int e = (int)((__float_as_uint(*amax) & 0x7FFFFFFFu) >> 23);
-    if (e == 0 || e == 255) return 1.f;
-    int se = 268 - e;                      // biased exponent of S
-    se = se < 2 ? 2 : (se > 252 ? 252 : se);
-    return __uint_as_float((unsigned)se << 23);
-}
-__device__ __forceinline__ float pow2_inv(float S) {
-    return __uint_as_float((254u - (__float_as_uint(S) >> 23)) << 23);
-}
-
-template <int NP> struct Scheme;
-
-template <> struct Scheme<3> {
-    static constexpr bool SCALED = false;  // bf16 keeps the fp32 exponent: no operand ranges needed
-    static constexpr int ROWB = 112;       // LDS row: 3 planes x 32 B (16 k) + 16 B pad -> conflict-free ds_read_b128
-    static constexpr int WREC = 24;        // bytes per pre-split 4-float weight record {plane0[4], plane1[4], plane2[4]}
-    // split four consecutive-k floats into three planes of 4 bf16 (2 dwords each), exact by truncation
-    static __device__ __forceinline__ void split4(const float4 v, float, uint2 (&p)[3]) {
-        const float a[4] = {v.x, v.y, v.z, v.w};
-        unsigned h[4], m[4], l[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            h[e] = __float_as_uint(a[e]);
-            const float r1 = a[e] - __uint_as_float(h[e] & TOP);
-            m[e] = __float_as_uint(r1);
-            const float r2 = r1 - __uint_as_float(m[e] & TOP);
-            l[e] = __float_as_uint(r2);
-        }
-        // pack the upper halves of two words: low 16 bits <- even k, high 16 bits <- odd k
-        p[0] = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
-        p[1] = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
-        p[2] = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
-    }
-    // smallest terms first
-    static __device__ __forceinline__ void mma(const bf16x8_t (&a)[3], const bf16x8_t (&b)[3], f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
-    }
-};
-
-template <> struct Scheme<2> {
-    static constexpr bool SCALED = true;
-    static constexpr int ROWB = 80;        // 2 planes x 32 B + 16 B pad (20-bank row stride: conflict-free ds_read_b128)
-    static constexpr int WREC = 16;        // {plane0[4 fp16], plane1[4]}
-    static __device__ __forceinline__ void split4(const float4 v, float S, uint2 (&p)[2]) {
-        const float a[4] = {v.x * S, v.y * S, v.z * S, v.w * S};
-        _Float16 h[4], l[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            h[e] = (_Float16)a[e];                                  // round to nearest
-            l[e] = (_Float16)(a[e] - (float)h[e]);                  // the residual is exact in fp32
-        }
-        const half2_t h01 = {h[0], h[1]}, h23 = {h[2], h[3]}, l01 = {l[0], l[1]}, l23 = {l[2], l[3]};
-        p[0] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
-        p[1] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
-    }
-    static __device__ __forceinline__ void mma(const bf16x8_t (&a)[2], const bf16x8_t (&b)[2], f32x16& c) {
-        const half8_t a0 = __builtin_bit_cast(half8_t, a[0]), a1 = __builtin_bit_cast(half8_t, a[1]);
-        const half8_t b0 = __builtin_bit_cast(half8_t, b[0]), b1 = __builtin_bit_cast(half8_t, b[1]);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
-    }
-};
-
-// "h1": ONE scaled fp16 plane, one MFMA per product block -- the mixed-precision mode (fp16 operands with an 11-bit
-// significand, fp32 accumulation; BASELINE config 5 asks for 16-bit compute).  Same power-of-two scaling as h3, so the fp16
-// exponent range is never the limit.  NOT fp32-grade: per-product relative error ~2^-12 (FAVAE_CONV_MODE=h1 / favae_set_conv_mode(1)).
-template <> struct Scheme<1> {
-    static constexpr bool SCALED = true;
-    static constexpr int ROWB = 48;        // 32 B + 16 B pad (12-bank row stride: 16 consecutive rows hit 16 distinct bank quads)
-    static constexpr int WREC = 8;         // {plane0[4 fp16]}
-    static __device__ __forceinline__ void split4(const float4 v, float S, uint2 (&p)[1]) {
-        const half2_t h01 = {(_Float16)(v.x * S), (_Float16)(v.y * S)}, h23 = {(_Float16)(v.z * S), (_Float16)(v.w * S)};
-        p[0] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
-    }
-    static __device__ __forceinline__ void mma(const bf16x8_t (&a)[1], const bf16x8_t (&b)[1], f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a[0]), __builtin_bit_cast(half8_t, b[0]), c, 0, 0, 0);
-    }
-};
-
 // one pre-split weight record (4 consecutive k) -> NP plane pieces
 template <int NP, typename R>
 __device__ __forceinline__ void load_wrec(R rw, unsigned voff, unsigned soff, uint2 (&p)[NP]) {
@@ -129,22 +34,6 @@ __device__ __forceinline__ void load_wrec(R rw, unsigned voff, unsigned soff, ui
     }
 }
 
-template <int NP>
-__device__ __forceinline__ void store_planes(unsigned char* d, int plane_stride, const uint2 (&p)[NP]) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) *reinterpret_cast<uint2*>(d + i * plane_stride) = p[i];
-}
-
-// ---- transposing fragment reads of the weight-gradient kernels --------------------------------------------------------
-constexpr int RSB = 320;                   // bytes per pixel row of a plane (128 ch x 2 B + 64 B pad: conflict-free tr reads)
-constexpr int PLB = 16 * RSB;              // bytes per plane (16 pixels)
-
-__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* p) {
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + 4 * RSB));
-    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8_t, v);
-}
 }  // namespace sp
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -507,8 +396,9 @@ __global__ __launch_bounds__(256) void split_w_kernel(const float4* __restrict__
 // Per-thread global offsets are constants of the launch: only the scalar offsets advance (K chunk, tap).
 // Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, H % 8 == 0, W % 16 == 0, Cin % 16 == 0, pre-split weights.
 // ---------------------------------------------------------------------------------------------------------------
-template <int XFORM, int NP, int KS = 3>
+template <int XFORM, int NP, int KS = 3, bool PL = false>      // PL: also store the staged operand planes (ConvArgs::planes_out)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6 : 4, 8))) void conv3x3_halo_sp_kernel(ConvArgs a) {
+    static_assert(!PL || (NP == 2 && KS == 3), "operand planes: dense 3x3 conv with two fp16 planes");
     using S = sp::Scheme<NP>;
     // KS = 3: the 3x3 stride-1 pad-1 conv.  KS = 2: a 2x2 phase conv of an Upsample / of the Downsample data gradient (top / left
     // padding a.pad / a.pad_w in {0, 1}, ONE side of the conv on every second pixel of a tensor of twice the size: a.in_* / a.out_*).
@@ -539,7 +429,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
     const auto rw = make_rsrc(a.w, a.w_bytes);
     const auto rsc_d = make_rsrc(XFORM ? a.scale : a.x, XFORM ? a.aff_bytes : 0u);
     const auto rsh_d = make_rsrc(XFORM ? a.shift : a.x, XFORM ? a.aff_bytes : 0u);
-    const auto rpl = make_rsrc(a.planes_out ? a.planes_out : (const void*)a.x, (a.planes_out && tn == 0) ? a.planes_bytes : 0u);
+    const auto rpl = make_rsrc(PL ? a.planes_out : (const void*)a.x, (PL && tn == 0) ? a.planes_bytes : 0u);
 
     // halo staging slots of this thread (720 float4 over 512 threads): constant offsets.  The fused-transform operands
     // (scale, shift) depend on (image, channel quad) only: one load per K chunk serves both slots; padding pixels must
@@ -548,7 +438,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
     int hoff[2];
     bool hok[2], hin[2];
     // planes_out (dense 3x3 convs, two planes): the workgroups of output-channel tile 0 store the interior pixels of their halo
-    const bool wr_planes = NP == 2 && KS == 3;
+    const bool wr_planes = PL;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i = tid + 512 * j;
@@ -594,7 +484,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
     // The record of (pixel, channel quad) goes to the byte offset of the fp32 quad it was made from; non-interior slots (and every
     // slot when no planes were asked for: zero-sized resource) are dropped by the buffer range check.
     auto flush_planes = [&](int buf, int kc) {
-        if constexpr (NP == 2 && KS == 3) {
+        if constexpr (PL) {
             typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -637,7 +527,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
             if (!last_tap) load_b(kc, tap + 1);
             else if (more_kc) load_b(kc + 1, 0);
             if (tap == TAPS / 2 && more_kc) load_halo(kc + 1);           // in flight over the second half of the taps
-            if (tap == 1 && a.planes_out) flush_planes(hb, kc);
+            if (PL && tap == 1) flush_planes(hb, kc);
             const int kh = tap / KS, kw = tap - kh * KS;
             const unsigned char* Ab = Afr + hb * HALO_B + kh * HPITCH + kw * S::ROWB;
             const unsigned char* Bb = Bfr + cur * BT_B;

@@ -59,6 +59,11 @@ SIGNATURES = {
                             c_int64, c_int64, c_int, c_int, _S]),
     "favae_softmax_rows": (c_int, [_P, _P, c_int64, c_int, _S]),
     "favae_softmax_rows_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_float, _S]),
+    "favae_bgemm_sp": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int64, c_int64, _P, _P, c_int64, c_int64, _P, _P,
+                               c_int64, c_int64, c_int, c_int, _S]),
+    "favae_softmax_rows_lse": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_int, _S]),
+    "favae_attn_bwd_point": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_float, _P, _S]),
+    "favae_rowdot": (c_int, [_P, _P, _P, c_int64, c_int, _S]),
     "favae_blur_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _S]),
     "favae_blur_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "favae_blur_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _S]),

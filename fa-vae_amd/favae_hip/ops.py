@@ -797,7 +797,26 @@ class LpipsLevelFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------------------
 # single-head attention core (models/codec.py:92,99): qkv (N,3C,H,W) -> o (N,C,H,W)
 # ---------------------------------------------------------------------------------------------------------------
+_ATTN_TILED = os.environ.get("FAVAE_ATTN_TILED", "1") != "0"      # 0: the materialised fp32-MFMA attention of round 1 (A/B switch)
+_ATTN_CHUNK_ELEMS = 48 << 20        # scores of one query chunk, all images: 192 MB fp32 -- stays in the 256 MB Infinity Cache
+
+
+def _attn_chunk_rows(N, L):
+    rq = _ATTN_CHUNK_ELEMS // (N * L)
+    rq = max(128, (rq // 128) * 128)
+    return min(L, rq)
+
+
 class AttnCoreFn(torch.autograd.Function):
+    """Single-head attention core softmax(q k^T / sqrt(C)) v on the packed in-projection output (N, 3C, H, W) channels-last
+    (F.scaled_dot_product_attention inside nn.MultiheadAttention, models/codec.py:92,99) WITHOUT the (N, L, L) matrices: queries are
+    processed in chunks whose score tile (all images) fits the Infinity Cache; only the row log-sum-exp (N, L) is saved and the
+    backward pass recomputes the probabilities of a chunk as exp(s - lse) (flash-attention recomputation).  Every
+    product runs on the split-precision matrix path (favae_bgemm_sp: fp32-grade products from two scaled fp16 planes): forward
+    2 GEMMs (4 L^2 C FLOP per image), backward 5 (10 L^2 C).  Operand ranges: max|qkv| for q, k, v; 1 for the probabilities;
+    max|dO|; max|dS| from the point-wise backward kernel.
+    f=4 at 256x256 (L = 4096, C = 512, batch 16): 2 x 1.07 GB of saved activations per block less than the materialised version."""
+
     @staticmethod
     def forward(ctx, qkv):
         qkv = to_cl(qkv)
@@ -805,19 +824,55 @@ class AttnCoreFn(torch.autograd.Function):
         C, L = C3 // 3, H * W
         dev = qkv.device
         alpha = 1.0 / math.sqrt(C)
-        P = torch.empty((N, L, L), dtype=torch.float32, device=dev)
         q, k, v = qkv.data_ptr(), qkv.data_ptr() + 4 * C, qkv.data_ptr() + 8 * C
-        call("favae_bgemm", 0, 0, L, L, C, alpha, q, C3, L * C3, k, C3, L * C3, ptr(P), L, L * L, N, 0)
-        call("favae_softmax_rows", ptr(P), ptr(P), N * L, L)
         o = new_cl(N, C, H, W, dev)
-        call("favae_bgemm", 0, 1, L, C, L, 1.0, ptr(P), L, L * L, v, C3, L * C3, ptr(o), C, L * C, N, 0)
-        ctx.save_for_backward(qkv, P)
+        if not (_ATTN_TILED and _fp16_planes() and C % 4 == 0 and L % 4 == 0):
+            P = torch.empty((N, L, L), dtype=torch.float32, device=dev)
+            call("favae_bgemm", 0, 0, L, L, C, alpha, q, C3, L * C3, k, C3, L * C3, ptr(P), L, L * L, N, 0)
+            call("favae_softmax_rows", ptr(P), ptr(P), N * L, L)
+            call("favae_bgemm", 0, 1, L, C, L, 1.0, ptr(P), L, L * L, v, C3, L * C3, ptr(o), C, L * C, N, 0)
+            ctx.tiled = False
+            ctx.save_for_backward(qkv, P)
+            return o
+        amax = absmax(qkv)
+        one = torch.ones((1,), dtype=torch.float32, device=dev)
+        lse = torch.empty((N, L), dtype=torch.float32, device=dev)
+        RQ = _attn_chunk_rows(N, L)
+        S = torch.empty((N * RQ * L,), dtype=torch.float32, device=dev)
+        for r0 in range(0, L, RQ):
+            rq = min(RQ, L - r0)
+            call("favae_bgemm_sp", 0, 0, rq, L, C, alpha, q + 4 * r0 * C3, C3, L * C3, ptr(amax), k, C3, L * C3, ptr(amax), ptr(S), L,
+                 rq * L, N, 0)
+            call("favae_softmax_rows_lse", ptr(S), ptr(lse), N * rq, L, rq, r0, L)
+            call("favae_bgemm_sp", 0, 1, rq, C, L, 1.0, ptr(S), L, rq * L, ptr(one), v, C3, L * C3, ptr(amax), o.data_ptr() + 4 * r0 * C,
+                 C, L * C, N, 0)
+        ctx.tiled = True
+        ctx.save_for_backward(qkv, o, lse, amax, one)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        qkv, P = ctx.saved_tensors
         do = to_cl(do)
+        if not ctx.tiled:
+            qkv, P = ctx.saved_tensors
+            N, C3, H, W = qkv.shape
+            C, L = C3 // 3, H * W
+            dev = qkv.device
+            alpha = 1.0 / math.sqrt(C)
+            dqkv = new_cl(N, C3, H, W, dev)
+            q, k, v = qkv.data_ptr(), qkv.data_ptr() + 4 * C, qkv.data_ptr() + 8 * C
+            dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + 4 * C, dqkv.data_ptr() + 8 * C
+            # dV[j][c] = sum_i P[i][j] dO[i][c]
+            call("favae_bgemm", 1, 1, L, C, L, 1.0, ptr(P), L, L * L, ptr(do), C, L * C, dv, C3, L * C3, N, 0)
+            # dP[i][j] = sum_c dO[i][c] V[j][c]
+            dP = torch.empty((N, L, L), dtype=torch.float32, device=dev)
+            call("favae_bgemm", 0, 0, L, L, C, 1.0, ptr(do), C, L * C, v, C3, L * C3, ptr(dP), L, L * L, N, 0)
+            call("favae_softmax_rows_bwd", ptr(P), ptr(dP), ptr(dP), N * L, L, alpha)      # dS (alpha folded in)
+            # dQ[i][c] = sum_j dS[i][j] K[j][c] ; dK[j][c] = sum_i dS[i][j] Q[i][c]
+            call("favae_bgemm", 0, 1, L, C, L, 1.0, ptr(dP), L, L * L, k, C3, L * C3, dq, C3, L * C3, N, 0)
+            call("favae_bgemm", 1, 1, L, C, L, 1.0, ptr(dP), L, L * L, q, C3, L * C3, dk, C3, L * C3, N, 0)
+            return dqkv
+        qkv, o, lse, amax, one = ctx.saved_tensors
         N, C3, H, W = qkv.shape
         C, L = C3 // 3, H * W
         dev = qkv.device
@@ -825,15 +880,28 @@ class AttnCoreFn(torch.autograd.Function):
         dqkv = new_cl(N, C3, H, W, dev)
         q, k, v = qkv.data_ptr(), qkv.data_ptr() + 4 * C, qkv.data_ptr() + 8 * C
         dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + 4 * C, dqkv.data_ptr() + 8 * C
-        # dV[j][c] = sum_i P[i][j] dO[i][c]
-        call("favae_bgemm", 1, 1, L, C, L, 1.0, ptr(P), L, L * L, ptr(do), C, L * C, dv, C3, L * C3, N, 0)
-        # dP[i][j] = sum_c dO[i][c] V[j][c]
-        dP = torch.empty((N, L, L), dtype=torch.float32, device=dev)
-        call("favae_bgemm", 0, 0, L, L, C, 1.0, ptr(do), C, L * C, v, C3, L * C3, ptr(dP), L, L * L, N, 0)
-        call("favae_softmax_rows_bwd", ptr(P), ptr(dP), ptr(dP), N * L, L, alpha)      # dS (alpha folded in)
-        # dQ[i][c] = sum_j dS[i][j] K[j][c] ; dK[j][c] = sum_i dS[i][j] Q[i][c]
-        call("favae_bgemm", 0, 1, L, C, L, 1.0, ptr(dP), L, L * L, k, C3, L * C3, dq, C3, L * C3, N, 0)
-        call("favae_bgemm", 1, 1, L, C, L, 1.0, ptr(dP), L, L * L, q, C3, L * C3, dk, C3, L * C3, N, 0)
+        dmax = absmax(do)
+        delta = torch.empty((N, L), dtype=torch.float32, device=dev)
+        call("favae_rowdot", ptr(do), ptr(o), ptr(delta), N * L, C)
+        dsmax = torch.empty((1,), dtype=torch.float32, device=dev)
+        RQ = _attn_chunk_rows(N, L)
+        S = torch.empty((N * RQ * L,), dtype=torch.float32, device=dev)
+        dP = torch.empty((N * RQ * L,), dtype=torch.float32, device=dev)
+        for ci, r0 in enumerate(range(0, L, RQ)):
+            rq = min(RQ, L - r0)
+            qc, doc = q + 4 * r0 * C3, do.data_ptr() + 4 * r0 * C
+            # scores of the chunk again, dP = dO V^T, then in place: S <- P = exp(S - lse), dP <- dS = alpha P (dP - delta)
+            call("favae_bgemm_sp", 0, 0, rq, L, C, alpha, qc, C3, L * C3, ptr(amax), k, C3, L * C3, ptr(amax), ptr(S), L, rq * L, N, 0)
+            call("favae_bgemm_sp", 0, 0, rq, L, C, 1.0, doc, C, L * C, ptr(dmax), v, C3, L * C3, ptr(amax), ptr(dP), L, rq * L, N, 0)
+            call("favae_attn_bwd_point", ptr(S), ptr(dP), ptr(lse), ptr(delta), N * rq, L, rq, r0, L, alpha, ptr(dsmax))
+            acc = 1 if ci else 0
+            # dV[j][c] (+)= sum_i P[i][j] dO[i][c]        (contraction over the chunk's queries: both operands [k][rows])
+            call("favae_bgemm_sp", 1, 1, L, C, rq, 1.0, ptr(S), L, rq * L, ptr(one), doc, C, L * C, ptr(dmax), dv, C3, L * C3, N, acc)
+            # dQ[i][c] = sum_j dS[i][j] K[j][c]
+            call("favae_bgemm_sp", 0, 1, rq, C, L, 1.0, ptr(dP), L, rq * L, ptr(dsmax), k, C3, L * C3, ptr(amax), dq + 4 * r0 * C3, C3,
+                 L * C3, N, 0)
+            # dK[j][c] (+)= sum_i dS[i][j] Q[i][c]
+            call("favae_bgemm_sp", 1, 1, L, C, rq, 1.0, ptr(dP), L, rq * L, ptr(dsmax), qc, C3, L * C3, ptr(amax), dk, C3, L * C3, N, acc)
         return dqkv
 
 

@@ -187,6 +187,24 @@ int favae_softmax_rows(const float* s, float* p, int64_t rows, int L, favae_stre
 int favae_softmax_rows_bwd(const float* p, const float* dp, float* ds, int64_t rows, int L, float alpha,
                            favae_stream_t stream);
 
+/* The attention core without the N x L x L probability matrix (flash-style: row log-sum-exp saved, probabilities recomputed in the
+ * backward pass), in query chunks whose score tile stays in the Infinity Cache, on the split-precision matrix path:
+ *   favae_bgemm_sp        favae_bgemm with fp32-grade products on the 16-bit matrix pipe (two scaled fp16 planes per operand,
+ *                         DESIGN.md section 3); amaxA / amaxB: device scalars >= max|A|, max|B|.  Returns FAVAE_ERR_UNSUPPORTED
+ *                         for (ta, tb) = (1, 0), unaligned operands, ld / stride % 4 != 0 (the caller then uses favae_bgemm).
+ *   favae_softmax_rows_lse  in-place softmax of `rows` = batch * rows_per_batch score rows (row r of batch element n = query
+ *                         row0 + r) + lse[n * Ltot + row0 + r] = log-sum-exp of the row
+ *   favae_attn_bwd_point  in place: s <- p = exp(s - lse); dp <- ds = alpha * p * (dp - delta); *ds_absmax = max|ds|
+ *   favae_rowdot          out[r] = sum_c a[r][c] * b[r][c]          (delta = rowsum(dO * O))
+ * Replaces F.scaled_dot_product_attention inside nn.MultiheadAttention (models/codec.py:92,99) and its autograd. */
+int favae_bgemm_sp(int ta, int tb, int M, int N, int K, float alpha, const float* A, int64_t lda, int64_t strideA,
+                   const float* amaxA, const float* B, int64_t ldb, int64_t strideB, const float* amaxB, float* C, int64_t ldc,
+                   int64_t strideC, int batch, int accumulate, favae_stream_t stream);
+int favae_softmax_rows_lse(float* s, float* lse, int64_t rows, int L, int rows_per_batch, int row0, int Ltot, favae_stream_t stream);
+int favae_attn_bwd_point(float* s, float* dp, const float* lse, const float* delta, int64_t rows, int L, int rows_per_batch,
+                         int row0, int Ltot, float alpha, float* ds_absmax, favae_stream_t stream);
+int favae_rowdot(const float* a, const float* b, float* out, int64_t rows, int C, favae_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Learnable-sigma Gaussian blur (depthwise, reflect padding).  Replaces _get_gaussian_kernel1d/2d + F.pad(reflect)
  * + F.conv2d(groups=C)  (models/codec.py:255-277, models/vqgan_fcm.py:20-41).  `sigma` is a device scalar.

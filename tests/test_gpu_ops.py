@@ -316,6 +316,70 @@ def test_attention_core_l256_c512(K):
     check(od, o, 2e-5, "o")
 
 
+def _attn_ref(qkv, gy):
+    """softmax(q k^T / sqrt(C)) v and its gradient on the CPU, in fp64 (the checker)"""
+    N, C3, H, W = qkv.shape
+    C, L = C3 // 3, H * W
+    x = qkv.double().requires_grad_(True)
+    t = x.view(N, C3, L).transpose(1, 2)
+    q, k, v = t.split(C, dim=-1)
+    o = (torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), -1) @ v).transpose(1, 2).reshape(N, C, H, W)
+    (o * gy.double()).sum().backward()
+    return o.detach(), x.grad
+
+
+@pytest.mark.parametrize("N,C,H,W,chunk", [(1, 512, 64, 64, None),      # the f=4 mid-stage AttnBlock: L = 4096, d = 512 (4 query chunks
+                                                                           # of 1024 rows here via the chunk override)
+                                           (2, 512, 16, 16, None),      # the f=16 AttnBlock: L = 256, one chunk
+                                           (2, 64, 12, 20, 128),        # L = 240: ragged last chunk (128 + 112), N x C edge tiles
+                                           (3, 128, 8, 8, None)])
+def test_attention_core_tiled_forward_backward(K, N, C, H, W, chunk):
+    """AttnCoreFn (models/codec.py:87-102 core) keeps no N x L x L tensor: chunked scores, saved row log-sum-exp, probabilities
+    recomputed in the backward pass, all GEMMs on the split-precision path.  Against an fp64 CPU reference:
+    forward <= 2e-5, gradient <= 1e-4 of the tensor maximum (the bars VERDICT r01 item 7 names)."""
+    qkv = rnd((N, 3 * C, H, W), 23, 0.5)
+    gy = rnd((N, C, H, W), 24)
+    o_ref, g_ref = _attn_ref(qkv, gy)
+    prev = K._ATTN_CHUNK_ELEMS
+    if chunk is not None:
+        K._ATTN_CHUNK_ELEMS = chunk * N * H * W
+    elif H * W == 4096:
+        K._ATTN_CHUNK_ELEMS = 1024 * N * H * W
+    try:
+        qd = K.to_cl(qkv.to(dev())).requires_grad_(True)          # channels-last like the in-projection conv's output
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        od = K.AttnCoreFn.apply(qd)
+        saved = torch.cuda.memory_allocated() - base
+        (od * gy.to(dev())).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        K._ATTN_CHUNK_ELEMS = prev
+    check(od, o_ref, 2e-5, "o")
+    check(qd.grad, g_ref, 1e-4, "dqkv")
+    L = H * W
+    if L == 4096:      # nothing of size N L^2 survives the forward pass: o + lse + scalars only (the qkv input is the caller's)
+        assert saved < 1.5 * (N * C * L * 4 + N * L * 4) + (1 << 20), saved
+
+
+def test_attention_core_tiled_matches_materialised(K):
+    """the tiled core against the round-1 materialised fp32-MFMA core on the same input (A/B switch FAVAE_ATTN_TILED)"""
+    qkv = rnd((2, 3 * 256, 16, 16), 25, 0.7)
+    gy = rnd((2, 256, 16, 16), 26)
+    outs = []
+    for tiled in (True, False):
+        prev, K._ATTN_TILED = K._ATTN_TILED, tiled
+        try:
+            qd = qkv.to(dev()).requires_grad_(True)
+            od = K.AttnCoreFn.apply(qd)
+            (od * gy.to(dev())).sum().backward()
+            outs.append((od.detach().cpu(), qd.grad.cpu()))
+        finally:
+            K._ATTN_TILED = prev
+    check(outs[0][0], outs[1][0], 1e-5, "o tiled vs materialised")
+    check(outs[0][1], outs[1][1], 5e-5, "dqkv tiled vs materialised")
+
+
 def test_blur_against_reference_golden(K, golden_dir):
     g = np.load(os.path.join(golden_dir, "blur.npz"))
     tags = sorted({k.split(".")[0] for k in g.files})
