@@ -65,6 +65,17 @@ __device__ __forceinline__ double block_sum_d256(double v, double* red) {
 
 __device__ __forceinline__ float silu_f(float y) { return y / (1.0f + __expf(-y)); }
 
+// d act(y) / dy of the fused input activations (FAVAE_ACT_*: 1 SiLU, 2 LeakyReLU(0.2), 3 ReLU)
+__device__ __forceinline__ float favae_act_grad(float y, int act) {
+    if (act == 1) {
+        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+        return s * (1.0f + y * (1.0f - s));
+    }
+    if (act == 2) return y > 0.f ? 1.0f : 0.2f;
+    if (act == 3) return y > 0.f ? 1.0f : 0.0f;
+    return 1.0f;
+}
+
 // XCD-aware bijective remap of a 1-D block id: each of the 8 XCDs (private L2) gets a contiguous chunk of logical
 // tile ids so that neighbouring tiles (shared halo rows / shared A panels) hit the same L2.  (guide T1, bijective form)
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -108,6 +108,16 @@ struct ConvArgs {
     // weight-gradient kernel, which then loads its operands without any transform / split arithmetic
     void* planes_out;
     unsigned planes_bytes;
+    // conv3x3_halo_sp_kernel<0, 2, 3, false, true> only (data gradient of a conv whose input was GroupNorm(+act)'ed): the epilogue
+    // also forms this tile's share of the two GroupNorm-backward sums S1 = sum dy, S2 = sum dy * xhat (dy = da * act'(y)) from the
+    // da it has in registers and the matching tile of the conv input x -- the streaming pass-1 kernel (2 tensor reads) goes away.
+    const float* gb_x;
+    const float* gb_mean;
+    const float* gb_rstd;
+    const float* gb_gamma;
+    const float* gb_beta;
+    double* gb_part;          // [N][tiles per image][C][2]
+    int gb_groups, gb_act;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -798,9 +808,14 @@ extern "C" int favae_split_weights(const float* in, void* out, int64_t n, int pl
     return FAVAE_OK;
 }
 
+struct GnBwdEpi {              // GroupNorm-backward partial sums in the data-gradient epilogue (ConvArgs::gb_*)
+    const float *x, *mean, *rstd, *gamma, *beta;
+    double* part;
+    int groups, act;
+};
 static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                          const float* scale, const float* shift, float* y, int wplanes, const float* x_amax,
-                         favae_stream_t stream, void* planes_out);
+                         favae_stream_t stream, void* planes_out, const GnBwdEpi* gb = nullptr);
 
 extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const float* w, const float* bias,
                               const float* resid, const float* scale, const float* shift, float* y,
@@ -840,9 +855,29 @@ extern "C" int favae_conv_fwd_split_planes(const favae_conv_desc* d, const float
     return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, planes_out);
 }
 
+// Data gradient of a conv whose INPUT was act(GroupNorm(x)): da = conv(dy, flipped w) as favae_conv_fwd_split, plus, from the
+// epilogue, the per-tile partial sums of the GroupNorm backward (norm.hip: S1 = sum dy, S2 = sum dy xhat with dy = da act'(y))
+// into part[N][tiles][C][2] (double; tiles = (H/8) (W/16) per image) -- favae_gn_act_bwd_tiles consumes them.
+extern "C" int favae_conv_gnbwd_tiles(const favae_conv_desc* d) {
+    if (!desc_ok(d) || !planes_producer_ok(d, false)) return 0;
+    return (d->Hout / 8) * (d->Wout / 16);
+}
+
+extern "C" int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy, const void* wsplit, int planes,
+                                      const float* dy_absmax, float* da, const float* x, const float* mean, const float* rstd,
+                                      const float* gamma, const float* beta, int groups, int act, void* part, size_t part_bytes,
+                                      favae_stream_t stream) {
+    FAVAE_REQUIRE(desc_ok(d) && dy && wsplit && dy_absmax && da && x && mean && rstd && gamma && beta && part && groups > 0);
+    const int tiles = favae_conv_gnbwd_tiles(d);
+    if (!tiles || planes != 2 || d->Cout % groups != 0) return FAVAE_ERR_UNSUPPORTED;
+    if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return FAVAE_ERR_WORKSPACE;
+    GnBwdEpi gb{x, mean, rstd, gamma, beta, (double*)part, groups, act};
+    return conv_fwd_impl(d, dy, (const float*)wsplit, nullptr, nullptr, nullptr, nullptr, da, planes, dy_absmax, stream, nullptr, &gb);
+}
+
 static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                          const float* scale, const float* shift, float* y, int wplanes, const float* x_amax,
-                         favae_stream_t stream, void* planes_out) {
+                         favae_stream_t stream, void* planes_out, const GnBwdEpi* gb) {
     FAVAE_REQUIRE(desc_ok(d) && x && w && y);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     // roofline numerators of this conv: 2*M*Cout*KH*KW*Cin FLOP; one read of x (+ resid), one write of y, the weights
@@ -884,6 +919,11 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     }
     ConvArgs a;
     a.planes_out = planes_out;
+    a.gb_x = nullptr; a.gb_mean = a.gb_rstd = a.gb_gamma = a.gb_beta = nullptr; a.gb_part = nullptr; a.gb_groups = 1; a.gb_act = 0;
+    if (gb) {
+        a.gb_x = gb->x; a.gb_mean = gb->mean; a.gb_rstd = gb->rstd; a.gb_gamma = gb->gamma; a.gb_beta = gb->beta;
+        a.gb_part = gb->part; a.gb_groups = gb->groups; a.gb_act = gb->act;
+    }
     a.x_amax = x_amax; a.w_amax = w;
     a.x = x; a.w = w6 ? (const float*)((const char*)w + sp::WHDR + d->w_rec_offset) : w;
     const bool special = desc_special(d);
@@ -945,6 +985,9 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     } while (0)
 #define FAVAE_LAUNCH_HALO(X) FAVAE_LAUNCH_HALO_K(X, 3)
         if (planes_out && !(halo_ok && wplanes == 2 && xf != 3)) return FAVAE_ERR_UNSUPPORTED;
+        if (gb && !(halo_ok && wplanes == 2 && xf == 0 && !planes_out && !bias && !resid)) return FAVAE_ERR_UNSUPPORTED;
+        if (gb) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, true>), hgrid, dim3(512), 0, s, a);
+        else
         if (planes_out && xf == 0) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, true>), hgrid, dim3(512), 0, s, a);
         else if (planes_out && xf == 1) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<1, 2, 3, true>), hgrid, dim3(512), 0, s, a);
         else if (planes_out) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 2, 3, true>), hgrid, dim3(512), 0, s, a);

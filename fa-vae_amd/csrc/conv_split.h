@@ -396,9 +396,11 @@ __global__ __launch_bounds__(256) void split_w_kernel(const float4* __restrict__
 // Per-thread global offsets are constants of the launch: only the scalar offsets advance (K chunk, tap).
 // Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, H % 8 == 0, W % 16 == 0, Cin % 16 == 0, pre-split weights.
 // ---------------------------------------------------------------------------------------------------------------
-template <int XFORM, int NP, int KS = 3, bool PL = false>      // PL: also store the staged operand planes (ConvArgs::planes_out)
+// PL: also store the staged operand planes (ConvArgs::planes_out).  GB: GroupNorm-backward partial sums in the epilogue (gb_*)
+template <int XFORM, int NP, int KS = 3, bool PL = false, bool GB = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6 : 4, 8))) void conv3x3_halo_sp_kernel(ConvArgs a) {
     static_assert(!PL || (NP == 2 && KS == 3), "operand planes: dense 3x3 conv with two fp16 planes");
+    static_assert(!GB || (XFORM == 0 && KS == 3 && !PL), "GroupNorm-backward sums: plain dense 3x3 data gradient");
     using S = sp::Scheme<NP>;
     // KS = 3: the 3x3 stride-1 pad-1 conv.  KS = 2: a 2x2 phase conv of an Upsample / of the Downsample data gradient (top / left
     // padding a.pad / a.pad_w in {0, 1}, ONE side of the conv on every second pixel of a tensor of twice the size: a.in_* / a.out_*).
@@ -548,21 +550,75 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
 
     float un_a = 1.f, un_w = 1.f;
     if constexpr (S::SCALED) { un_a = sp::pow2_inv(Sa); un_w = sp::pow2_inv(sp::pow2_scale(a.w_amax)); }
+    double gs1[2] = {0.0, 0.0}, gs2[2] = {0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + (lane & 31);
         if (col >= a.Cout) continue;
         const float bv = a.bias ? a.bias[col] : 0.f;
+        // output offsets of this lane's 16 rows: tile row pr >> 4 = 2 wm + (r >> 3), column (r & 3) + 8 ((r >> 2) & 1) + 4 (lane >> 5)
+        const size_t obase = ((size_t)n * a.out_img + (size_t)ty0 * a.out_step * a.out_row + tx0 * a.out_step + a.out_off) * a.Cout + col;
+        float xg[GB ? 16 : 1];
+        if constexpr (GB) {              // the 16 x values first: one batch of independent loads in flight (32-bit offsets)
+            const auto rgx = make_rsrc(a.gb_x, (unsigned)((size_t)a.N * a.out_img * a.Cout * 4));
+            const unsigned ob32 = (unsigned)obase * 4u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                xg[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rgx, ob32 + (unsigned)(((pr >> 4) * a.out_row + (pr & 15)) * a.Cout) * 4u, 0, 0));
+            }
+        }
+        float g_mu = 0.f, g_rs = 0.f, g_ga = 0.f, g_be = 0.f, f1 = 0.f, f2 = 0.f;
+        if constexpr (GB) {
+            const int grp = col / (a.Cout / a.gb_groups);
+            g_mu = a.gb_mean[n * a.gb_groups + grp];
+            g_rs = a.gb_rstd[n * a.gb_groups + grp];
+            g_ga = a.gb_gamma[col];
+            g_be = a.gb_beta[col];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int pr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);          // pixel of the tile
-            const size_t o = ((size_t)n * a.out_img + (size_t)(ty0 + (pr >> 4)) * a.out_step * a.out_row + (tx0 + (pr & 15)) * a.out_step +
-                              a.out_off) * a.Cout + col;
+            const size_t o = obase + ((size_t)(pr >> 4) * a.out_step * a.out_row + (pr & 15) * a.out_step) * a.Cout;
             float v = acc[j][r];
             if constexpr (S::SCALED) v = v * un_a * un_w;
             v += bv;
             if (a.resid) v += a.resid[o];
             a.y[o] = v;
+            if constexpr (GB) {          // v = da at (pixel, channel col); the conv input x has the same shape
+                const float xh = (xg[r] - g_mu) * g_rs;
+                const float dyv = v * favae_act_grad(fmaf(xh, g_ga, g_be), a.gb_act);
+                f1 += dyv;               // 16 terms in fp32, everything above that in fp64
+                f2 = fmaf(dyv, xh, f2);
+            }
+        }
+        if constexpr (GB) { gs1[j] = (double)f1; gs2[j] = (double)f2; }
+    }
+    if constexpr (GB) {
+        // fixed summation order: 16 rows per lane, the two half-waves, then the four pixel-row waves -> one (S1, S2) pair per
+        // channel of this 8x16-pixel tile, reduced over the tiles of the image by gn_bwd_finalize_kernel (deterministic)
+        double* red = reinterpret_cast<double*>(lds);                // [4 wm][128 channels][2]
+        __syncthreads();                                             // the main loop's last LDS reads are done
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            gs1[j] += __shfl_xor(gs1[j], 32, 64);
+            gs2[j] += __shfl_xor(gs2[j], 32, 64);
+            if (lane < 32) {
+                red[(wm * 128 + wn * 64 + j * 32 + lane) * 2] = gs1[j];
+                red[(wm * 128 + wn * 64 + j * 32 + lane) * 2 + 1] = gs2[j];
+            }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < a.Cout) {
+            double u = 0.0, w2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { u += red[(q * 128 + tid) * 2]; w2 += red[(q * 128 + tid) * 2 + 1]; }
+            const int tpi = tiles_w * tiles_h;
+            const int ti = (ty0 / TH) * tiles_w + tx0 / TW;
+            double* out = a.gb_part + (((size_t)n * tpi + ti) * a.Cout + n0 + tid) * 2;
+            out[0] = u;
+            out[1] = w2;
         }
     }
 }

@@ -14,15 +14,7 @@
 
 namespace {
 
-__device__ __forceinline__ float act_grad(float y, int act) {
-    if (act == FAVAE_ACT_SILU) {
-        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
-        return s * (1.0f + y * (1.0f - s));
-    }
-    if (act == FAVAE_ACT_LEAKY02) return y > 0.f ? 1.0f : 0.2f;
-    if (act == FAVAE_ACT_RELU) return y > 0.f ? 1.0f : 0.0f;
-    return 1.0f;
-}
+__device__ __forceinline__ float act_grad(float y, int act) { return favae_act_grad(y, act); }
 
 // part[n][split][c][2] (double): MODE 0: sum x, sum x^2 ; MODE 1: S1, S2 of the backward.
 // VEC: thread = (channel quad, row lane); otherwise thread = (channel, row lane); C > 256*V loops over channel blocks.
@@ -402,22 +394,53 @@ extern "C" int favae_gn_stats(const float* x, const float* gamma, const float* b
     return FAVAE_OK;
 }
 
+// tile_partials > 0: pass 1 was done by the data-gradient conv's epilogue (favae_conv_dgrad_gnbwd): ws starts with
+// part[N][tile_partials][C][2]
+static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, const float* beta, const float* mean,
+                           const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
+                           float* dgamma, float* dbeta, int accumulate, int tile_partials, void* ws, size_t ws_bytes,
+                           favae_stream_t stream);
+
+extern "C" size_t favae_gn_bwd_tiles_workspace(int N, int tiles, int C) {
+    return (size_t)N * tiles * C * 2 * sizeof(double) + acc_bytes(N, C) + 2 * (size_t)N * C * sizeof(float) + 512;
+}
+
 extern "C" int favae_gn_act_bwd(const float* da, const float* x, const float* gamma, const float* beta, const float* mean,
                                 const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
                                 float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes,
                                 favae_stream_t stream) {
+    return gn_act_bwd_impl(da, x, gamma, beta, mean, rstd, N, HW, C, G, act, dx_add, dx, dgamma, dbeta, accumulate, 0, ws, ws_bytes,
+                           stream);
+}
+
+extern "C" int favae_gn_act_bwd_tiles(const float* da, const float* x, const float* gamma, const float* beta, const float* mean,
+                                      const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
+                                      float* dgamma, float* dbeta, int accumulate, int tiles, void* ws, size_t ws_bytes,
+                                      favae_stream_t stream) {
+    FAVAE_REQUIRE(tiles > 0);
+    return gn_act_bwd_impl(da, x, gamma, beta, mean, rstd, N, HW, C, G, act, dx_add, dx, dgamma, dbeta, accumulate, tiles, ws,
+                           ws_bytes, stream);
+}
+
+static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, const float* beta, const float* mean,
+                           const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
+                           float* dgamma, float* dbeta, int accumulate, int tile_partials, void* ws, size_t ws_bytes,
+                           favae_stream_t stream) {
     FAVAE_REQUIRE(da && x && gamma && beta && mean && rstd && dx && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
     FAVAE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr));
-    if (ws_bytes < favae_gn_workspace(N, HW, C)) return FAVAE_ERR_WORKSPACE;
+    if (ws_bytes < (tile_partials ? favae_gn_bwd_tiles_workspace(N, tile_partials, C) : favae_gn_workspace(N, HW, C)))
+        return FAVAE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     double* part = (double*)ws;
-    double* acc = (double*)((char*)ws + part_bytes(N, HW, C));
+    double* acc = (double*)((char*)ws + (tile_partials ? (size_t)N * tile_partials * C * 2 * sizeof(double) : part_bytes(N, HW, C)));
     float* k1 = (float*)((char*)acc + acc_bytes(N, C));
     float* k2 = k1 + (size_t)N * C;
-    launch_partial<1>(x, da, gamma, beta, mean, rstd, part, N, (long)HW, C, G, act, s);
-    FAVAE_CHECK_LAUNCH();
+    if (!tile_partials) {
+        launch_partial<1>(x, da, gamma, beta, mean, rstd, part, N, (long)HW, C, G, act, s);
+        FAVAE_CHECK_LAUNCH();
+    }
     FAVAE_KLAUNCH(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, s, (const double*)part, gamma, k1, k2, acc, (long)HW, C, G,
-                       gn_splits(N, HW));
+                       tile_partials ? tile_partials : gn_splits(N, HW));
     FAVAE_CHECK_LAUNCH();
     if (dgamma) {
         FAVAE_KLAUNCH(gn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)acc, dgamma, dbeta, N, C, accumulate);

@@ -323,7 +323,11 @@ class ConvCfg:
 _PLANES = os.environ.get("FAVAE_WGRAD_PLANES", "0") == "1"
 
 
-def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=None, planes_out=None):
+# GroupNorm-backward pass 1 (two tensor reads per GroupNorm) inside the epilogue of the data-gradient conv (A/B switch)
+_GNBWD_FUSE = os.environ.get("FAVAE_GNBWD_FUSE", "1") != "0"
+
+
+def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=None, planes_out=None, gnbwd=None):
     """conv forward / data gradient.  When the library runs this shape on the split-precision matrix path the weights are
     pre-split once per call (instead of once per tile in the K loop); the fp16 scheme (2 planes) also needs the operand
     range: `x_bound` = device scalar >= max|T(x)| (computed here for an un-transformed operand when not supplied).
@@ -350,15 +354,19 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
             if scale is not None:
                 raise RuntimeError("a transformed conv operand needs its range bound (gn_stats(with_bound=True))")
             x_bound = absmax(x)
-        if planes_out is not None:
+        if gnbwd is not None:                # data gradient + GroupNorm-backward partial sums (favae_conv_dgrad_gnbwd)
+            gx, gmean, grstd, ggw, ggb, ggroups, gact, gws = gnbwd
+            call("favae_conv_dgrad_gnbwd", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(y), ptr(gx), ptr(gmean), ptr(grstd),
+                 ptr(ggw), ptr(ggb), ggroups, gact, ptr(gws), gws.numel())
+        elif planes_out is not None:
             call("favae_conv_fwd_split_planes", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
                  ptr(shift), ptr(y), ptr(planes_out))
         else:
             call("favae_conv_fwd_split", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
                  ptr(shift), ptr(y))
     else:
-        if planes_out is not None:
-            raise RuntimeError("pre-split planes were requested for a conv that does not run on the split matrix path")
+        if planes_out is not None or gnbwd is not None:
+            raise RuntimeError("pre-split planes / fused GroupNorm-backward sums need the split matrix path")
         if w_ohwi is None:
             w_ohwi = _flipped(flip_of)
         call("favae_conv_fwd", byref(d), ptr(x), ptr(w_ohwi), ptr(b), ptr(resid), ptr(scale), ptr(shift), ptr(y))
@@ -533,13 +541,21 @@ class FusedConvFn(torch.autograd.Function):
             else:
                 raise RuntimeError("unsupported conv geometry for the data gradient")
             dys = None
+            gn_tiles, gn_ws = 0, None
             if not phased:
                 da = new_cl(N, Cin, Hv, Wv, dev)
                 d2 = make_conv_desc(N, Ho, Wo, Cout, Hv, Wv, Cin, cfg.kh, cfg.kw, 1, pad2, g2, ACT_NONE, 1)
                 if use_planes and query("favae_conv_planes_ok", byref(d2), 0):
                     dys = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=dev)
+                gnb = None
+                if (_GNBWD_FUSE and has_gn and cfg.norm == "group" and not cfg.upsample and dys is None and mean is not None
+                        and dyb is not None):
+                    gn_tiles = query("favae_conv_gnbwd_tiles", byref(d2))
+                    if gn_tiles:
+                        gn_ws = workspace(query("favae_gn_bwd_tiles_workspace", N, gn_tiles, Cin), dev)
+                        gnb = (x, mean, rstd, gn_w, gn_b, cfg.groups, act, gn_ws)
                 _conv_launch(d2, dy, None, None, None, None, None, da, dyb, flip_of=(wk, Cout, cfg.kh, cfg.kw, Cin, w_amax),
-                             planes_out=dys)
+                             planes_out=dys, gnbwd=gnb)
             if run_wgrad is not None:
                 run_wgrad(dys)
                 run_wgrad = None
@@ -556,10 +572,15 @@ class FusedConvFn(torch.autograd.Function):
                     dgb = torch.empty_like(dgw)
                 # BatchNorm = GroupNorm with one channel per group over the batch folded into the pixel dimension
                 gN, gHW, gG = (1, N * Hin * Win, Cin) if cfg.norm == "batch" else (N, Hin * Win, cfg.groups)
-                ws = workspace(query("favae_gn_workspace", gN, gHW, Cin), dev)
-                call("favae_gn_act_bwd", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin,
-                     gG, act, ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,
-                     ptr(ws), ws.numel())
+                if gn_tiles:                                  # pass 1 came out of the data-gradient conv's epilogue
+                    call("favae_gn_act_bwd_tiles", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin,
+                         gG, act, ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,
+                         gn_tiles, ptr(gn_ws), gn_ws.numel())
+                else:
+                    ws = workspace(query("favae_gn_workspace", gN, gHW, Cin), dev)
+                    call("favae_gn_act_bwd", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin,
+                         gG, act, ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,
+                         ptr(ws), ws.numel())
                 dskip = None                                  # consumed by the kernel (dx = GN-backward + dskip)
             elif ctx.has_xform:                               # activation without normalisation
                 dx = new_cl(N, Cin, Hin, Win, dev)

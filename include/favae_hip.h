@@ -345,6 +345,26 @@ int favae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
                     int step, float grad_scale, favae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * GroupNorm-backward pass 1 inside the data-gradient conv.  The backward of act(GroupNorm(x)) needs, per (image, channel), S1 = sum
+ * dy and S2 = sum dy*xhat with dy = da * act'(y), da = the data gradient of the conv that consumed it.  The dense 3x3 data-gradient
+ * kernel has da in its accumulators: favae_conv_dgrad_gnbwd = favae_conv_fwd_split(d, dy, flipped weights) -> da, whose epilogue
+ * also reads the matching tile of x and writes per-tile partial sums part[N][tiles][C][2] (double, fixed summation order:
+ * deterministic); favae_gn_act_bwd_tiles = favae_gn_act_bwd without its streaming pass 1 (two tensor reads less per GroupNorm).
+ *   favae_conv_gnbwd_tiles(d)       tiles per image ((H/8)(W/16)) when the data gradient `d` runs that kernel, else 0
+ *   favae_gn_bwd_tiles_workspace    bytes of the workspace shared by the two calls: it STARTS with `part`
+ * Reference: autograd of GroupNorm + SiLU in ResnetBlock / NonResnetBlock / final (models/codec.py:38-46,65-73,170-175).
+ * ---------------------------------------------------------------------------------------------------------- */
+int favae_conv_gnbwd_tiles(const favae_conv_desc* d);
+size_t favae_gn_bwd_tiles_workspace(int N, int tiles, int C);
+int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy, const void* wsplit, int planes, const float* dy_absmax,
+                           float* da, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           int groups, int act, void* part, size_t part_bytes, favae_stream_t stream);
+int favae_gn_act_bwd_tiles(const float* da, const float* x, const float* gamma, const float* beta, const float* mean,
+                           const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
+                           float* dgamma, float* dbeta, int accumulate, int tiles, void* ws, size_t ws_bytes,
+                           favae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Pre-split operand planes for the weight gradient (no reference counterpart: the reference's autograd re-reads fp32 tensors).
  * In the default arithmetic the weight-gradient kernel of a 3x3 conv spends a third of its time turning its two fp32 operands into
  * scaled fp16 planes (and re-applying GroupNorm+SiLU to x).  The kernels that ALREADY stage exactly these values -- the forward conv

@@ -240,12 +240,12 @@ def test_side_stream_weight_gradients_are_race_free(mtag, hw):
     from favae_step import TrainStep
     x = O.det_input(2, hw, hw, 31).to(DEV)
 
-    def grads(side_on, delay):
+    def grads(side_on, delay, planes=False, fuse=True):
         model, _, _ = build(mtag)
         ts = TrainStep(model, lr=1e-4)
         model.train()
-        prev = K._SIDE["on"], K._SIDE["delay"]
-        K._SIDE["on"], K._SIDE["delay"] = side_on, delay
+        prev = K._SIDE["on"], K._SIDE["delay"], K._PLANES, K._GNBWD_FUSE
+        K._SIDE["on"], K._SIDE["delay"], K._PLANES, K._GNBWD_FUSE = side_on, delay, planes, fuse
         try:
             ts.gflat.zero_()
             out = ts.losses(x)
@@ -253,7 +253,7 @@ def test_side_stream_weight_gradients_are_race_free(mtag, hw):
             K.sync_side_stream()
             torch.cuda.synchronize()
         finally:
-            K._SIDE["on"], K._SIDE["delay"] = prev
+            K._SIDE["on"], K._SIDE["delay"], K._PLANES, K._GNBWD_FUSE = prev
         assert not K._SIDE["pending"]
         return ts.gflat.clone()
     ref = grads(False, 0)
@@ -261,14 +261,14 @@ def test_side_stream_weight_gradients_are_race_free(mtag, hw):
     got = grads(True, 400000)                    # ~0.2 ms in front of each of the ~150 side-stream launches
     assert torch.equal(got, ref), "two-stream gradients differ from the single-stream run: %g" % float((got - ref).abs().max())
     # pre-split operand planes (FAVAE_WGRAD_PLANES=1: forward / data-gradient kernels store their staged operands, the
-    # weight-gradient kernel loads them): the same bits, so the same gradients
-    prev = K._PLANES
-    K._PLANES = True
-    try:
-        got = grads(True, 400000)
-    finally:
-        K._PLANES = prev
-    assert torch.equal(got, ref), "gradients with pre-split planes differ: %g" % float((got - ref).abs().max())
+    # weight-gradient kernel loads them): the same bits, so the same gradients.  (The GroupNorm-backward sums of the data-gradient
+    # epilogue are a different summation order than the streaming pass, and a conv uses one or the other: compared with both off.)
+    ref2 = grads(False, 0, planes=False, fuse=False)
+    got = grads(True, 400000, planes=True, fuse=False)
+    assert torch.equal(got, ref2), "gradients with pre-split planes differ: %g" % float((got - ref2).abs().max())
+    # and the two GroupNorm-backward formulations agree to rounding
+    scale = float(ref2.abs().max())
+    assert float((ref - ref2).abs().max()) < 2e-5 * scale, float((ref - ref2).abs().max()) / scale
 
 
 def test_gan_stage1_discriminator_alone_against_reference_golden(golden_dir):
