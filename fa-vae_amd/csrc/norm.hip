@@ -172,25 +172,40 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     }
 }
 
-// backward, one block per image: acc[n][c] = sum over splits of (S1,S2); k1/k2 per group
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
-                                                              float* __restrict__ k1, float* __restrict__ k2,
-                                                              double* __restrict__ acc, long HW, int C, int G, int S) {
+// backward, one block (1024 threads) per image: acc[n][c] = sum over splits of (S1,S2); k1/k2 per group.  The S partials of a
+// channel are summed by 1024 / C2 threads (C2 = min(C, 1024)) over interleaved slices, then the slices in ascending order --
+// a fixed order for a given (S, C): deterministic.  (S is ~32 for the streaming pass 1 and (H/8)(W/16) = up to 512 for the
+// per-tile partials of the data-gradient epilogue, where one thread per channel took 60 us.)
+__global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
+                                                               float* __restrict__ k1, float* __restrict__ k2,
+                                                               double* __restrict__ acc, long HW, int C, int G, int S) {
+    __shared__ double sl[2 * 1024];
     const int n = blockIdx.x;
     const int cpg = C / G;
     double* a = acc + (size_t)n * C * 2;
-    for (int c = threadIdx.x; c < C; c += 256) {
+    const int C2 = C < 1024 ? C : 1024, NS = 1024 / C2;           // slices per channel
+    const int ci = threadIdx.x % C2, si = threadIdx.x / C2;
+    for (int c0 = 0; c0 < C; c0 += C2) {
+        const int c = c0 + ci;
         double s1 = 0.0, s2 = 0.0;
-        for (int s = 0; s < S; ++s) {
-            const double* p = part + (((size_t)n * S + s) * C + c) * 2;
-            s1 += p[0];
-            s2 += p[1];
+        if (si < NS && c < C) {
+            for (int s = si; s < S; s += NS) {
+                const double* p = part + (((size_t)n * S + s) * C + c) * 2;
+                s1 += p[0];
+                s2 += p[1];
+            }
         }
-        a[2 * c] = s1;
-        a[2 * c + 1] = s2;
+        sl[2 * threadIdx.x] = s1;
+        sl[2 * threadIdx.x + 1] = s2;
+        __syncthreads();
+        if (si == 0 && c < C) {
+            for (int q = 1; q < NS; ++q) { s1 += sl[2 * (q * C2 + ci)]; s2 += sl[2 * (q * C2 + ci) + 1]; }
+            a[2 * c] = s1;
+            a[2 * c + 1] = s2;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int g = threadIdx.x; g < G; g += 256) {
+    for (int g = threadIdx.x; g < G; g += 1024) {
         double u = 0.0, v = 0.0;
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
             u += (double)gamma[c] * a[2 * c];
@@ -439,7 +454,7 @@ static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, 
         launch_partial<1>(x, da, gamma, beta, mean, rstd, part, N, (long)HW, C, G, act, s);
         FAVAE_CHECK_LAUNCH();
     }
-    FAVAE_KLAUNCH(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, s, (const double*)part, gamma, k1, k2, acc, (long)HW, C, G,
+    FAVAE_KLAUNCH(gn_bwd_finalize_kernel, dim3(N), dim3(1024), 0, s, (const double*)part, gamma, k1, k2, acc, (long)HW, C, G,
                        tile_partials ? tile_partials : gn_splits(N, HW));
     FAVAE_CHECK_LAUNCH();
     if (dgamma) {
