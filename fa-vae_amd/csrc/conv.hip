@@ -118,6 +118,9 @@ struct ConvArgs {
     const float* gb_beta;
     double* gb_part;          // [N][tiles per image][C][2]
     int gb_groups, gb_act;
+    // conv3x3_halo_sp_kernel<., 2, 3, false, false, true>: per-tile sums (sum y, sum y^2) per output channel of the FINAL output
+    // (bias and residual included) -- pass 1 of the GroupNorm that consumes this conv's output (gn_partial<0>: one tensor read)
+    double* gs_part;          // [N][tiles per image][Cout][2]
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -815,7 +818,7 @@ struct GnBwdEpi {              // GroupNorm-backward partial sums in the data-gr
 };
 static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                          const float* scale, const float* shift, float* y, int wplanes, const float* x_amax,
-                         favae_stream_t stream, void* planes_out, const GnBwdEpi* gb = nullptr);
+                         favae_stream_t stream, void* planes_out, const GnBwdEpi* gb = nullptr, double* stats_part = nullptr);
 
 extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const float* w, const float* bias,
                               const float* resid, const float* scale, const float* shift, float* y,
@@ -863,6 +866,25 @@ extern "C" int favae_conv_gnbwd_tiles(const favae_conv_desc* d) {
     return (d->Hout / 8) * (d->Wout / 16);
 }
 
+// Forward conv that also emits pass 1 of the GroupNorm consuming its output: per-tile (sum y, sum y^2) per channel into
+// part[N][tiles][Cout][2] (double); favae_gn_stats_tiles turns them into the statistics (norm.hip).
+extern "C" int favae_conv_stats_tiles(const favae_conv_desc* d, int has_affine) {
+    if (!desc_ok(d) || !planes_producer_ok(d, has_affine != 0)) return 0;
+    if (has_affine && d->act != FAVAE_ACT_SILU) return 0;
+    return (d->Hout / 8) * (d->Wout / 16);
+}
+
+extern "C" int favae_conv_fwd_split_stats(const favae_conv_desc* d, const float* x, const void* wsplit, int planes,
+                                          const float* x_absmax, const float* bias, const float* resid, const float* scale,
+                                          const float* shift, float* y, void* part, size_t part_bytes, favae_stream_t stream) {
+    FAVAE_REQUIRE(desc_ok(d) && wsplit && x_absmax && part);
+    const int tiles = favae_conv_stats_tiles(d, scale != nullptr);
+    if (!tiles || planes != 2) return FAVAE_ERR_UNSUPPORTED;
+    if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return FAVAE_ERR_WORKSPACE;
+    return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr, nullptr,
+                         (double*)part);
+}
+
 extern "C" int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy, const void* wsplit, int planes,
                                       const float* dy_absmax, float* da, const float* x, const float* mean, const float* rstd,
                                       const float* gamma, const float* beta, int groups, int act, void* part, size_t part_bytes,
@@ -877,7 +899,7 @@ extern "C" int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy,
 
 static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                          const float* scale, const float* shift, float* y, int wplanes, const float* x_amax,
-                         favae_stream_t stream, void* planes_out, const GnBwdEpi* gb) {
+                         favae_stream_t stream, void* planes_out, const GnBwdEpi* gb, double* stats_part) {
     FAVAE_REQUIRE(desc_ok(d) && x && w && y);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     // roofline numerators of this conv: 2*M*Cout*KH*KW*Cin FLOP; one read of x (+ resid), one write of y, the weights
@@ -920,6 +942,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     ConvArgs a;
     a.planes_out = planes_out;
     a.gb_x = nullptr; a.gb_mean = a.gb_rstd = a.gb_gamma = a.gb_beta = nullptr; a.gb_part = nullptr; a.gb_groups = 1; a.gb_act = 0;
+    a.gs_part = stats_part;
     if (gb) {
         a.gb_x = gb->x; a.gb_mean = gb->mean; a.gb_rstd = gb->rstd; a.gb_gamma = gb->gamma; a.gb_beta = gb->beta;
         a.gb_part = gb->part; a.gb_groups = gb->groups; a.gb_act = gb->act;
@@ -986,7 +1009,10 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
 #define FAVAE_LAUNCH_HALO(X) FAVAE_LAUNCH_HALO_K(X, 3)
         if (planes_out && !(halo_ok && wplanes == 2 && xf != 3)) return FAVAE_ERR_UNSUPPORTED;
         if (gb && !(halo_ok && wplanes == 2 && xf == 0 && !planes_out && !bias && !resid)) return FAVAE_ERR_UNSUPPORTED;
+        if (stats_part && !(halo_ok && wplanes == 2 && (xf == 0 || xf == 2) && !planes_out && !gb)) return FAVAE_ERR_UNSUPPORTED;
         if (gb) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (stats_part && xf == 0) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (stats_part) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 2, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
         else
         if (planes_out && xf == 0) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, true>), hgrid, dim3(512), 0, s, a);
         else if (planes_out && xf == 1) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<1, 2, 3, true>), hgrid, dim3(512), 0, s, a);

@@ -397,10 +397,12 @@ __global__ __launch_bounds__(256) void split_w_kernel(const float4* __restrict__
 // Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, H % 8 == 0, W % 16 == 0, Cin % 16 == 0, pre-split weights.
 // ---------------------------------------------------------------------------------------------------------------
 // PL: also store the staged operand planes (ConvArgs::planes_out).  GB: GroupNorm-backward partial sums in the epilogue (gb_*)
-template <int XFORM, int NP, int KS = 3, bool PL = false, bool GB = false>
+// SE: per-tile (sum y, sum y^2) of the output in the epilogue (gs_part): pass 1 of the GroupNorm that consumes this conv's output
+template <int XFORM, int NP, int KS = 3, bool PL = false, bool GB = false, bool SE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6 : 4, 8))) void conv3x3_halo_sp_kernel(ConvArgs a) {
     static_assert(!PL || (NP == 2 && KS == 3), "operand planes: dense 3x3 conv with two fp16 planes");
     static_assert(!GB || (XFORM == 0 && KS == 3 && !PL), "GroupNorm-backward sums: plain dense 3x3 data gradient");
+    static_assert(!SE || (KS == 3 && !PL && !GB && NP == 2), "output statistics: dense 3x3 forward conv");
     using S = sp::Scheme<NP>;
     // KS = 3: the 3x3 stride-1 pad-1 conv.  KS = 2: a 2x2 phase conv of an Upsample / of the Downsample data gradient (top / left
     // padding a.pad / a.pad_w in {0, 1}, ONE side of the conv on every second pixel of a tensor of twice the size: a.in_* / a.out_*).
@@ -592,10 +594,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
                 f1 += dyv;               // 16 terms in fp32, everything above that in fp64
                 f2 = fmaf(dyv, xh, f2);
             }
+            if constexpr (SE) {          // statistics feed E[y^2] - mean^2: fp64 from the first product on (norm.hip)
+                gs1[j] += (double)v;
+                gs2[j] += (double)v * (double)v;
+            }
         }
         if constexpr (GB) { gs1[j] = (double)f1; gs2[j] = (double)f2; }
     }
-    if constexpr (GB) {
+    if constexpr (GB || SE) {
         // fixed summation order: 16 rows per lane, the two half-waves, then the four pixel-row waves -> one (S1, S2) pair per
         // channel of this 8x16-pixel tile, reduced over the tiles of the image by gn_bwd_finalize_kernel (deterministic)
         double* red = reinterpret_cast<double*>(lds);                // [4 wm][128 channels][2]
@@ -616,7 +622,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
             for (int q = 0; q < 4; ++q) { u += red[(q * 128 + tid) * 2]; w2 += red[(q * 128 + tid) * 2 + 1]; }
             const int tpi = tiles_w * tiles_h;
             const int ti = (ty0 / TH) * tiles_w + tx0 / TW;
-            double* out = a.gb_part + (((size_t)n * tpi + ti) * a.Cout + n0 + tid) * 2;
+            double* out = (GB ? a.gb_part : a.gs_part) + (((size_t)n * tpi + ti) * a.Cout + n0 + tid) * 2;
             out[0] = u;
             out[1] = w2;
         }

@@ -120,27 +120,43 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     }
 }
 
-// one block per image: sum the splits per channel -> acc[n][c][2] (double), then group statistics + per-channel affine
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ mean,
-                                                          float* __restrict__ rstd, float* __restrict__ scale,
-                                                          float* __restrict__ shift, double* __restrict__ acc, long HW, int C,
-                                                          int G, int S, float eps, unsigned* __restrict__ absmax) {
+// one block (1024 threads) per image: sum the splits per channel -> acc[n][c][2] (double), then group statistics + per-channel
+// affine.  Split sums as in gn_bwd_finalize_kernel: 1024 / min(C, 1024) interleaved slices per channel, slices added in ascending
+// order (deterministic); S is ~32 for the streaming pass and (H/8)(W/16) for tile partials from a conv epilogue.
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ mean,
+                                                           float* __restrict__ rstd, float* __restrict__ scale,
+                                                           float* __restrict__ shift, double* __restrict__ acc, long HW, int C,
+                                                           int G, int S, float eps, unsigned* __restrict__ absmax) {
+    __shared__ double sl[2 * 1024];
     const int n = blockIdx.x;
     const int cpg = C / G;
     double* a = acc + (size_t)n * C * 2;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int s = 0; s < S; ++s) {
-            const double* p = part + (((size_t)n * S + s) * C + c) * 2;
-            s1 += p[0];
-            s2 += p[1];
+    {
+        const int C2 = C < 1024 ? C : 1024, NS = 1024 / C2;
+        const int ci = threadIdx.x % C2, si = threadIdx.x / C2;
+        for (int c0 = 0; c0 < C; c0 += C2) {
+            const int c = c0 + ci;
+            double s1 = 0.0, s2 = 0.0;
+            if (si < NS && c < C) {
+                for (int s = si; s < S; s += NS) {
+                    const double* p = part + (((size_t)n * S + s) * C + c) * 2;
+                    s1 += p[0];
+                    s2 += p[1];
+                }
+            }
+            sl[2 * threadIdx.x] = s1;
+            sl[2 * threadIdx.x + 1] = s2;
+            __syncthreads();
+            if (si == 0 && c < C) {
+                for (int q = 1; q < NS; ++q) { s1 += sl[2 * (q * C2 + ci)]; s2 += sl[2 * (q * C2 + ci) + 1]; }
+                a[2 * c] = s1;
+                a[2 * c + 1] = s2;
+            }
+            __syncthreads();
         }
-        a[2 * c] = s1;
-        a[2 * c + 1] = s2;
     }
-    __syncthreads();
-    for (int g = threadIdx.x; g < G; g += 256) {
+    for (int g = threadIdx.x; g < G; g += 1024) {
         double s1 = 0.0, s2 = 0.0;
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s1 += a[2 * c]; s2 += a[2 * c + 1]; }
         const double cnt = (double)cpg * (double)HW;
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
         // |gamma (x - mu) rstd + beta| <= |gamma| sqrt(count) + |beta|  (sum of squares of the normalised group = count), and
         // |SiLU(t)|, |LeakyReLU(t)| <= |t|: an upper bound of the transformed activations for the fp16 split scale (conv_split.h)
         const float root = sqrtf((float)cpg * (float)HW);
-        for (int c = threadIdx.x; c < C; c += 256) {
+        for (int c = threadIdx.x; c < C; c += 1024) {
             const int g = c / cpg;
             const float mu = mean[n * G + g], rs = rstd[n * G + g];
             const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
@@ -403,8 +419,25 @@ extern "C" int favae_gn_stats(const float* x, const float* gamma, const float* b
     if (absmax_out && hipMemsetAsync(absmax_out, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
     launch_partial<0>(x, nullptr, gamma, beta, nullptr, nullptr, part, N, (long)HW, C, G, 0, s);
     FAVAE_CHECK_LAUNCH();
-    FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N), dim3(256), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
+    FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N), dim3(1024), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
                        acc, (long)HW, C, G, gn_splits(N, HW), eps, (unsigned*)absmax_out);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+// GroupNorm statistics from per-tile partial sums part[N][tiles][C][2] (double) that the conv producing x emitted from its
+// epilogue (favae_conv_fwd_split_stats): the streaming pass over x is not needed.  ws: favae_gn_workspace(N, HW, C) bytes.
+extern "C" int favae_gn_stats_tiles(const void* part, int tiles, const float* gamma, const float* beta, int N, int64_t HW, int C,
+                                    int G, float eps, float* mean, float* rstd, float* scale, float* shift, float* absmax_out,
+                                    void* ws, size_t ws_bytes, favae_stream_t stream) {
+    FAVAE_REQUIRE(part && tiles > 0 && mean && rstd && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
+    FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
+    FAVAE_REQUIRE(!absmax_out || scale);
+    if (ws_bytes < acc_bytes(N, C)) return FAVAE_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (absmax_out && hipMemsetAsync(absmax_out, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
+    FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N), dim3(1024), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
+                       (double*)ws, (long)HW, C, G, tiles, eps, (unsigned*)absmax_out);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }

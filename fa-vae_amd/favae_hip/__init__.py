@@ -100,6 +100,9 @@ SIGNATURES = {
     "favae_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     "favae_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     "favae_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _S]),
+    "favae_conv_stats_tiles": (c_int, [POINTER(ConvDesc), c_int]),
+    "favae_conv_fwd_split_stats": (c_int, [POINTER(ConvDesc), _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _S]),
+    "favae_gn_stats_tiles": (c_int, [_P, c_int, _P, _P, c_int, c_int64, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _S]),
     "favae_conv_gnbwd_tiles": (c_int, [POINTER(ConvDesc)]),
     "favae_gn_bwd_tiles_workspace": (c_size_t, [c_int, c_int, c_int]),
     "favae_conv_dgrad_gnbwd": (c_int, [POINTER(ConvDesc), _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _S]),

@@ -132,9 +132,15 @@ def weight_ohwi(w):
 # ---------------------------------------------------------------------------------------------------------------
 # GroupNorm statistics (no autograd by itself; used inside FusedConv)
 # ---------------------------------------------------------------------------------------------------------------
+# per-tile (sum y, sum y^2) emitted by the conv that produced a tensor ride on the tensor object as `_favae_gnstats`
+_GNSTATS_FUSE = os.environ.get("FAVAE_GNSTATS_FUSE", "1") != "0"
+
+
 def gn_stats(x, gamma, beta, groups, eps=1e-5, with_bound=False):
     """GroupNorm statistics + the per-(image, channel) affine the conv kernels apply on load.  with_bound: also return the
-    device scalar bounding |act(GN(x))| that the fp16 split-precision conv kernels scale their operand with."""
+    device scalar bounding |act(GN(x))| that the fp16 split-precision conv kernels scale their operand with.
+    When the conv that produced x left its per-tile partial sums on the tensor (FusedConvFn.forward), the streaming pass over x is
+    skipped and only the finalize kernel runs."""
     N, C, H, W = x.shape
     dev = x.device
     mean = torch.empty((N, groups), dtype=torch.float32, device=dev)
@@ -144,8 +150,13 @@ def gn_stats(x, gamma, beta, groups, eps=1e-5, with_bound=False):
     bound = torch.empty((1,), dtype=torch.float32, device=dev) if with_bound else None
     nb = query("favae_gn_workspace", N, H * W, C)
     ws = workspace(nb, dev)
-    call("favae_gn_stats", ptr(x), ptr(gamma), ptr(beta), N, H * W, C, groups, eps, ptr(mean), ptr(rstd), ptr(scale),
-         ptr(shift), ptr(bound), ptr(ws), ws.numel())
+    pre = getattr(x, "_favae_gnstats", None) if _GNSTATS_FUSE else None
+    if pre is not None and pre[0].numel() == N * pre[1] * C * 2 and pre[2] == x._version:
+        call("favae_gn_stats_tiles", ptr(pre[0]), pre[1], ptr(gamma), ptr(beta), N, H * W, C, groups, eps, ptr(mean), ptr(rstd),
+             ptr(scale), ptr(shift), ptr(bound), ptr(ws), ws.numel())
+    else:
+        call("favae_gn_stats", ptr(x), ptr(gamma), ptr(beta), N, H * W, C, groups, eps, ptr(mean), ptr(rstd), ptr(scale),
+             ptr(shift), ptr(bound), ptr(ws), ws.numel())
     if with_bound:
         return mean, rstd, scale, shift, bound
     return mean, rstd, scale, shift
@@ -327,7 +338,7 @@ _PLANES = os.environ.get("FAVAE_WGRAD_PLANES", "0") == "1"
 _GNBWD_FUSE = os.environ.get("FAVAE_GNBWD_FUSE", "1") != "0"
 
 
-def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=None, planes_out=None, gnbwd=None):
+def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=None, planes_out=None, gnbwd=None, stats_out=None):
     """conv forward / data gradient.  When the library runs this shape on the split-precision matrix path the weights are
     pre-split once per call (instead of once per tile in the K loop); the fp16 scheme (2 planes) also needs the operand
     range: `x_bound` = device scalar >= max|T(x)| (computed here for an un-transformed operand when not supplied).
@@ -361,12 +372,15 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
         elif planes_out is not None:
             call("favae_conv_fwd_split_planes", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
                  ptr(shift), ptr(y), ptr(planes_out))
+        elif stats_out is not None:          # forward + per-tile statistics of the output (pass 1 of the next GroupNorm)
+            call("favae_conv_fwd_split_stats", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
+                 ptr(shift), ptr(y), ptr(stats_out), stats_out.numel() * 8)
         else:
             call("favae_conv_fwd_split", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
                  ptr(shift), ptr(y))
     else:
-        if planes_out is not None or gnbwd is not None:
-            raise RuntimeError("pre-split planes / fused GroupNorm-backward sums need the split matrix path")
+        if planes_out is not None or gnbwd is not None or stats_out is not None:
+            raise RuntimeError("pre-split planes / fused GroupNorm sums need the split matrix path")
         if w_ohwi is None:
             w_ohwi = _flipped(flip_of)
         call("favae_conv_fwd", byref(d), ptr(x), ptr(w_ohwi), ptr(b), ptr(resid), ptr(scale), ptr(shift), ptr(y))
@@ -426,7 +440,16 @@ class FusedConvFn(torch.autograd.Function):
         if (_PLANES and ctx.needs_input_grad[1] and query("favae_conv_planes_ok", byref(d), 0 if scale is None else 1)
                 and query("favae_conv_wgrad_takes_planes", byref(d))):
             xs = torch.empty((N, Hin, Win, Cin), dtype=torch.float32, device=dev)
-        w_amax = _conv_launch(d, x, wk, b, resid, scale, shift, y, xb, planes_out=xs)
+        # per-tile (sum y, sum y^2) of the output for the GroupNorm that will consume it (almost every 3x3 conv feeds one)
+        st_tiles = 0
+        st_part = None
+        if _GNSTATS_FUSE and xs is None:
+            st_tiles = query("favae_conv_stats_tiles", byref(d), 0 if scale is None else 1)
+            if st_tiles:
+                st_part = torch.empty((N * st_tiles * Cout * 2,), dtype=torch.float64, device=dev)
+        w_amax = _conv_launch(d, x, wk, b, resid, scale, shift, y, xb, planes_out=xs, stats_out=st_part)
+        if st_part is not None:
+            y._favae_gnstats = (st_part, st_tiles, y._version)
         ctx.cfg = cfg
         ctx.has_b = b is not None
         ctx.has_gn = gn_w is not None

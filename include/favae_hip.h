@@ -345,6 +345,21 @@ int favae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
                     int step, float grad_scale, favae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * GroupNorm statistics pass inside the conv that PRODUCES the normalised tensor.  nn.GroupNorm (models/codec.py:38,42,92,171)
+ * needs per (image, group) the mean and variance of its input, which is the output of the previous conv: the dense 3x3 forward
+ * kernel sums y and y^2 per channel over its 8x16-pixel tile in the epilogue (fp64 from the first product, fixed order:
+ * deterministic) into part[N][tiles][Cout][2], and favae_gn_stats_tiles finishes the statistics without reading the tensor.
+ *   favae_conv_stats_tiles(d, has_affine)   tiles per image when favae_conv_fwd_split(d, ...) runs that kernel, else 0
+ * ---------------------------------------------------------------------------------------------------------- */
+int favae_conv_stats_tiles(const favae_conv_desc* d, int has_affine);
+int favae_conv_fwd_split_stats(const favae_conv_desc* d, const float* x, const void* wsplit, int planes, const float* x_absmax,
+                               const float* bias, const float* resid, const float* scale, const float* shift, float* y,
+                               void* part, size_t part_bytes, favae_stream_t stream);
+int favae_gn_stats_tiles(const void* part, int tiles, const float* gamma, const float* beta, int N, int64_t HW, int C, int G,
+                         float eps, float* mean, float* rstd, float* scale, float* shift, float* absmax_out, void* ws,
+                         size_t ws_bytes, favae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * GroupNorm-backward pass 1 inside the data-gradient conv.  The backward of act(GroupNorm(x)) needs, per (image, channel), S1 = sum
  * dy and S2 = sum dy*xhat with dy = da * act'(y), da = the data gradient of the conv that consumed it.  The dense 3x3 data-gradient
  * kernel has da in its accumulators: favae_conv_dgrad_gnbwd = favae_conv_fwd_split(d, dy, flipped weights) -> da, whose epilogue
