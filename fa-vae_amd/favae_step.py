@@ -11,6 +11,11 @@ MI355X-first choices:
   * the input batch is converted to channels-last once; every activation stays NHWC in HBM;
   * no host synchronisation inside the step: losses stay on the device (the reference's ten .item() calls per step,
     train_favae.py:118-119, are left to the caller's logging cadence).
+
+Epoch-dependent switches of the reference (disc_start_epochs, ffl_start_epochs, train_favae.py:82,93,108) are fixed per TrainStep
+(`train_disc`, `ffl_weight` / `dsl_weight` at construction): at such an epoch boundary build a new TrainStep on the same model and
+carry the optimizer state over with opt_g_state_dict() / opt_d_state_dict() -> load_opt_state_dicts(); opt_g and opt_d keep separate
+step counts (`t`, `t_d`), as the reference's two Adam instances do.
 """
 import torch
 import torch.distributed as dist
