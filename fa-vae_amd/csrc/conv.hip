@@ -836,8 +836,14 @@ extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, co
 
 // producer side of the pre-split operand planes: 1 when favae_conv_fwd_split(d, ...) runs the dense 3x3 halo kernel with two fp16
 // planes -- the kernel that can store its staged operand as a by-product (ConvArgs::planes_out)
-static bool planes_producer_ok(const favae_conv_desc* d, bool has_affine) {
-    if (!sp_fwd_eligible(d, has_affine) || conv_mode() != 2 || desc_special(d) || !use_halo()) return false;
+// 1 when favae_conv_fwd_split(d, ...) runs the dense 3x3 halo kernel with fp16 planes (two: h3, or one: h1) -- the kernel whose
+// epilogue can emit GroupNorm sums (SE / GB variants)
+static bool halo3_fp16_ok(const favae_conv_desc* d, bool has_affine);
+
+static bool planes_producer_ok(const favae_conv_desc* d, bool has_affine) { return conv_mode() == 2 && halo3_fp16_ok(d, has_affine); }
+
+static bool halo3_fp16_ok(const favae_conv_desc* d, bool has_affine) {
+    if (!sp_fwd_eligible(d, has_affine) || (conv_mode() != 2 && conv_mode() != 1) || desc_special(d) || !use_halo()) return false;
     const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, wb = (size_t)d->Cout * 9 * d->Cin * 4;
     if (has_affine && d->act != FAVAE_ACT_NONE && d->act != FAVAE_ACT_SILU) return false;
     return d->Cout > 64 && d->Cin % 16 == 0 && d->stride == 1 && d->gather == FAVAE_GATHER_PLAIN && d->KH == 3 && d->KW == 3 &&
@@ -862,14 +868,14 @@ extern "C" int favae_conv_fwd_split_planes(const favae_conv_desc* d, const float
 // epilogue, the per-tile partial sums of the GroupNorm backward (norm.hip: S1 = sum dy, S2 = sum dy xhat with dy = da act'(y))
 // into part[N][tiles][C][2] (double; tiles = (H/8) (W/16) per image) -- favae_gn_act_bwd_tiles consumes them.
 extern "C" int favae_conv_gnbwd_tiles(const favae_conv_desc* d) {
-    if (!desc_ok(d) || !planes_producer_ok(d, false)) return 0;
+    if (!desc_ok(d) || !halo3_fp16_ok(d, false)) return 0;
     return (d->Hout / 8) * (d->Wout / 16);
 }
 
 // Forward conv that also emits pass 1 of the GroupNorm consuming its output: per-tile (sum y, sum y^2) per channel into
 // part[N][tiles][Cout][2] (double); favae_gn_stats_tiles turns them into the statistics (norm.hip).
 extern "C" int favae_conv_stats_tiles(const favae_conv_desc* d, int has_affine) {
-    if (!desc_ok(d) || !planes_producer_ok(d, has_affine != 0)) return 0;
+    if (!desc_ok(d) || !halo3_fp16_ok(d, has_affine != 0)) return 0;
     if (has_affine && d->act != FAVAE_ACT_SILU) return 0;
     return (d->Hout / 8) * (d->Wout / 16);
 }
@@ -879,7 +885,7 @@ extern "C" int favae_conv_fwd_split_stats(const favae_conv_desc* d, const float*
                                           const float* shift, float* y, void* part, size_t part_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && wsplit && x_absmax && part);
     const int tiles = favae_conv_stats_tiles(d, scale != nullptr);
-    if (!tiles || planes != 2) return FAVAE_ERR_UNSUPPORTED;
+    if (!tiles || (planes != 2 && planes != 1)) return FAVAE_ERR_UNSUPPORTED;
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return FAVAE_ERR_WORKSPACE;
     return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr, nullptr,
                          (double*)part);
@@ -891,7 +897,7 @@ extern "C" int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy,
                                       favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && dy && wsplit && dy_absmax && da && x && mean && rstd && gamma && beta && part && groups > 0);
     const int tiles = favae_conv_gnbwd_tiles(d);
-    if (!tiles || planes != 2 || d->Cout % groups != 0) return FAVAE_ERR_UNSUPPORTED;
+    if (!tiles || (planes != 2 && planes != 1) || d->Cout % groups != 0) return FAVAE_ERR_UNSUPPORTED;
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return FAVAE_ERR_WORKSPACE;
     GnBwdEpi gb{x, mean, rstd, gamma, beta, (double*)part, groups, act};
     return conv_fwd_impl(d, dy, (const float*)wsplit, nullptr, nullptr, nullptr, nullptr, da, planes, dy_absmax, stream, nullptr, &gb);
@@ -1008,11 +1014,15 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     } while (0)
 #define FAVAE_LAUNCH_HALO(X) FAVAE_LAUNCH_HALO_K(X, 3)
         if (planes_out && !(halo_ok && wplanes == 2 && xf != 3)) return FAVAE_ERR_UNSUPPORTED;
-        if (gb && !(halo_ok && wplanes == 2 && xf == 0 && !planes_out && !bias && !resid)) return FAVAE_ERR_UNSUPPORTED;
-        if (stats_part && !(halo_ok && wplanes == 2 && (xf == 0 || xf == 2) && !planes_out && !gb)) return FAVAE_ERR_UNSUPPORTED;
-        if (gb) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, true>), hgrid, dim3(512), 0, s, a);
-        else if (stats_part && xf == 0) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
-        else if (stats_part) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 2, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
+        const bool fp16p = wplanes == 2 || wplanes == 1;
+        if (gb && !(halo_ok && fp16p && xf == 0 && !planes_out && !bias && !resid)) return FAVAE_ERR_UNSUPPORTED;
+        if (stats_part && !(halo_ok && fp16p && (xf == 0 || xf == 2) && !planes_out && !gb)) return FAVAE_ERR_UNSUPPORTED;
+        if (gb && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (gb) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 1, 3, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (stats_part && xf == 0 && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (stats_part && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 2, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (stats_part && xf == 0) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 1, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (stats_part) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 1, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
         else
         if (planes_out && xf == 0) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, true>), hgrid, dim3(512), 0, s, a);
         else if (planes_out && xf == 1) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<1, 2, 3, true>), hgrid, dim3(512), 0, s, a);

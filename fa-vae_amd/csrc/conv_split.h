@@ -402,7 +402,8 @@ template <int XFORM, int NP, int KS = 3, bool PL = false, bool GB = false, bool 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6 : 4, 8))) void conv3x3_halo_sp_kernel(ConvArgs a) {
     static_assert(!PL || (NP == 2 && KS == 3), "operand planes: dense 3x3 conv with two fp16 planes");
     static_assert(!GB || (XFORM == 0 && KS == 3 && !PL), "GroupNorm-backward sums: plain dense 3x3 data gradient");
-    static_assert(!SE || (KS == 3 && !PL && !GB && NP == 2), "output statistics: dense 3x3 forward conv");
+    static_assert(!SE || (KS == 3 && !PL && !GB && NP <= 2), "output statistics: dense 3x3 forward conv, fp16 planes");
+    static_assert(!GB || NP <= 2, "GroupNorm-backward sums: fp16 planes");
     using S = sp::Scheme<NP>;
     // KS = 3: the 3x3 stride-1 pad-1 conv.  KS = 2: a 2x2 phase conv of an Upsample / of the Downsample data gradient (top / left
     // padding a.pad / a.pad_w in {0, 1}, ONE side of the conv on every second pixel of a tensor of twice the size: a.in_* / a.out_*).
