@@ -39,6 +39,8 @@ if PKG not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
 PEAK_16BIT_MFMA_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_TBS = 8.0                    # HBM3E (MI355X_MICROARCH.md)
+MFMA_WALL_RANDOM_TFLOPS = 1360.0      # measured: register-resident v_mfma_f32_32x32x16_f16 loop on random operands, 1.34-1.38 PFLOP/s
+                                      # (tools/experiments/mfma_power.hip; 1.84 on zeros): what the matrix pipe sustains on real data
 SPLIT_PRODUCTS = {0: None, 1: 1, 2: 3, 3: 6}   # 16-bit MFMA products per fp32 multiply-add: planes -> products (conv_split.h)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
 
@@ -179,6 +181,7 @@ def roofline_entry(name, r, step_us, traffic, excl=None):
         peak = PEAK_16BIT_MFMA_TFLOPS / SPLIT_PRODUCTS[planes] if planes else PEAK_F32_MFMA_TFLOPS
         e.update({"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                   "vs_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
+                  "frac_of_measured_mfma_wall": (ach / (MFMA_WALL_RANDOM_TFLOPS / SPLIT_PRODUCTS[planes])) if planes else None,
                   "avg_algorithmic_gflop_per_launch": 1e-9 * r["flops"] / r["launches"]})
     elif r["bytes"] > 0:
         ach = 1e-12 * r["bytes"] / (1e-6 * r["total_us"])
