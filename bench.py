@@ -425,7 +425,7 @@ def main():
         if "all" in extras:
             res["ms_per_step_profiler_off"] = extras["ms_per_step_profiler_off"]
             su = 1e6 * extras["t_all"]
-            tab = sorted(extras["all"].items(), key=lambda kv: -kv[1]["total_us"])[:24]
+            tab = sorted(extras["all"].items(), key=lambda kv: -kv[1]["total_us"])[:48]
             res["kernel_table"] = {"note": "every kernel launch of 2 untimed steps (two-stream), sorted by total time; per-launch duration "
                                            "from HIP events on the launch stream; *_single_stream from 2 more steps with the weight-gradient "
                                            "stream off (exclusive durations)",

@@ -131,14 +131,17 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* __restr
     __shared__ double sl[2 * 1024];
     const int n = blockIdx.x;
     const int cpg = C / G;
+    // blockIdx.y = a slab of whole groups (gridDim.y divides G): more blocks in flight for this latency-bound kernel
+    const int GS = G / gridDim.y, gb = blockIdx.y * GS, ge = gb + GS, cb = gb * cpg, ce = ge * cpg;
     double* a = acc + (size_t)n * C * 2;
     {
-        const int C2 = C < 1024 ? C : 1024, NS = 1024 / C2;
+        const int CS = ce - cb;
+        const int C2 = CS < 1024 ? CS : 1024, NS = 1024 / C2;
         const int ci = threadIdx.x % C2, si = threadIdx.x / C2;
-        for (int c0 = 0; c0 < C; c0 += C2) {
+        for (int c0 = cb; c0 < ce; c0 += C2) {
             const int c = c0 + ci;
             double s1 = 0.0, s2 = 0.0;
-            if (si < NS && c < C) {
+            if (si < NS && c < ce) {
                 for (int s = si; s < S; s += NS) {
                     const double* p = part + (((size_t)n * S + s) * C + c) * 2;
                     s1 += p[0];
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* __restr
             sl[2 * threadIdx.x] = s1;
             sl[2 * threadIdx.x + 1] = s2;
             __syncthreads();
-            if (si == 0 && c < C) {
+            if (si == 0 && c < ce) {
                 for (int q = 1; q < NS; ++q) { s1 += sl[2 * (q * C2 + ci)]; s2 += sl[2 * (q * C2 + ci) + 1]; }
                 a[2 * c] = s1;
                 a[2 * c + 1] = s2;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* __restr
             __syncthreads();
         }
     }
-    for (int g = threadIdx.x; g < G; g += 1024) {
+    for (int g = gb + threadIdx.x; g < ge; g += 1024) {
         double s1 = 0.0, s2 = 0.0;
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s1 += a[2 * c]; s2 += a[2 * c + 1]; }
         const double cnt = (double)cpg * (double)HW;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* __restr
         // |gamma (x - mu) rstd + beta| <= |gamma| sqrt(count) + |beta|  (sum of squares of the normalised group = count), and
         // |SiLU(t)|, |LeakyReLU(t)| <= |t|: an upper bound of the transformed activations for the fp16 split scale (conv_split.h)
         const float root = sqrtf((float)cpg * (float)HW);
-        for (int c = threadIdx.x; c < C; c += 1024) {
+        for (int c = cb + threadIdx.x; c < ce; c += 1024) {
             const int g = c / cpg;
             const float mu = mean[n * G + g], rs = rstd[n * G + g];
             const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
@@ -182,9 +185,17 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* __restr
             bound = fmaxf(bound, fmaf(fabsf(ga), root, fabsf(be)));
         }
     }
-    if (absmax) {
+    if (absmax) {                            // one same-address atomic per block (they serialise at ~10 ns each)
         bound = wave_max(bound);
-        if ((threadIdx.x & 63) == 0) atomicMax(absmax, __float_as_uint(bound));
+        float* wm = reinterpret_cast<float*>(sl);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = bound;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float b = 0.f;
+            for (int w = 0; w < 16; ++w) b = fmaxf(b, wm[w]);
+            atomicMax(absmax, __float_as_uint(b));
+        }
     }
 }
 
@@ -198,13 +209,15 @@ __global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const double* __r
     __shared__ double sl[2 * 1024];
     const int n = blockIdx.x;
     const int cpg = C / G;
+    const int GS = G / gridDim.y, gb = blockIdx.y * GS, ge = gb + GS, cb = gb * cpg, ce = ge * cpg;   // slab of whole groups
     double* a = acc + (size_t)n * C * 2;
-    const int C2 = C < 1024 ? C : 1024, NS = 1024 / C2;           // slices per channel
+    const int CS = ce - cb;
+    const int C2 = CS < 1024 ? CS : 1024, NS = 1024 / C2;         // slices per channel
     const int ci = threadIdx.x % C2, si = threadIdx.x / C2;
-    for (int c0 = 0; c0 < C; c0 += C2) {
+    for (int c0 = cb; c0 < ce; c0 += C2) {
         const int c = c0 + ci;
         double s1 = 0.0, s2 = 0.0;
-        if (si < NS && c < C) {
+        if (si < NS && c < ce) {
             for (int s = si; s < S; s += NS) {
                 const double* p = part + (((size_t)n * S + s) * C + c) * 2;
                 s1 += p[0];
@@ -214,14 +227,14 @@ __global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const double* __r
         sl[2 * threadIdx.x] = s1;
         sl[2 * threadIdx.x + 1] = s2;
         __syncthreads();
-        if (si == 0 && c < C) {
+        if (si == 0 && c < ce) {
             for (int q = 1; q < NS; ++q) { s1 += sl[2 * (q * C2 + ci)]; s2 += sl[2 * (q * C2 + ci) + 1]; }
             a[2 * c] = s1;
             a[2 * c + 1] = s2;
         }
         __syncthreads();
     }
-    for (int g = threadIdx.x; g < G; g += 1024) {
+    for (int g = gb + threadIdx.x; g < ge; g += 1024) {
         double u = 0.0, v = 0.0;
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
             u += (double)gamma[c] * a[2 * c];
@@ -368,6 +381,13 @@ __global__ void bn_update_running_kernel(const float* mean, const float* rstd, i
     rv[c] = (1.f - mom) * rv[c] + mom * (float)unb;
 }
 
+// group slabs per image for the finalize kernels: up to 8 blocks per image, whole groups per block
+int gn_slabs(int G) {
+    int s = 8;
+    while (s > 1 && G % s) s >>= 1;
+    return s;
+}
+
 int gn_splits(int N, long HW) {
     long s = (HW + 1023) / 1024;          // >= 1024 pixels per block
     long cap = (1024 + N - 1) / N;        // ~1024 blocks in total
@@ -419,7 +439,7 @@ extern "C" int favae_gn_stats(const float* x, const float* gamma, const float* b
     if (absmax_out && hipMemsetAsync(absmax_out, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
     launch_partial<0>(x, nullptr, gamma, beta, nullptr, nullptr, part, N, (long)HW, C, G, 0, s);
     FAVAE_CHECK_LAUNCH();
-    FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N), dim3(1024), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
+    FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N, gn_slabs(G)), dim3(1024), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
                        acc, (long)HW, C, G, gn_splits(N, HW), eps, (unsigned*)absmax_out);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -436,7 +456,7 @@ extern "C" int favae_gn_stats_tiles(const void* part, int tiles, const float* ga
     if (ws_bytes < acc_bytes(N, C)) return FAVAE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     if (absmax_out && hipMemsetAsync(absmax_out, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
-    FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N), dim3(1024), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
+    FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N, gn_slabs(G)), dim3(1024), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
                        (double*)ws, (long)HW, C, G, tiles, eps, (unsigned*)absmax_out);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -487,7 +507,7 @@ static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, 
         launch_partial<1>(x, da, gamma, beta, mean, rstd, part, N, (long)HW, C, G, act, s);
         FAVAE_CHECK_LAUNCH();
     }
-    FAVAE_KLAUNCH(gn_bwd_finalize_kernel, dim3(N), dim3(1024), 0, s, (const double*)part, gamma, k1, k2, acc, (long)HW, C, G,
+    FAVAE_KLAUNCH(gn_bwd_finalize_kernel, dim3(N, gn_slabs(G)), dim3(1024), 0, s, (const double*)part, gamma, k1, k2, acc, (long)HW, C, G,
                        tile_partials ? tile_partials : gn_splits(N, HW));
     FAVAE_CHECK_LAUNCH();
     if (dgamma) {
