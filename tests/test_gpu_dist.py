@@ -78,3 +78,32 @@ def test_bench_gpus_flag_launches_ranks():
         assert out.returncode == 0, out.stderr[-3000:]
         res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         assert res["n_gpus"] == n and res["rccl_world_size"] == n and len(res["per_rank_images_per_s"]) == n
+
+
+def test_bench_line_schema():
+    """The JSON line of bench.py carries what the driver's contract and the tier's measurement section name: metric / value / unit /
+    n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, `roofline`
+    {bound, achieved, peak, unit, frac, traffic} for the dominant kernel measured by the in-library profiler, `cpu_baseline`
+    {value, unit, cores, kind, sample}.  Small batch, same model."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--no-extras",
+                          "--cpu-batch", "1", "--cpu-steps", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    res = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in res, k
+    assert res["unit"] == "images/s" and res["n_gpus"] == 1 and res["steps"] == 2 and res["warmup"] == 1 and res["dtype"] == "f32"
+    assert res["higher_is_better"] is True and res["scaling"] == "weak" and res["vs_baseline"] is None and res["data"] == "synthetic"
+    assert "workload" in res["config"] and "model" not in res["config"]
+    assert abs(res["value"] - 2 * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]
+    r = res["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "algorithmic_bytes_per_launch"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "<" in r["kernel"], "the kernel is named by its full instantiation (the name a rocprofv3 trace shows)"
+    c = res["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "images/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
