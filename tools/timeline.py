@@ -72,3 +72,22 @@ if len(steps) >= 4:
         m1 = a1.get(k, [0, 0.0])[1]
         print(f"  {k:60s} n={n:4d}  {ms:7.2f} | {m1:7.2f} | {ms / m1 if m1 else 0:5.2f}   v{res[k][0]}+a{res[k][1]} lds {res[k][2]}")
     print(f"  sum {sum(v[1] for v in a2.values()):.2f} | {sum(v[1] for v in a1.values()):.2f}")
+
+# largest idle gaps of the main queue in the last two-stream step: which kernels surround them
+if steps:
+    st = steps[min(len(steps) - 1, 2)] if len(steps) < 4 else steps[-3]
+    mainq = max(set(r[3] for r in st), key=lambda q: sum(1 for r in st if r[3] == q))
+    rows_q = sorted([r for r in st if r[3] == mainq], key=lambda r: r[1])
+    gaps = []
+    for a, b in zip(rows_q[:-1], rows_q[1:]):
+        g = b[1] - a[2]
+        if g > 0:
+            gaps.append((g, short(a[0]), short(b[0])))
+    tot = sum(g for g, _, _ in gaps)
+    print(f"\nmain queue: {len(gaps)} gaps, {tot / 1e6:.2f} ms in total; > 20 us: {sum(g for g, _, _ in gaps if g > 20e3) / 1e6:.2f} ms")
+    agg = defaultdict(lambda: [0, 0.0])
+    for g, ka, kb in gaps:
+        agg[(ka, kb)][0] += 1
+        agg[(ka, kb)][1] += g / 1e3
+    for (ka, kb), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"  {us:9.1f} us in {n:4d} gaps   after {ka[:44]:44s} before {kb[:44]}")
