@@ -330,7 +330,8 @@ class ConvCfg:
 # weight-gradient kernel loads them without any transform / split arithmetic (include/favae_hip.h, favae_conv_*_planes).  Same
 # bits, weight-gradient kernel alone 284 -> 352 TFLOP/s -- but OFF by default: in the training step the weight gradients are
 # already hidden on the second stream, while the plane stores cost the un-overlapped forward kernel 8 % (same-box A/B, batch 32:
-# 180.8 ms/step off, 182.5 on).
+# 180.8 ms/step off, 182.5 on).  A conv that stores planes does not also run the GroupNorm epilogue variants
+# (statistics of its output / backward sums), so with those in place the gap is larger: 175.7 off, 187.8 on.
 _PLANES = os.environ.get("FAVAE_WGRAD_PLANES", "0") == "1"
 
 
