@@ -39,8 +39,9 @@ if PKG not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
 PEAK_16BIT_MFMA_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_TBS = 8.0                    # HBM3E (MI355X_MICROARCH.md)
-MFMA_WALL_RANDOM_TFLOPS = 1360.0      # measured: register-resident v_mfma_f32_32x32x16_f16 loop on random operands, 1.34-1.38 PFLOP/s
-                                      # (tools/experiments/mfma_power.hip; 1.84 on zeros): what the matrix pipe sustains on real data
+MFMA_WALL_RANDOM_TFLOPS = 1400.0      # measured: register-resident v_mfma_f32_32x32x16_f16 loop on random operands, 1.34-1.44 PFLOP/s
+                                      # over 3 ms .. 1.5 s runs (tools/experiments/mfma_power.hip; 1.84-1.92 on zeros): what the matrix
+                                      # pipe sustains on real data
 SPLIT_PRODUCTS = {0: None, 1: 1, 2: 3, 3: 6}   # 16-bit MFMA products per fp32 multiply-add: planes -> products (conv_split.h)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
 

@@ -33,8 +33,9 @@ __global__ __launch_bounds__(256) void mfma_loop(const half8* __restrict__ ab, f
     out[t] = s;
 }
 
-int main() {
-    const int blocks = 256 * 8, threads = 256, iters = 4000;      // 8 workgroups of 4 waves per CU = 8 waves per SIMD
+int main(int argc, char** argv) {
+    const int blocks = 256 * 8, threads = 256;
+    const int iters = argc > 1 ? atoi(argv[1]) : 4000;          // 4000: 3 ms per launch; 400000: 0.3 s per launch (sustained clocks)      // 8 workgroups of 4 waves per CU = 8 waves per SIMD
     const size_t n = (size_t)blocks * threads;
     std::vector<_Float16> h(n * 32);
     half8* d_ab; float* d_out;
