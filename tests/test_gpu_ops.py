@@ -362,6 +362,74 @@ def test_attention_core_tiled_forward_backward(K, N, C, H, W, chunk):
         assert saved < 1.5 * (N * C * L * 4 + N * L * 4) + (1 << 20), saved
 
 
+@pytest.mark.parametrize("N,C1,C2,H,W", [(2, 128, 128, 16, 32), (1, 128, 256, 8, 16), (3, 256, 128, 24, 48)])
+def test_gn_epilogue_fusions_match_streaming_passes(K, N, C1, C2, H, W):
+    """GroupNorm statistics emitted by the producing conv's epilogue (favae_conv_fwd_split_stats -> favae_gn_stats_tiles) and
+    GroupNorm-backward sums from the data-gradient epilogue (favae_conv_dgrad_gnbwd -> favae_gn_act_bwd_tiles) against the streaming
+    passes they replace, on a conv -> GroupNorm+SiLU -> conv chain: same outputs and gradients to fp32 rounding (the sums are taken in
+    another order), incl. two output-channel tiles and non-square images."""
+    d = dev()
+    x = rnd((N, C1, H, W), 81)
+    w1 = rnd((C2, C1, 3, 3), 82, 0.03)
+    b1 = rnd((C2,), 83, 0.1)
+    gw = 1 + rnd((C2,), 84, 0.2)
+    gb = rnd((C2,), 85, 0.2)
+    w2 = rnd((C1, C2, 3, 3), 86, 0.03)
+    b2 = rnd((C1,), 87, 0.1)
+    gy = rnd((N, C1, H, W), 88)
+    cfg0, cfg = K.ConvCfg(3, 3, 1, 1), K.ConvCfg(3, 3, 1, 1, act=1, groups=32)
+    outs = []
+    for fuse in (True, False):
+        prev = K._GNSTATS_FUSE, K._GNBWD_FUSE
+        K._GNSTATS_FUSE = K._GNBWD_FUSE = fuse
+        try:
+            xs = x.to(d).requires_grad_(True)
+            ps = [t.to(d).requires_grad_(True) for t in (w1, b1, gw, gb, w2, b2)]
+            h = K.fused_conv(xs, ps[0], ps[1], cfg=cfg0)
+            assert hasattr(h, "_favae_gnstats") == fuse
+            y = K.fused_conv(h, ps[4], ps[5], ps[2], ps[3], None, cfg)
+            gr = torch.autograd.grad(y, [xs] + ps, gy.to(d))
+            K.sync_side_stream()
+            torch.cuda.synchronize()
+            outs.append([y.detach().cpu()] + [g.cpu() for g in gr])
+        finally:
+            K._GNSTATS_FUSE, K._GNBWD_FUSE = prev
+    names = ["y", "dx", "dw1", "db1", "dgamma", "dbeta", "dw2", "db2"]
+    for nm, a, b in zip(names, outs[0], outs[1]):
+        check(a, b, 2e-5 if nm in ("db1",) else 3e-6, nm)      # db1 = sum of a GroupNorm input gradient: cancels to noise level
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,Kd", [(128, 128, 16), (200, 136, 72), (64, 516, 260), (36, 40, 4)])
+def test_bgemm_sp_vs_fp64(K, ta, tb, M, N, Kd):
+    """favae_bgemm_sp (split-precision batched GEMM of the attention core) on ragged shapes -- M, N not multiples of the 128-wide
+    tile, K not a multiple of the 16-deep step -- for the three operand-layout combinations it supports, with and without
+    accumulation, batch 3, strided batches: C = alpha * A B^T against fp64, fp32-grade tolerance."""
+    import favae_hip as H
+    d = dev()
+    B = 3
+    a_shape = (B, M, Kd) if ta == 0 else (B, Kd, M)
+    b_shape = (B, N, Kd) if tb == 0 else (B, Kd, N)
+    A = rnd(a_shape, 71, 2.0).to(d)
+    Bm = rnd(b_shape, 72, 0.5).to(d)
+    C0 = rnd((B, M, N), 73).to(d)
+    Ad = A.double().cpu() if ta == 0 else A.double().cpu().transpose(1, 2)
+    Bd = Bm.double().cpu() if tb == 0 else Bm.double().cpu().transpose(1, 2)
+    ref = 0.37 * Ad @ Bd.transpose(1, 2)
+    amax_a, amax_b = K.absmax(A), K.absmax(Bm)
+    for acc in (0, 1):
+        C = C0.clone()
+        H.call("favae_bgemm_sp", ta, tb, M, N, Kd, 0.37, H.ptr(A), a_shape[2], a_shape[1] * a_shape[2], H.ptr(amax_a), H.ptr(Bm),
+               b_shape[2], b_shape[1] * b_shape[2], H.ptr(amax_b), H.ptr(C), N, M * N, B, acc)
+        want = ref + (C0.double().cpu() if acc else 0.0)
+        check(C, want, 3e-6, f"bgemm_sp ta={ta} tb={tb} acc={acc}")
+    # the unsupported layout combination is refused, not mis-computed
+    if (ta, tb) == (0, 0):
+        with pytest.raises(RuntimeError):
+            H.call("favae_bgemm_sp", 1, 0, M, N, Kd, 1.0, H.ptr(A), M, M * Kd, H.ptr(amax_a), H.ptr(Bm), Kd, N * Kd, H.ptr(amax_b),
+                   H.ptr(C), N, M * N, B, 0)
+
+
 def test_attention_core_tiled_matches_materialised(K):
     """the tiled core against the round-1 materialised fp32-MFMA core on the same input (A/B switch FAVAE_ATTN_TILED)"""
     qkv = rnd((2, 3 * 256, 16, 16), 25, 0.7)
