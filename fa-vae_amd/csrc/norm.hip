@@ -120,15 +120,16 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     }
 }
 
-// one block (1024 threads) per image: sum the splits per channel -> acc[n][c][2] (double), then group statistics + per-channel
-// affine.  Split sums as in gn_bwd_finalize_kernel: 1024 / min(C, 1024) interleaved slices per channel, slices added in ascending
+// one block (256 threads: it must fit on a CU next to a resident 512-thread weight-gradient workgroup -- 1024-thread blocks waited
+// up to 0.2 ms for a free CU in the f=4 step) per (image, group slab): sum the splits per channel -> acc[n][c][2] (double), then group statistics + per-channel
+// affine.  Split sums as in gn_bwd_finalize_kernel: 256 / min(C, 256) interleaved slices per channel, slices added in ascending
 // order (deterministic); S is ~32 for the streaming pass and (H/8)(W/16) for tile partials from a conv epilogue.
-__global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ mean,
                                                            float* __restrict__ rstd, float* __restrict__ scale,
                                                            float* __restrict__ shift, double* __restrict__ acc, long HW, int C,
                                                            int G, int S, float eps, unsigned* __restrict__ absmax) {
-    __shared__ double sl[2 * 1024];
+    __shared__ double sl[2 * 256];
     const int n = blockIdx.x;
     const int cpg = C / G;
     // blockIdx.y = a slab of whole groups (gridDim.y divides G): more blocks in flight for this latency-bound kernel
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* __restr
     double* a = acc + (size_t)n * C * 2;
     {
         const int CS = ce - cb;
-        const int C2 = CS < 1024 ? CS : 1024, NS = 1024 / C2;
+        const int C2 = CS < 256 ? CS : 256, NS = 256 / C2;
         const int ci = threadIdx.x % C2, si = threadIdx.x / C2;
         for (int c0 = cb; c0 < ce; c0 += C2) {
             const int c = c0 + ci;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* __restr
             __syncthreads();
         }
     }
-    for (int g = gb + threadIdx.x; g < ge; g += 1024) {
+    for (int g = gb + threadIdx.x; g < ge; g += 256) {
         double s1 = 0.0, s2 = 0.0;
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s1 += a[2 * c]; s2 += a[2 * c + 1]; }
         const double cnt = (double)cpg * (double)HW;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* __restr
         // |gamma (x - mu) rstd + beta| <= |gamma| sqrt(count) + |beta|  (sum of squares of the normalised group = count), and
         // |SiLU(t)|, |LeakyReLU(t)| <= |t|: an upper bound of the transformed activations for the fp16 split scale (conv_split.h)
         const float root = sqrtf((float)cpg * (float)HW);
-        for (int c = cb + threadIdx.x; c < ce; c += 1024) {
+        for (int c = cb + threadIdx.x; c < ce; c += 256) {
             const int g = c / cpg;
             const float mu = mean[n * G + g], rs = rstd[n * G + g];
             const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
@@ -193,26 +194,26 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* __restr
         __syncthreads();
         if (threadIdx.x == 0) {
             float b = 0.f;
-            for (int w = 0; w < 16; ++w) b = fmaxf(b, wm[w]);
+            for (int w = 0; w < 4; ++w) b = fmaxf(b, wm[w]);
             atomicMax(absmax, __float_as_uint(b));
         }
     }
 }
 
-// backward, one block (1024 threads) per image: acc[n][c] = sum over splits of (S1,S2); k1/k2 per group.  The S partials of a
-// channel are summed by 1024 / C2 threads (C2 = min(C, 1024)) over interleaved slices, then the slices in ascending order --
+// backward, one block (256 threads) per image: acc[n][c] = sum over splits of (S1,S2); k1/k2 per group.  The S partials of a
+// channel are summed by 256 / C2 threads (C2 = min(C, 256)) over interleaved slices, then the slices in ascending order --
 // a fixed order for a given (S, C): deterministic.  (S is ~32 for the streaming pass 1 and (H/8)(W/16) = up to 512 for the
 // per-tile partials of the data-gradient epilogue, where one thread per channel took 60 us.)
-__global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
                                                                float* __restrict__ k1, float* __restrict__ k2,
                                                                double* __restrict__ acc, long HW, int C, int G, int S) {
-    __shared__ double sl[2 * 1024];
+    __shared__ double sl[2 * 256];
     const int n = blockIdx.x;
     const int cpg = C / G;
     const int GS = G / gridDim.y, gb = blockIdx.y * GS, ge = gb + GS, cb = gb * cpg, ce = ge * cpg;   // slab of whole groups
     double* a = acc + (size_t)n * C * 2;
     const int CS = ce - cb;
-    const int C2 = CS < 1024 ? CS : 1024, NS = 1024 / C2;         // slices per channel
+    const int C2 = CS < 256 ? CS : 256, NS = 256 / C2;         // slices per channel
     const int ci = threadIdx.x % C2, si = threadIdx.x / C2;
     for (int c0 = cb; c0 < ce; c0 += C2) {
         const int c = c0 + ci;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const double* __r
         }
         __syncthreads();
     }
-    for (int g = gb + threadIdx.x; g < ge; g += 1024) {
+    for (int g = gb + threadIdx.x; g < ge; g += 256) {
         double u = 0.0, v = 0.0;
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
             u += (double)gamma[c] * a[2 * c];
@@ -439,7 +440,7 @@ extern "C" int favae_gn_stats(const float* x, const float* gamma, const float* b
     if (absmax_out && hipMemsetAsync(absmax_out, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
     launch_partial<0>(x, nullptr, gamma, beta, nullptr, nullptr, part, N, (long)HW, C, G, 0, s);
     FAVAE_CHECK_LAUNCH();
-    FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N, gn_slabs(G)), dim3(1024), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
+    FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N, gn_slabs(G)), dim3(256), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
                        acc, (long)HW, C, G, gn_splits(N, HW), eps, (unsigned*)absmax_out);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -456,7 +457,7 @@ extern "C" int favae_gn_stats_tiles(const void* part, int tiles, const float* ga
     if (ws_bytes < acc_bytes(N, C)) return FAVAE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     if (absmax_out && hipMemsetAsync(absmax_out, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
-    FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N, gn_slabs(G)), dim3(1024), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
+    FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N, gn_slabs(G)), dim3(256), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
                        (double*)ws, (long)HW, C, G, tiles, eps, (unsigned*)absmax_out);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -507,7 +508,7 @@ static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, 
         launch_partial<1>(x, da, gamma, beta, mean, rstd, part, N, (long)HW, C, G, act, s);
         FAVAE_CHECK_LAUNCH();
     }
-    FAVAE_KLAUNCH(gn_bwd_finalize_kernel, dim3(N, gn_slabs(G)), dim3(1024), 0, s, (const double*)part, gamma, k1, k2, acc, (long)HW, C, G,
+    FAVAE_KLAUNCH(gn_bwd_finalize_kernel, dim3(N, gn_slabs(G)), dim3(256), 0, s, (const double*)part, gamma, k1, k2, acc, (long)HW, C, G,
                        tile_partials ? tile_partials : gn_splits(N, HW));
     FAVAE_CHECK_LAUNCH();
     if (dgamma) {
