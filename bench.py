@@ -195,7 +195,7 @@ def roofline_entry(name, r, step_us, traffic, excl=None):
         e["traffic_over_algorithmic"] = t / (r["bytes"] / r["launches"])
     if excl and name in excl and "achieved" in e:
         x = excl[name]
-        num = x["flops"] if r["flops"] > 0 else x["bytes"]
+        num = x["flops"] if e["bound"] == "mfma" else x["bytes"]
         e["achieved_single_stream"] = 1e-12 * num / (1e-6 * x["total_us"])
         e["frac_single_stream"] = e["achieved_single_stream"] / e["peak"]
         e["avg_launch_us_single_stream"] = x["total_us"] / x["launches"]
