@@ -13,12 +13,15 @@ and exits with the children's status.  Under torchrun (WORLD_SIZE set) it is one
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement"):
   value      whole-job images/s  (sum over ranks / max-over-ranks time, barrier + synchronize on both sides)
+  (the line stays < 4 KB: the kernel table, the other matrix-bound kernels and all prose notes go to the side file
+   gpurun_out/bench_detail.json, or $FAVAE_BENCH_DETAIL)
   roofline   the kernel with the largest time share of the timed region among the matrix-bound kernels (conv forward, data
              gradient AND weight gradient families): algorithmic FLOPs (2*M*Cout*KH*KW*Cin per launch) / launch durations, both
              recorded by the library's launch profiler (csrc/prof.hip): two HIP events around every such launch, on the stream the
              kernel is launched on (the weight gradients run on a second stream), inside the timed region;
              peak = 2500 TFLOP/s dense 16-bit MFMA / products per fp32 multiply-add (3 with two fp16 planes, 6 with three bf16)
-  kernel_table  every kernel of one extra (untimed) step, same profiler at "all launches": per-kernel time, achieved TB/s or TFLOP/s
+  kernel_table  (side file) every kernel of two extra (untimed) steps, same profiler at "all launches": per-kernel time, achieved
+             GB/s or TFLOP/s
   cpu_baseline  the CPU oracle (kind "port": pure-PyTorch restatement of the reference step, oracle/) timed on this
              host's cores on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -43,22 +46,95 @@ MFMA_WALL_RANDOM_TFLOPS = 1400.0      # measured: register-resident v_mfma_f32_3
                                       # over 3 ms .. 1.5 s runs (tools/experiments/mfma_power.hip; 1.84-1.92 on zeros): what the matrix
                                       # pipe sustains on real data
 SPLIT_PRODUCTS = {0: None, 1: 1, 2: 3, 3: 6}   # 16-bit MFMA products per fp32 multiply-add: planes -> products (conv_split.h)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+MAX_LINE_BYTES = 4096                 # the driver keeps an 8 KB tail of stdout: the JSON line must stay far below it
+NOTES = {
+    "roofline": "dominant kernel of the timed region by total time among all matrix-bound launches (conv forward, data-gradient and "
+                "weight-gradient kernels; the latter run on a second HIP stream). achieved = algorithmic fp32 FLOPs (2*M*Cout*KH*KW*Cin "
+                "per launch) / launch durations from two HIP events around every launch on its own stream (csrc/prof.hip), first "
+                "`profiled_steps` steps of the timed region. peak = 2500 TFLOP/s dense 16-bit MFMA / products per fp32 multiply-add "
+                "(planes=2: two scaled fp16 planes, 3 products -> 833; planes=3: 6 products; planes=1: one 16-bit plane, 2500).",
+    "single_stream": "*_single_stream: the same launches in 2 untimed steps with the weight-gradient stream off (exclusive durations)",
+    "traffic": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch averaged over the launches of one step, separate rocprofv3 "
+               "--pmc passes (gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md; fabric-side counter, includes Infinity-Cache "
+               "hits); null when the traffic file was collected on a different build of csrc/ (build stamp mismatch)",
+    "kernel_table": "every kernel launch of 2 untimed steps (two-stream), sorted by total time; per-launch duration from HIP events on "
+                    "the launch stream",
+    "with_lpips": "same workload + perceptual_weight * lpips(x, x_recon).mean() every step (train_favae.py:77-79); VGG16 / lin weights "
+                  "random-init (vgg16_lpips.pt is not available offline): timing only",
+    "roofline_step": "whole step per GPU against SURVEY 8(d)'s per-image work (conv + attention + VQ FLOPs; fused-ideal fp32 bytes)",
+}
+
+
+def rnd(v, digits=5):
+    """5 significant digits: keeps the JSON line short without touching `value` / `ms_per_step`"""
+    if v is None or not isinstance(v, float) or v != v or v in (float("inf"), float("-inf")):
+        return v
+    return float("%.*g" % (digits, v))
+
+
+def build_stamp():
+    """sha256 over the kernel sources and the C header: identifies the build a PMC traffic file belongs to"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.h")) +
+                    [os.path.join(ROOT, "include", "favae_hip.h")]):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic():
+    """per-launch HBM bytes from the committed PMC passes (profiles/), only when they were collected on THIS build"""
+    try:
+        t = json.load(open(TRAFFIC_FILE))
+    except Exception:
+        return {}, {"file": os.path.relpath(TRAFFIC_FILE, ROOT), "status": "missing"}
+    stamp, want = t.get("_build"), build_stamp()
+    if stamp != want:
+        return {}, {"file": os.path.relpath(TRAFFIC_FILE, ROOT), "status": "stale", "file_build": stamp, "this_build": want}
+    return t, {"file": os.path.relpath(TRAFFIC_FILE, ROOT), "status": "ok", "build": want}
+
+
+def compact_roofline(e):
+    keep = ("kernel", "launches", "avg_launch_us", "share_of_step_time", "bound", "achieved", "peak", "unit", "frac",
+            "frac_of_measured_mfma_wall", "algorithmic_bytes_per_launch", "avg_algorithmic_gflop_per_launch", "traffic",
+            "traffic_over_algorithmic", "achieved_single_stream", "frac_single_stream", "avg_launch_us_single_stream", "profiled_steps")
+    return {k: rnd(e[k]) for k in keep if k in e}
+
+
+def write_detail(detail):
+    """kernel table, the other matrix-bound kernels and the prose notes: a side file, never the stdout line"""
+    path = os.environ.get("FAVAE_BENCH_DETAIL")
+    if not path:
+        d = os.path.join(os.getcwd(), "gpurun_out")
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "bench_detail.json")
+        except OSError:
+            path = os.path.join(os.getcwd(), "bench_detail.json")
+    try:
+        with open(path, "w") as f:
+            json.dump(detail, f, indent=1)
+        return path
+    except OSError as e:
+        print("[bench] could not write %s: %s" % (path, e), file=sys.stderr)
+        return None
 
 # name -> (description, codebook, n_embed, model kwargs, oracle config kwargs, default batch per GPU,
 #          algorithmic TFLOP and GB per image of the stage-0 step (SURVEY 8d; None where the survey gives none))
 CONFIGS = {
-    "celeba_f16": ("BASELINE configs[1]: FA-VAE f=16 CelebA-HQ config, codebook %d, embed_dim 256, residual FCM + non-pairwise DSL "
-                   "(k=9, sigma0=3)", 16384, 256,
+    "celeba_f16": ("BASELINE configs[1]: FA-VAE f=16 CelebA-HQ, codebook %d, embed_dim 256, FCM Res + non-pairwise DSL (k=9)", 16384, 256,
                    dict(ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_gauss_resblock=True),
                    dict(variant="gauss_resblock"), 32, (1.316, 8.1)),
-    "imagenet_f4": ("BASELINE configs[3]: FA-VAE f=4 ImageNet config, codebook %d, embed_dim 3 projected to codebook_dim 256, "
-                    "ch_mult (1,2,4), conv FCM with one sigma per pair (use_same_conv_gauss, num_groups 3, k=9, sigma0=3)", 8192, 3,
+    "imagenet_f4": ("BASELINE configs[3]: FA-VAE f=4 ImageNet, codebook %d, embed_dim 3 -> codebook_dim 256, ch_mult (1,2,4), "
+                    "use_same_conv_gauss (num_groups 3, k=9)", 8192, 3,
                     dict(ch_mult=(1, 2, 4), attn_resolutions=[], codebook_dim=256, use_same_conv_gauss=True, num_groups=3),
                     dict(n_embed=3, ch_mult=(1, 2, 4), attn_resolutions=(), codebook_dim=256, variant="same_conv_gauss", num_groups=3), 16,
                     (3.436, 11.3)),
-    "ffhq_f16": ("model of BASELINE configs[4]: FA-VAE f=16 FFHQ config, codebook %d, embed_dim 256, conv FCM with one sigma per pair "
-                 "(use_same_conv_gauss, num_groups 32, k=9, sigma0=3), fp32", 2048, 256,
+    "ffhq_f16": ("BASELINE configs[4] model: FA-VAE f=16 FFHQ, codebook %d, embed_dim 256, use_same_conv_gauss (num_groups 32, k=9)",
+                 2048, 256,
                  dict(ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_same_conv_gauss=True, num_groups=32),
                  dict(variant="same_conv_gauss", num_groups=32), 32, None),
 }
@@ -84,7 +160,7 @@ def parse():
     ap.add_argument("--lpips", action="store_true",
                     help="add the perceptual term lpips(x, x_recon) (train_favae.py:77-79) on random-init VGG16/lin "
                          "weights (vgg16_lpips.pt is not available offline: timing only) -- not the headline workload")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "bf16"],
                     help="fp32 (default, the headline: fp32-grade convs by operand splitting, parity 1e-4) or fp16 = the 16-bit "
                          "mixed-precision mode asked for by BASELINE configs[4] (conv operands rounded to ONE scaled fp16 plane, fp32 "
                          "accumulation, everything else fp32; like the reference under accelerate mixed precision) -- not the "
@@ -126,6 +202,7 @@ def launch_ranks(n):
     if rc != 0 or line is None:
         print("[bench] the %d-rank launch failed (exit code %s)" % (n, rc), file=sys.stderr)
         return rc or 1
+    assert len(line) < MAX_LINE_BYTES, "relayed bench line is %d bytes" % len(line)
     print(line, flush=True)
     return 0
 
@@ -185,8 +262,8 @@ def roofline_entry(name, r, step_us, traffic, excl=None):
                   "frac_of_measured_mfma_wall": (ach / (MFMA_WALL_RANDOM_TFLOPS / SPLIT_PRODUCTS[planes])) if planes else None,
                   "avg_algorithmic_gflop_per_launch": 1e-9 * r["flops"] / r["launches"]})
     elif r["bytes"] > 0:
-        ach = 1e-12 * r["bytes"] / (1e-6 * r["total_us"])
-        e.update({"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_TBS, "unit": "TB/s", "frac": ach / PEAK_HBM_TBS})
+        ach = 1e-9 * r["bytes"] / (1e-6 * r["total_us"])
+        e.update({"bound": "hbm", "achieved": ach, "peak": 1e3 * PEAK_HBM_TBS, "unit": "GB/s", "frac": ach / (1e3 * PEAK_HBM_TBS)})
     if r["bytes"] > 0:
         e["algorithmic_bytes_per_launch"] = r["bytes"] / r["launches"]
     t = (traffic.get(name) or traffic.get(name.split("(")[0]) or {}).get("hbm_bytes_per_launch_corrected")
@@ -196,7 +273,7 @@ def roofline_entry(name, r, step_us, traffic, excl=None):
     if excl and name in excl and "achieved" in e:
         x = excl[name]
         num = x["flops"] if e["bound"] == "mfma" else x["bytes"]
-        e["achieved_single_stream"] = 1e-12 * num / (1e-6 * x["total_us"])
+        e["achieved_single_stream"] = (1e-12 if e["bound"] == "mfma" else 1e-9) * num / (1e-6 * x["total_us"])
         e["frac_single_stream"] = e["achieved_single_stream"] / e["peak"]
         e["avg_launch_us_single_stream"] = x["total_us"] / x["launches"]
     return e
@@ -234,11 +311,9 @@ def cpu_baseline(args, torch):
         tr.step(O.det_input(B, args.res, args.res, 1235 + i))
         dts.append(time.perf_counter() - t0)
     dt = sum(dts)
-    return {"value": B * len(dts) / dt, "unit": "images/s", "cores": ncores, "kind": "port",
-            "per_step_images_per_s": [B / d for d in dts],
-            "sample": f"{len(dts)} timed training steps (after 1 warm-up step) of the same {args.config} config at batch {B} "
-                      f"(the GPU leg runs batch {args.batch}: 288 GB of HBM hold it, this host's cores would need minutes per step), "
-                      f"oracle/favae_oracle.py on torch {torch.__version__} CPU, {dt:.1f} s"}
+    return {"value": rnd(B * len(dts) / dt), "unit": "images/s", "cores": ncores, "kind": "port",
+            "sample": "%d timed steps (+1 warm-up) of the same %s step at batch %d, oracle/favae_oracle.py, torch %s CPU, %.1f s"
+                      % (len(dts), args.config, B, torch.__version__, dt)}
 
 
 def main():
@@ -272,8 +347,8 @@ def main():
     from models.vqgan_fcm import VQGANFCM
 
     favae_hip.load()
-    if args.precision == "fp16":
-        K.set_conv_mode("h1")
+    if args.precision != "fp32":
+        K.set_conv_mode({"fp16": "h1", "bf16": "b1"}[args.precision])
     torch.manual_seed(0)                           # favae_scripts/train_favae.py:235 (ranks are synchronised by TrainStep's broadcast)
     desc, _, n_embed, mk, _, _, work = CONFIGS[args.config]
 
@@ -288,7 +363,7 @@ def main():
         return TrainStep(model, lr=lr, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, distributed=use_dist,
                          train_disc=args.gan, lpips=lpips, perceptual_weight=1.0)
     ts = build(args.lpips)
-    exchange_desc = ("overlapped bucketed RCCL all-reduce (%d segments, started from gradient marks inside backward)" % len(ts.exchange.segments)
+    exchange_desc = ("RCCL all-reduce, %d segments overlapped with backward" % len(ts.exchange.segments)
                      if ts.exchange is not None else ("one RCCL all-reduce after backward" if use_dist else "none (1 GPU)"))
     xs = [synthetic_batch(args.batch, args.res, args.res, 1234 + 17 * rank + i).to(dev) for i in range(2)]
     prof = Prof(favae_hip)
@@ -353,11 +428,8 @@ def main():
                 t = torch.tensor([t_lp], device=dev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 t_lp = float(t.item())
-            extras["with_lpips"] = {"value": args.batch * world * n_lp / t_lp, "unit": "images/s", "ms_per_step": 1e3 * t_lp / n_lp,
-                                    "steps": n_lp,
-                                    "note": "same workload + perceptual_weight * lpips(x, x_recon).mean() every step, as the reference's "
-                                            "train() computes it (train_favae.py:77-79); VGG16 / lin weights random-init (vgg16_lpips.pt "
-                                            "is not available offline): timing only"}
+            extras["with_lpips"] = {"value": rnd(args.batch * world * n_lp / t_lp), "unit": "images/s",
+                                    "ms_per_step": rnd(1e3 * t_lp / n_lp), "steps": n_lp}
 
     if rank == 0:
         step_us = 1e6 * dt * PROF_STEPS / args.steps           # wall time of the profiled steps (for share_of_step_time)
@@ -367,78 +439,64 @@ def main():
             "unit": "images/s",
             "n_gpus": world,
             "rccl_world_size": dist.get_world_size() if use_dist else 1,
-            "per_rank_images_per_s": per_rank,
+            "per_rank_images_per_s": [rnd(v) for v in per_rank],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f16",
+            "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": (desc % args.codebook) + ", FFL 1.0 + DSL 0.01, %dx%d, batch %d per GPU, stage-0 step "
-                                   "(no LPIPS term, no discriminator training; discriminator forward on)" % (args.res, args.res, args.batch)
-                                   + (" + discriminator training (hinge, adaptive weight, stage 1)" if args.gan else "")
-                                   + (" + LPIPS perceptual term (random-init weights: timing only)" if args.lpips else "")
-                                   + (" -- MIXED PRECISION: conv operands in one scaled fp16 plane (FAVAE_CONV_MODE=h1), fp32 "
-                                      "accumulation; not fp32-grade, not the headline" if args.precision == "fp16" else ""),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss_g_last": loss,
+            "config": {"workload": (desc % args.codebook) + ", FFL 1.0 + DSL 0.01, %dx%d, batch %d/GPU, stage-0 step (discriminator "
+                                   "forward on" % (args.res, args.res, args.batch)
+                                   + (", discriminator training" if args.gan else "")
+                                   + (", LPIPS term on random-init weights" if args.lpips else ", no LPIPS term") + ")"
+                                   + {"fp32": "", "fp16": "; MIXED PRECISION h1: conv operands in one scaled fp16 plane, fp32 accumulate",
+                                      "bf16": "; MIXED PRECISION b1: conv operands in one bf16 plane, fp32 accumulate"}[args.precision],
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss_g_last": rnd(loss, 7),
                        "gradient_exchange": exchange_desc},
         }
-        traffic = {}
-        try:                                            # per-launch HBM bytes from the committed PMC passes (profiles/)
-            traffic = json.load(open(TRAFFIC_FILE))
-        except Exception:
-            pass
+        traffic, traffic_meta = load_traffic()
         excl = extras.get("excl")
         ranked = sorted(timed_recs.items(), key=lambda kv: -kv[1]["total_us"])
+        detail = {"line": None, "traffic_file": traffic_meta, "notes": NOTES}
         if ranked:
-            res["roofline"] = roofline_entry(ranked[0][0], ranked[0][1], step_us, traffic, excl)
-            res["roofline"]["note"] = (
-                "dominant kernel of the timed region by total time among all matrix-bound launches (conv forward, data-gradient and "
-                "weight-gradient kernels; the latter run on a second HIP stream). fp32 conv on the 16-bit matrix pipe by operand "
-                "splitting (conv_split.h): planes=2 -> two scaled fp16 planes, 3 v_mfma_f32_32x32x16_f16 products per fp32 "
-                "multiply-add, peak = 2500/3 TFLOP/s; planes=3 -> three bf16 planes, 6 products, peak = 2500/6. achieved = algorithmic "
-                "fp32 FLOPs / launch durations from two HIP events around every launch on its own stream (csrc/prof.hip), recorded "
-                "over the first `profiled_steps` steps of the timed region. "
-                "Template args: halo<input transform (0 plain: data gradients, 2 GroupNorm+SiLU), planes, kernel size>, "
-                "wgrad_row3<input transform, planes>")
-            res["roofline"]["profiled_steps"] = PROF_STEPS
-            res["roofline"]["stream_note"] = ("achieved/frac: launch durations inside the timed region, where the main-stream kernels and the "
-                                              "weight-gradient kernels of the second stream share the CUs; *_single_stream: the same "
-                                              "launches in 2 untimed steps with that stream off")
-            res["roofline"]["traffic_note"] = ("traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch averaged over the launches of one "
-                                               "step, separate rocprofv3 --pmc passes (gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md; "
-                                               "fabric-side counter, includes Infinity-Cache hits), from " + os.path.relpath(TRAFFIC_FILE, ROOT))
-            res["roofline_others"] = [roofline_entry(kn, c, step_us, traffic, excl) for kn, c in ranked[1:]]
+            full = roofline_entry(ranked[0][0], ranked[0][1], step_us, traffic, excl)
+            full["profiled_steps"] = PROF_STEPS
+            res["roofline"] = compact_roofline(full)
+            detail["roofline"] = full
+            detail["roofline_others"] = [roofline_entry(kn, c, step_us, traffic, excl) for kn, c in ranked[1:]]
         if work is not None and not args.gan and not args.lpips:
             tf, gb = work
             a_f = tf * args.batch * args.steps / dt                                  # per GPU
             a_b = gb * 1e-3 * args.batch * args.steps / dt
-            planes = {"fp32": 2, "fp16": 1}[args.precision]
+            planes = {"fp32": 2, "fp16": 1, "bf16": 1}[args.precision]
             peak = PEAK_16BIT_MFMA_TFLOPS / SPLIT_PRODUCTS[planes]
-            res["roofline_step"] = {"algorithmic_tflop_per_image": tf, "algorithmic_gb_per_image": gb,
-                                    "mfma": {"achieved": a_f, "peak": peak, "unit": "TFLOP/s", "frac": a_f / peak,
-                                             "vs_fp32_mfma_peak": a_f / PEAK_F32_MFMA_TFLOPS},
-                                    "hbm": {"achieved": a_b, "peak": PEAK_HBM_TBS, "unit": "TB/s", "frac": a_b / PEAK_HBM_TBS},
-                                    "note": "whole step per GPU against SURVEY 8(d)'s per-image work (conv + attention + VQ FLOPs; "
-                                            "fused-ideal fp32 bytes); the binding ceiling is the matrix one"}
+            res["roofline_step"] = {"tflop_per_image": tf, "gb_per_image": gb,
+                                    "mfma": {"achieved": rnd(a_f), "peak": rnd(peak), "unit": "TFLOP/s", "frac": rnd(a_f / peak)},
+                                    "hbm": {"achieved": rnd(1e3 * a_b), "peak": 1e3 * PEAK_HBM_TBS, "unit": "GB/s",
+                                            "frac": rnd(a_b / PEAK_HBM_TBS)}}
         if "all" in extras:
-            res["ms_per_step_profiler_off"] = extras["ms_per_step_profiler_off"]
+            res["ms_per_step_profiler_off"] = rnd(extras["ms_per_step_profiler_off"])
             su = 1e6 * extras["t_all"]
-            tab = sorted(extras["all"].items(), key=lambda kv: -kv[1]["total_us"])[:48]
-            res["kernel_table"] = {"note": "every kernel launch of 2 untimed steps (two-stream), sorted by total time; per-launch duration "
-                                           "from HIP events on the launch stream; *_single_stream from 2 more steps with the weight-gradient "
-                                           "stream off (exclusive durations)",
-                                   "ms_per_step": 1e3 * extras["t_all"] / 2,
-                                   "ms_per_step_single_stream": 1e3 * extras["t_excl"] / 2,
-                                   "kernels": [roofline_entry(kn, c, su, traffic, excl) for kn, c in tab]}
+            tab = sorted(extras["all"].items(), key=lambda kv: -kv[1]["total_us"])[:64]
+            detail["kernel_table"] = {"ms_per_step": 1e3 * extras["t_all"] / 2,
+                                      "ms_per_step_single_stream": 1e3 * extras["t_excl"] / 2,
+                                      "kernels": [roofline_entry(kn, c, su, traffic, excl) for kn, c in tab]}
+            res["ms_per_step_single_stream"] = rnd(1e3 * extras["t_excl"] / 2)
         if "with_lpips" in extras:
             res["with_lpips"] = extras["with_lpips"]
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             print("[bench] GPU part done: %.2f images/s; timing the CPU baseline sample..." % res["value"], file=sys.stderr, flush=True)
             res["cpu_baseline"] = cpu_baseline(args, torch)
-        print(json.dumps(res), flush=True)
+        line = json.dumps(res)
+        assert len(line) < MAX_LINE_BYTES, "bench line grew to %d bytes: tables and notes belong in the side file" % len(line)
+        detail["line"] = res
+        path = write_detail(detail)
+        if path:
+            print("[bench] kernel table / notes: %s" % path, file=sys.stderr, flush=True)
+        print(line, flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,52 @@
+"""CPU: the machine-readable line of bench.py stays small (the driver keeps an 8 KB tail of stdout; round 2's 39 KB line was
+unparseable) and the PMC traffic file is only used for the build it was collected on."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _rec(n, us, gflop, gb):
+    return {"launches": n, "total_us": n * us, "min_us": us, "max_us": us, "flops": n * gflop * 1e9, "bytes": n * gb * 1e9}
+
+
+def test_compact_roofline_is_small_and_numeric():
+    name = "conv_wgrad_row3_sp_kernel<2, 2, 0>"
+    r = _rec(268, 927.4123, 177.41, 0.534)
+    full = bench.roofline_entry(name, r, 4 * 174000.0, {name: {"hbm_bytes_per_launch_corrected": 1.873e9}}, {name: _rec(134, 672.0, 177.41, 0.534)})
+    c = bench.compact_roofline(full)
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "algorithmic_bytes_per_launch",
+              "traffic_over_algorithmic", "frac_single_stream"):
+        assert k in c, k
+    assert c["bound"] == "mfma" and c["unit"] == "TFLOP/s" and abs(c["peak"] - 2500.0 / 3) < 0.01
+    assert abs(c["frac"] - c["achieved"] / c["peak"]) < 1e-4
+    assert abs(c["traffic_over_algorithmic"] - 1.873 / 0.534) < 1e-3
+    assert not any(isinstance(v, str) and len(v) > 80 for v in c.values())
+    assert len(json.dumps(c)) < 700
+
+
+def test_hbm_bound_entry_uses_gb_per_s():
+    e = bench.roofline_entry("gn_bwd_apply_rows_kernel", _rec(75, 316.2, 0.0, 0.876), 174000.0, {}, None)
+    assert e["bound"] == "hbm" and e["unit"] == "GB/s" and e["peak"] == 8000.0
+    assert abs(e["achieved"] - 0.876e9 / 316.2e-6 * 1e-9) < 1.0 and abs(e["frac"] - e["achieved"] / 8000.0) < 1e-9
+
+
+def test_traffic_file_is_bound_to_the_build(tmp_path, monkeypatch):
+    stamp = bench.build_stamp()
+    assert len(stamp) == 16 and stamp == bench.build_stamp()
+    p = tmp_path / "t.json"
+    monkeypatch.setattr(bench, "TRAFFIC_FILE", str(p))
+    assert bench.load_traffic()[1]["status"] == "missing"
+    p.write_text(json.dumps({"_build": "0" * 16, "k<1>": {"hbm_bytes_per_launch_corrected": 1.0}}))
+    t, meta = bench.load_traffic()
+    assert t == {} and meta["status"] == "stale"
+    p.write_text(json.dumps({"_build": stamp, "k<1>": {"hbm_bytes_per_launch_corrected": 1.0}}))
+    t, meta = bench.load_traffic()
+    assert meta["status"] == "ok" and t["k<1>"]["hbm_bytes_per_launch_corrected"] == 1.0
+
+
+def test_rounding_keeps_five_digits():
+    assert bench.rnd(184.6647291815485) == 184.66 and bench.rnd(None) is None and bench.rnd(3) == 3

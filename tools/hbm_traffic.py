@@ -3,6 +3,8 @@
 dispatch summed over the XCDs).  bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- the gfx950 FETCH_SIZE x2
 correction of MI355X_MICROARCH.md -- averaged over the launches of the profiled run.
 usage: tools/hbm_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps in the run> <out.json>
+The output carries "_build" = bench.build_stamp() of the tree it was collected on; bench.py refuses a file whose stamp differs from
+the build it runs (roofline.traffic is then null).
 
 collect with (separately, no other tracing):
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d <dir> -o f -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
@@ -10,8 +12,11 @@ collect with (separately, no other tracing):
 import collections
 import csv
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
 def short(name):
@@ -38,7 +43,10 @@ def main():
         fa, wa = sum(fv) / len(fv), sum(wv) / len(wv)
         out[k] = {"launches_per_step": max(len(fv), len(wv)) / steps, "fetch_size_kb_avg": fa, "write_size_kb_avg": wa,
                   "hbm_bytes_per_launch_corrected": (2.0 * fa + wa) * 1024.0}
-    json.dump(out, open(sys.argv[4], "w"), indent=1)
+    import bench
+    final = {"_build": bench.build_stamp()}
+    final.update(out)
+    json.dump(final, open(sys.argv[4], "w"), indent=1)
     for k in list(out)[:12]:
         print("%-70s %8.1f MB/launch" % (k[:70], out[k]["hbm_bytes_per_launch_corrected"] / 1e6))
 
