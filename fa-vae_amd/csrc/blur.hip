@@ -292,7 +292,7 @@ extern "C" int favae_blur_fwd(const float* x, const float* sigma, int ksize, int
         }
     }
     BlurArgs a{};
-    if (!plan(ksize, N, H, W, C, false, a)) return FAVAE_ERR_UNSUPPORTED;
+    if (!plan(ksize, N, H, W, C, false, a)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     a.x = x; a.sigma = sigma; a.y = y;
     const size_t shm = shm_floats(a, false) * sizeof(float);
     static bool attr0 = false;
@@ -304,7 +304,7 @@ extern "C" int favae_blur_fwd(const float* x, const float* sigma, int ksize, int
         attr0 = true;
     }
     const long grid = (long)N * a.tiles_h * a.tiles_w * a.cchunks;
-    if (grid >= (1L << 31)) return FAVAE_ERR_UNSUPPORTED;
+    if (grid >= (1L << 31)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     const dim3 g3((unsigned)grid), b3(256);
     hipStream_t s0 = (hipStream_t)stream;
     if (ksize == 9) FAVAE_KLAUNCH((blur_sep_kernel<0, 9>), g3, b3, shm, s0, a);
@@ -334,8 +334,8 @@ extern "C" int favae_blur_bwd(const float* x, const float* dy, const float* sigm
     FAVAE_REQUIRE(x && dy && sigma && ws && blur_ok(ksize, N, H, W, C));
     FAVAE_REQUIRE(dx || dsigma);
     BlurArgs a{};
-    if (!plan(ksize, N, H, W, C, true, a)) return FAVAE_ERR_UNSUPPORTED;
-    if (ws_bytes < favae_blur_bwd_workspace(ksize, N, H, W, C)) return FAVAE_ERR_WORKSPACE;
+    if (!plan(ksize, N, H, W, C, true, a)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (ws_bytes < favae_blur_bwd_workspace(ksize, N, H, W, C)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     StreamArgs sa{};
     bool stream_path = stream_ok(ksize, N, H, W, C) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
     long grid = (long)N * a.tiles_h * a.tiles_w * a.cchunks;
@@ -345,12 +345,12 @@ extern "C" int favae_blur_bwd(const float* x, const float* dy, const float* sigm
         if (sgrid < (1L << 31)) grid = sgrid;
         else stream_path = false;
     }
-    if (grid >= (1L << 31)) return FAVAE_ERR_UNSUPPORTED;
+    if (grid >= (1L << 31)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     float* part = (float*)ws;
     char* p2 = (char*)ws + (((size_t)grid * ksize * sizeof(float) + 255) / 256) * 256;
     const size_t cws = favae_colsum_workspace(grid, ksize);
     float* dgv = (float*)(p2 + ((cws + 255) / 256) * 256);
-    if ((char*)(dgv + ksize) > (char*)ws + ws_bytes) return FAVAE_ERR_WORKSPACE;
+    if ((char*)(dgv + ksize) > (char*)ws + ws_bytes) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     a.x = x; a.dy = dy; a.sigma = sigma; a.dx = dx; a.part = dsigma ? part : nullptr;
     const size_t shm = shm_floats(a, true) * sizeof(float);
     static bool attr = false;

@@ -8,7 +8,7 @@
 #define FAVAE_CHECK_LAUNCH()                                   \
     do {                                                       \
         hipError_t e__ = hipGetLastError();                    \
-        if (e__ != hipSuccess) return FAVAE_ERR_LAUNCH;        \
+        if (e__ != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH); \
     } while (0)
 
 // ---- launch profiler (prof.hip): FAVAE_KLAUNCH == hipLaunchKernelGGL, plus two events on the launch stream when enabled --------
@@ -16,6 +16,7 @@ extern int favae_prof_level_;
 void* favae_prof_begin_(const void* host_fn, hipStream_t s);
 void favae_prof_end_(void* rec, hipStream_t s);
 void favae_prof_note_(double flops, double bytes);      // algorithmic work of the NEXT launch of this thread (roofline numerator)
+int favae_prof_fail_(int code);                         // error return of an entry point: drops a pending note (it must not reach a later launch)
 #define FAVAE_PROF_NOTE(flops, bytes)                          \
     do {                                                       \
         if (favae_prof_level_) favae_prof_note_((double)(flops), (double)(bytes)); \
@@ -29,7 +30,7 @@ void favae_prof_note_(double flops, double bytes);      // algorithmic work of t
 
 #define FAVAE_REQUIRE(cond)                                    \
     do {                                                       \
-        if (!(cond)) return FAVAE_ERR_BAD_ARG;                 \
+        if (!(cond)) return favae_prof_fail_(FAVAE_ERR_BAD_ARG); \
     } while (0)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

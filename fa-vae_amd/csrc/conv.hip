@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 }
 
 int launch_absmax(const float* x, int64_t n, float* out, hipStream_t s) {
-    if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
+    if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     long blocks = (n / 4 + 255) / 256;
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
     FAVAE_PROF_NOTE(0, 4.0 * n);
@@ -829,7 +829,7 @@ extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const fl
 extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, const void* wsplit, int planes,
                                     const float* x_absmax, const float* bias, const float* resid, const float* scale,
                                     const float* shift, float* y, favae_stream_t stream) {
-    if (!sp_fwd_eligible(d, scale != nullptr)) return FAVAE_ERR_UNSUPPORTED;
+    if (!sp_fwd_eligible(d, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     FAVAE_REQUIRE(wsplit && (planes == 3 || ((planes == 2 || planes == 1) && x_absmax)));
     return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr);
 }
@@ -858,9 +858,9 @@ extern "C" int favae_conv_planes_ok(const favae_conv_desc* d, int has_affine) {
 extern "C" int favae_conv_fwd_split_planes(const favae_conv_desc* d, const float* x, const void* wsplit, int planes,
                                            const float* x_absmax, const float* bias, const float* resid, const float* scale,
                                            const float* shift, float* y, void* planes_out, favae_stream_t stream) {
-    if (!sp_fwd_eligible(d, scale != nullptr)) return FAVAE_ERR_UNSUPPORTED;
+    if (!sp_fwd_eligible(d, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     FAVAE_REQUIRE(wsplit && (planes == 3 || ((planes == 2 || planes == 1) && x_absmax)));
-    if (planes_out && !(planes == 2 && planes_producer_ok(d, scale != nullptr) && al16(planes_out))) return FAVAE_ERR_UNSUPPORTED;
+    if (planes_out && !(planes == 2 && planes_producer_ok(d, scale != nullptr) && al16(planes_out))) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, planes_out);
 }
 
@@ -885,8 +885,8 @@ extern "C" int favae_conv_fwd_split_stats(const favae_conv_desc* d, const float*
                                           const float* shift, float* y, void* part, size_t part_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && wsplit && x_absmax && part);
     const int tiles = favae_conv_stats_tiles(d, scale != nullptr);
-    if (!tiles || (planes != 2 && planes != 1)) return FAVAE_ERR_UNSUPPORTED;
-    if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return FAVAE_ERR_WORKSPACE;
+    if (!tiles || (planes != 2 && planes != 1)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr, nullptr,
                          (double*)part);
 }
@@ -897,8 +897,8 @@ extern "C" int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy,
                                       favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && dy && wsplit && dy_absmax && da && x && mean && rstd && gamma && beta && part && groups > 0);
     const int tiles = favae_conv_gnbwd_tiles(d);
-    if (!tiles || (planes != 2 && planes != 1) || d->Cout % groups != 0) return FAVAE_ERR_UNSUPPORTED;
-    if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return FAVAE_ERR_WORKSPACE;
+    if (!tiles || (planes != 2 && planes != 1) || d->Cout % groups != 0) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     GnBwdEpi gb{x, mean, rstd, gamma, beta, (double*)part, groups, act};
     return conv_fwd_impl(d, dy, (const float*)wsplit, nullptr, nullptr, nullptr, nullptr, da, planes, dy_absmax, stream, nullptr, &gb);
 }
@@ -987,7 +987,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     const int xf = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_NONE ? 1 : 3)) : 0;
     const bool buf_ok = !force_generic() && !force_nobuf() && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) &&
                         (size_t)d->N * a.out_img * d->Cout * 4 < ((size_t)1 << 32) && (d->gather == FAVAE_GATHER_PLAIN || xf == 0);
-    if (special && !(buf_ok && use_b6() && bn == 128 && w6 && d->gather == FAVAE_GATHER_PLAIN)) return FAVAE_ERR_UNSUPPORTED;
+    if (special && !(buf_ok && use_b6() && bn == 128 && w6 && d->gather == FAVAE_GATHER_PLAIN)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     a.x_bytes = (unsigned)xb; a.aff_bytes = (unsigned)ab;
     a.planes_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)(wplanes ? wb / 16 * wrec_bytes(wplanes) : wb);
@@ -1013,10 +1013,10 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         else FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 3, KS>), hgrid, dim3(512), 0, s, a);               \
     } while (0)
 #define FAVAE_LAUNCH_HALO(X) FAVAE_LAUNCH_HALO_K(X, 3)
-        if (planes_out && !(halo_ok && wplanes == 2 && xf != 3)) return FAVAE_ERR_UNSUPPORTED;
+        if (planes_out && !(halo_ok && wplanes == 2 && xf != 3)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         const bool fp16p = wplanes == 2 || wplanes == 1;
-        if (gb && !(halo_ok && fp16p && xf == 0 && !planes_out && !bias && !resid)) return FAVAE_ERR_UNSUPPORTED;
-        if (stats_part && !(halo_ok && fp16p && (xf == 0 || xf == 2) && !planes_out && !gb)) return FAVAE_ERR_UNSUPPORTED;
+        if (gb && !(halo_ok && fp16p && xf == 0 && !planes_out && !bias && !resid)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+        if (stats_part && !(halo_ok && fp16p && (xf == 0 || xf == 2) && !planes_out && !gb)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (gb && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, true>), hgrid, dim3(512), 0, s, a);
         else if (gb) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 1, 3, false, true>), hgrid, dim3(512), 0, s, a);
         else if (stats_part && xf == 0 && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
@@ -1132,7 +1132,7 @@ static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float
     const int cm = conv_mode();
     const int np = ((cm == 2 || cm == 1) && x_absmax && dy_absmax) ? cm : 3;
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
-    if (ws_bytes < favae_conv_wgrad_workspace(d)) return FAVAE_ERR_WORKSPACE;
+    if (ws_bytes < favae_conv_wgrad_workspace(d)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     // roofline numerators: same FLOPs as the forward conv; one read of x and of dy, one write of dw
     FAVAE_PROF_NOTE(2.0 * d->N * d->Hout * d->Wout * d->Cout * d->KH * d->KW * d->Cin,
                     4.0 * ((double)d->N * d->Hin * d->Win * d->Cin + (double)d->N * d->Hout * d->Wout * d->Cout +
@@ -1186,7 +1186,7 @@ static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float
     a.pad_w = d->pad + d->pad_dw;
     a.dy_step = 1; a.dy_row = d->Wout; a.dy_img = d->Hout * d->Wout; a.dy_off = 0;
     if (d->lat_step == 2) {
-        if (d->lat_side != 1) return FAVAE_ERR_UNSUPPORTED;          // weight gradients: only the conv OUTPUT may be a sub-grid
+        if (d->lat_side != 1) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);          // weight gradients: only the conv OUTPUT may be a sub-grid
         a.dy_step = 2; a.dy_row = 2 * d->Wout; a.dy_img = 4 * d->Hout * d->Wout; a.dy_off = d->lat_oh * a.dy_row + d->lat_ow;
     }
     a.N = d->N; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->Cin; a.Hout = d->Hout; a.Wout = d->Wout; a.Cout = d->Cout;
@@ -1217,7 +1217,7 @@ static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float
     a.x_bytes = (unsigned)xb; a.aff_bytes = (unsigned)ab;
     if (special && !(buf_ok && use_b6() && bco == 128 && bci == 128 && d->gather == FAVAE_GATHER_PLAIN &&
                      (size_t)d->N * a.dy_img * d->Cout * 4 < ((size_t)1 << 32)))
-        return FAVAE_ERR_UNSUPPORTED;
+        return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
 #define FAVAE_LAUNCH_WBUF(X)                                                                                       \
     do {                                                                                                           \
         if (bco == 128 && bci == 128) FAVAE_KLAUNCH((conv_wgrad_buf_kernel<128, 128, 2, 2, X>), grid, dim3(256), 0, s, a); \
@@ -1496,12 +1496,12 @@ extern "C" size_t favae_colsum_workspace(int64_t M, int C) { return (size_t)cols
 extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, int accumulate, float* absmax_out, void* ws,
                             size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(a && out && ws && M > 0 && C > 0);
-    if (ws_bytes < favae_colsum_workspace(M, C)) return FAVAE_ERR_WORKSPACE;
+    if (ws_bytes < favae_colsum_workspace(M, C)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     const int nb = colsum_blocks(M);
     const long rpb = (M + nb - 1) / nb;
     hipStream_t s = (hipStream_t)stream;
     unsigned* amax = (unsigned*)absmax_out;
-    if (amax && hipMemsetAsync(amax, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
+    if (amax && hipMemsetAsync(amax, 0, sizeof(float), s) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     FAVAE_PROF_NOTE(0, 4.0 * M * C);
     if (C % 4 == 0 && ((((uintptr_t)a) & 15) == 0))
         FAVAE_KLAUNCH(colsum_partial_vec_kernel, dim3(1, nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb, amax);
@@ -1515,7 +1515,7 @@ extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, int ac
 
 extern "C" int favae_upsample2x_bwd(const float* du, float* dx, int N, int H, int W, int C, favae_stream_t stream) {
     FAVAE_REQUIRE(du && dx && N > 0 && H > 0 && W > 0 && C > 0);
-    if (C % 4) return FAVAE_ERR_UNSUPPORTED;
+    if (C % 4) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     size_t total = (size_t)N * H * W * (C / 4);
     FAVAE_KLAUNCH(upsample2x_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, du, dx, N, H, W,
                        C / 4);

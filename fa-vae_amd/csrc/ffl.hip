@@ -252,7 +252,7 @@ int launch_fft(FftArgs& a, hipStream_t s) {
     }
     const long chunks = (a.inner + a.IC - 1) / a.IC;
     const long blocks = a.outer * chunks;
-    if (blocks <= 0 || blocks >= (1L << 31)) return FAVAE_ERR_BAD_ARG;
+    if (blocks <= 0 || blocks >= (1L << 31)) return favae_prof_fail_(FAVAE_ERR_BAD_ARG);
     {   // bytes this pass must move: its input lines (two real tensors for IN_DIFF, complex otherwise) + its output lines
         const double lines = (double)a.outer * a.inner;
         const double in_b = IN == IN_DIFF ? 8.0 * a.Lin : 8.0 * a.Lin, out_b = (OUT == OUT_REAL ? (a.out2 ? 8.0 : 4.0) : 8.0) * a.Lout;
@@ -279,12 +279,12 @@ extern "C" size_t favae_ffl_workspace(int N, int H, int W, int C) {
 extern "C" int favae_ffl_fwd(const float* pred, const float* target, int N, int H, int W, int C, float loss_weight, float* loss,
                              float* spec, void* ws, size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(pred && target && loss && spec && ws && N > 0 && C > 0);
-    if (H < 1 || W < 1 || H > 1024 || W > 1024) return FAVAE_ERR_UNSUPPORTED;
-    if (ws_bytes < favae_ffl_workspace(N, H, W, C)) return FAVAE_ERR_WORKSPACE;
+    if (H < 1 || W < 1 || H > 1024 || W > 1024) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (ws_bytes < favae_ffl_workspace(N, H, W, C)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     hipStream_t s = (hipStream_t)stream;
     unsigned* planemax = (unsigned*)ws;
     double* part = (double*)((char*)ws + (((size_t)N * C * sizeof(unsigned) + 255) / 256) * 256);
-    if (hipMemsetAsync(planemax, 0, (size_t)N * C * sizeof(unsigned), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
+    if (hipMemsetAsync(planemax, 0, (size_t)N * C * sizeof(unsigned), s) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     FftArgs a{};
     a.C = C;
     const int Wh = stored_bins(W);
@@ -313,8 +313,8 @@ extern "C" int favae_ffl_fwd(const float* pred, const float* target, int N, int 
 extern "C" int favae_ffl_bwd(const float* spec, const float* gloss, int N, int H, int W, int C, float* gpred, float* gtarget,
                              void* ws, size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(spec && gloss && gpred && ws && N > 0 && C > 0);
-    if (H < 1 || W < 1 || H > 1024 || W > 1024) return FAVAE_ERR_UNSUPPORTED;
-    if (ws_bytes < favae_ffl_workspace(N, H, W, C)) return FAVAE_ERR_WORKSPACE;
+    if (H < 1 || W < 1 || H > 1024 || W > 1024) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (ws_bytes < favae_ffl_workspace(N, H, W, C)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     hipStream_t s = (hipStream_t)stream;
     FftArgs a{};
     a.C = C;

@@ -428,7 +428,7 @@ extern "C" int favae_bgemm_sp(int ta, int tb, int M, int N, int K, float alpha, 
     FAVAE_REQUIRE(A && B && C && amaxA && amaxB && M > 0 && N > 0 && K > 0 && batch > 0 && (ta == 0 || ta == 1) && (tb == 0 || tb == 1));
     const bool okA = aligned16(A) && lda % 4 == 0 && strideA % 4 == 0 && (ta == 0 ? K % 4 == 0 : M % 4 == 0);
     const bool okB = aligned16(B) && ldb % 4 == 0 && strideB % 4 == 0 && (tb == 0 ? K % 4 == 0 : N % 4 == 0);
-    if (!okA || !okB || (ta == 1 && tb == 0)) return FAVAE_ERR_UNSUPPORTED;
+    if (!okA || !okB || (ta == 1 && tb == 0)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     GemmSpArgs a;
     a.A = A; a.B = B; a.C = C; a.amaxA = amaxA; a.amaxB = amaxB;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.sA = strideA; a.sB = strideB; a.sC = strideC;
@@ -458,7 +458,7 @@ extern "C" int favae_attn_bwd_point(float* s, float* dp, const float* lse, const
     FAVAE_REQUIRE(s && dp && lse && delta && ds_absmax && rows > 0 && L > 0 && rows_per_batch > 0 && row0 >= 0 &&
                   row0 + rows_per_batch <= Ltot);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ds_absmax, 0, sizeof(float), st) != hipSuccess) return FAVAE_ERR_LAUNCH;
+    if (hipMemsetAsync(ds_absmax, 0, sizeof(float), st) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     FAVAE_PROF_NOTE(0, 16.0 * rows * L);
     FAVAE_KLAUNCH(attn_bwd_point_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, s, dp, lse, delta, (long)rows, L, rows_per_batch,
                   row0, Ltot, alpha, (unsigned*)ds_absmax);

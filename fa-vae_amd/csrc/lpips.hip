@@ -196,7 +196,7 @@ extern "C" size_t favae_lpips_level_workspace(int N) { return (size_t)(N > 0 ? N
 extern "C" int favae_lpips_level(const float* a, const float* b, const float* w, int N, int HW, int C, float* val, int accumulate,
                                  void* ws, size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(a && b && w && val && ws && N > 0 && HW > 0 && level_c_ok(C));
-    if (ws_bytes < favae_lpips_level_workspace(N)) return FAVAE_ERR_WORKSPACE;
+    if (ws_bytes < favae_lpips_level_workspace(N)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     const int chunks = level_chunks(HW, C);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(N * chunks));

@@ -108,8 +108,8 @@ int ew_blocks(long n) {
 
 template <int SQ>
 int diff_sum(const float* a, const float* b, int64_t n, float scale, float* loss, void* ws, size_t ws_bytes, hipStream_t s) {
-    if (!(a && b && loss && ws && n > 0)) return FAVAE_ERR_BAD_ARG;
-    if (ws_bytes < RED_BLOCKS * sizeof(double)) return FAVAE_ERR_WORKSPACE;
+    if (!(a && b && loss && ws && n > 0)) return favae_prof_fail_(FAVAE_ERR_BAD_ARG);
+    if (ws_bytes < RED_BLOCKS * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     long nb = (n / 4 + 255) / 256;
     if (nb > RED_BLOCKS) nb = RED_BLOCKS;
     if (nb < 1) nb = 1;
@@ -222,7 +222,7 @@ extern "C" int favae_u8_to_float_nhwc(const unsigned char* in, float* out, int64
 extern "C" int favae_hinge_mean(const float* x, int64_t n, int mode, float* loss, void* ws, size_t ws_bytes,
                                 favae_stream_t stream) {
     FAVAE_REQUIRE(x && loss && ws && n > 0 && mode >= 0 && mode <= 2);
-    if (ws_bytes < RED_BLOCKS * sizeof(double)) return FAVAE_ERR_WORKSPACE;
+    if (ws_bytes < RED_BLOCKS * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     long nb = (n + 255) / 256;
     nb = nb > RED_BLOCKS ? RED_BLOCKS : nb;
     hipStream_t s = (hipStream_t)stream;

@@ -432,12 +432,12 @@ extern "C" int favae_gn_stats(const float* x, const float* gamma, const float* b
                               size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(x && mean && rstd && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
-    if (ws_bytes < favae_gn_workspace(N, HW, C)) return FAVAE_ERR_WORKSPACE;
+    if (ws_bytes < favae_gn_workspace(N, HW, C)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     hipStream_t s = (hipStream_t)stream;
     double* part = (double*)ws;
     double* acc = (double*)((char*)ws + part_bytes(N, HW, C));
     FAVAE_REQUIRE(!absmax_out || scale);
-    if (absmax_out && hipMemsetAsync(absmax_out, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
+    if (absmax_out && hipMemsetAsync(absmax_out, 0, sizeof(float), s) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     launch_partial<0>(x, nullptr, gamma, beta, nullptr, nullptr, part, N, (long)HW, C, G, 0, s);
     FAVAE_CHECK_LAUNCH();
     FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N, gn_slabs(G)), dim3(256), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
@@ -454,9 +454,9 @@ extern "C" int favae_gn_stats_tiles(const void* part, int tiles, const float* ga
     FAVAE_REQUIRE(part && tiles > 0 && mean && rstd && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     FAVAE_REQUIRE(!absmax_out || scale);
-    if (ws_bytes < acc_bytes(N, C)) return FAVAE_ERR_WORKSPACE;
+    if (ws_bytes < acc_bytes(N, C)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     hipStream_t s = (hipStream_t)stream;
-    if (absmax_out && hipMemsetAsync(absmax_out, 0, sizeof(float), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
+    if (absmax_out && hipMemsetAsync(absmax_out, 0, sizeof(float), s) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N, gn_slabs(G)), dim3(256), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
                        (double*)ws, (long)HW, C, G, tiles, eps, (unsigned*)absmax_out);
     FAVAE_CHECK_LAUNCH();
@@ -498,7 +498,7 @@ static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, 
     FAVAE_REQUIRE(da && x && gamma && beta && mean && rstd && dx && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
     FAVAE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr));
     if (ws_bytes < (tile_partials ? favae_gn_bwd_tiles_workspace(N, tile_partials, C) : favae_gn_workspace(N, HW, C)))
-        return FAVAE_ERR_WORKSPACE;
+        return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     hipStream_t s = (hipStream_t)stream;
     double* part = (double*)ws;
     double* acc = (double*)((char*)ws + (tile_partials ? (size_t)N * tile_partials * C * 2 * sizeof(double) : part_bytes(N, HW, C)));

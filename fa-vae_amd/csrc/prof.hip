@@ -69,6 +69,11 @@ void favae_prof_note_(double flops, double bytes) {
     t_note = true;
 }
 
+int favae_prof_fail_(int code) {
+    t_note = false;
+    return code;
+}
+
 void* favae_prof_begin_(const void* host_fn, hipStream_t s) {
     const bool noted = t_note;
     const double fl = noted ? t_flops : 0.0, by = noted ? t_bytes : 0.0;
@@ -91,6 +96,7 @@ void favae_prof_end_(void* rec, hipStream_t s) {
 extern "C" int favae_prof_enable(int level) {
     if (level < 0 || level > 2) return FAVAE_ERR_BAD_ARG;
     favae_prof_level_ = level;
+    t_note = false;                         // a note left by a call that never launched must not be attributed to a later kernel
     return FAVAE_OK;
 }
 

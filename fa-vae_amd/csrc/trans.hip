@@ -144,7 +144,7 @@ int ew_grid(long n) {
 extern "C" int favae_affine_rows(const float* x, const float* scale, const float* shift, float* y, int N, int64_t HW, int C, int act,
                                  favae_stream_t stream) {
     FAVAE_REQUIRE(x && scale && shift && y && N > 0 && HW > 0 && C > 0);
-    if (C % 4 || ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)scale) | ((uintptr_t)shift)) & 15)) return FAVAE_ERR_UNSUPPORTED;
+    if (C % 4 || ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)scale) | ((uintptr_t)shift)) & 15)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     const long total4 = (long)N * HW * (C / 4);
     FAVAE_KLAUNCH(affine_rows_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
                        (const float4*)scale, (const float4*)shift, (float4*)y, total4, (long)HW * (C / 4), C / 4, act);
@@ -156,7 +156,7 @@ extern "C" int favae_layernorm_fwd(const float* x, const float* gamma, const flo
                                    int64_t rows, int C, float eps, favae_stream_t stream) {
     FAVAE_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0 && C > 0);
     if (C % 4 || C > 256 * LN_MAXQ || ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15))
-        return FAVAE_ERR_UNSUPPORTED;
+        return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     const long blocks = (rows + 3) / 4;
     FAVAE_KLAUNCH(layernorm_fwd_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, x,
                        gamma, beta, y, mean, rstd, (long)rows, C, eps);
@@ -169,7 +169,7 @@ extern "C" int favae_layernorm_bwd(const float* dy, const float* x, const float*
     FAVAE_REQUIRE(dy && x && gamma && mean && rstd && dx && dy_xhat && rows > 0 && C > 0);
     if (C % 4 || C > 256 * LN_MAXQ ||
         ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)dy_xhat) | ((uintptr_t)gamma)) & 15))
-        return FAVAE_ERR_UNSUPPORTED;
+        return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     const long blocks = (rows + 3) / 4;
     FAVAE_KLAUNCH(layernorm_bwd_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, dy, x,
                        gamma, mean, rstd, dx, dy_xhat, (long)rows, C);
@@ -179,7 +179,7 @@ extern "C" int favae_layernorm_bwd(const float* dy, const float* x, const float*
 
 extern "C" int favae_dropout(const float* x, const float* gate, float* y, int64_t n, float p, uint32_t seed, favae_stream_t stream) {
     FAVAE_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f);
-    if (n >= ((int64_t)1 << 32)) return FAVAE_ERR_UNSUPPORTED;          // the mask hashes a 32-bit element index
+    if (n >= ((int64_t)1 << 32)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);          // the mask hashes a 32-bit element index
     const double t = (double)p * 4294967296.0;
     const unsigned thresh = p > 0.f ? (unsigned)(t > 4294967295.0 ? 4294967295.0 : t) : 0u;
     const float scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;

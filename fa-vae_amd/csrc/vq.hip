@@ -410,8 +410,8 @@ extern "C" size_t favae_vq_workspace(int T, int d, int C) {
 extern "C" int favae_vq_lookup(const float* z, const float* embed, int T, int d, int C, float tie_eps, int64_t* idx, float* zq,
                                float* zn, float* en, void* ws, size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(z && embed && idx && zq && zn && en && ws && T > 0 && d > 0 && C > 0);
-    if (ws_bytes < favae_vq_workspace(T, d, C)) return FAVAE_ERR_WORKSPACE;
-    if ((size_t)d * sizeof(float) > 64 * 1024) return FAVAE_ERR_UNSUPPORTED;
+    if (ws_bytes < favae_vq_workspace(T, d, C)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
+    if ((size_t)d * sizeof(float) > 64 * 1024) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     hipStream_t s = (hipStream_t)stream;
     const int tiles_c = cdiv(C, VBM), tiles_t = cdiv(T, VBN);
     Top2* part = (Top2*)ws;
@@ -444,14 +444,14 @@ extern "C" size_t favae_vq_segment_workspace(int T, int C) {
 extern "C" int favae_vq_segment_sum(const float* zn, const int64_t* idx, int T, int d, int C, float* bins, float* embed_sum,
                                     void* ws, size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(zn && idx && bins && embed_sum && ws && T > 0 && d > 0 && C > 0);
-    if (d > 512) return FAVAE_ERR_UNSUPPORTED;
-    if (ws_bytes < favae_vq_segment_workspace(T, C)) return FAVAE_ERR_WORKSPACE;
+    if (d > 512) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (ws_bytes < favae_vq_segment_workspace(T, C)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     hipStream_t s = (hipStream_t)stream;
     int* count = (int*)ws;
     int* offs = count + C;
     int* list = offs + C + 1;
     float* part = (float*)((char*)ws + ((((size_t)2 * C + 1 + (size_t)T) * sizeof(int) + 255) / 256) * 256);
-    if (hipMemsetAsync(count, 0, (size_t)C * sizeof(int), s) != hipSuccess) return FAVAE_ERR_LAUNCH;
+    if (hipMemsetAsync(count, 0, (size_t)C * sizeof(int), s) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     int hb = cdiv(T, 256);
     if (hb > 1024) hb = 1024;
     FAVAE_KLAUNCH(vq_hist_kernel, dim3(hb), dim3(256), 0, s, (const long long*)idx, T, C, count);

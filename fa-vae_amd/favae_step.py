@@ -162,38 +162,54 @@ class TrainStep:
             dist.broadcast(self.dpflat, 0)
         flat = set(id(p) for p in self.params) | (set(id(p) for p in self.dparams) if self.train_disc else set())
         for t in list(self.model.parameters()) + list(self.model.buffers()):
-            if id(t) not in flat and t.is_floating_point():
+            if id(t) in flat:
+                continue
+            if t.dtype == torch.bool:           # e.g. the codebook's `initted` flag: collectives have no bool, go through uint8
+                u = t.data.to(torch.uint8)
+                dist.broadcast(u, 0)
+                t.data.copy_(u.to(torch.bool))
+            else:                               # every other buffer, integer ones included (BatchNorm num_batches_tracked)
                 dist.broadcast(t.data, 0)
 
     def _setup_overlapped_exchange(self):
         """Cut the flat gradient buffer where backward finishes whole module groups and start each group's all-reduce right there
-        (FAVAE_OVERLAP_COMM=0: one all-reduce after backward).  Flat layout = registration order: encoder [.. mid, final, (sigmas)],
-        decoder [(sigmas), fcm_1, conv_in, fcm_2, mid, fcm_3 | up, fcm_4, final], quantizer, model.sigmas; backward finishes
-        decoder.up..final first, then the rest of the decoder and the quantizer, then encoder.mid..final, then the encoder's
-        down path."""
+        (FAVAE_OVERLAP_COMM=0: one all-reduce after backward).  Flat layout = registration order: encoder [conv_in, down, mid, final,
+        (sigmas)], decoder [(sigmas), fcm_1, conv_in, fcm_2, mid, fcm_3 | up, fcm_4, final], quantizer, model.sigmas; backward
+        finishes decoder.up..final first, then the rest of the decoder and the quantizer, then encoder.mid..final, then the encoder's
+        down path.  A segment may be several ranges (the sigmas are cut out of their neighbours)."""
         import os
         total = self.gflat.numel()
         if os.environ.get("FAVAE_OVERLAP_COMM", "1") == "0":
             return
-        off = {}
+        enc, dec = self.model.encoder, self.model.decoder
+        if not (hasattr(dec, "up") and hasattr(enc, "mid") and list(dec.up.parameters()) and list(enc.mid.parameters())):
+            return
+        # Segment of a parameter = the mark behind which EVERY autograd node that uses it has run.  That is a property of the
+        # module the parameter lives in: decoder.{up, fcm_4, final} are only used downstream of decoder.up's input (mark 0), the
+        # other decoder submodules and the quantizer downstream of the encoder output (mark 1), encoder.{mid, final} downstream of
+        # encoder.mid's input (mark 2).  Everything else goes to the last segment, which is exchanged after backward has returned:
+        # the encoder's down path, and every parameter registered directly on encoder / decoder / model -- the learnable blur
+        # sigmas, whose taps sit on BOTH sides of the marks (EncoderGauss blurs the conv_in and down outputs before encoder.mid's
+        # input exists: their dsigma arrives after mark 2 has fired).
+        seg_of = {}
+        for mods, i in (((getattr(dec, n, None) for n in ("up", "fcm_4", "final")), 0),
+                        ((m for n, m in dec.named_children() if n not in ("up", "fcm_4", "final")), 1),
+                        ((self.model.quantizer,), 1),
+                        ((enc.mid, enc.final), 2)):
+            for m in mods:
+                if m is not None:
+                    for p in m.parameters():
+                        seg_of[id(p)] = i
+        segs = [[], [], [], []]
         pos = 0
         for p in self.params:
-            off[id(p)] = pos
-            pos += p.numel()
-        enc, dec = self.model.encoder, self.model.decoder
-
-        def first_off(mod):
-            ps = list(mod.parameters())
-            return off[id(ps[0])] if ps else None
-        n_enc = sum(p.numel() for p in enc.parameters())
-        n_dec = sum(p.numel() for p in dec.parameters())
-        o_up, o_mid = first_off(dec.up) if hasattr(dec, "up") else None, first_off(enc.mid) if hasattr(enc, "mid") else None
-        if o_up is None or o_mid is None:
-            return
-        segs = [[(o_up, n_enc + n_dec)],                       # decoder.up, fcm_4, final
-                [(n_enc, o_up), (n_enc + n_dec, total)],       # decoder head, quantizer, pair-wise sigmas
-                [(o_mid, n_enc)],                              # encoder.mid, final, own sigmas
-                [(0, o_mid)]]                                  # encoder.conv_in, down
+            i, n = seg_of.get(id(p), 3), p.numel()
+            if segs[i] and segs[i][-1][1] == pos:
+                segs[i][-1] = (segs[i][-1][0], pos + n)       # contiguous with the previous range of this segment
+            else:
+                segs[i].append((pos, pos + n))
+            pos += n
+        assert pos == total
         self.exchange = GradExchange(self.gflat, segs, side_stream=lambda: K._SIDE["stream"])
         self._armed = False
 
@@ -203,18 +219,25 @@ class TrainStep:
                     self.exchange.fire(i)
             return cb
 
+        def marked(x, i):
+            y = _GradMark.apply(x, mark(i))
+            st = getattr(x, "_favae_gnstats", None)
+            if st is not None:                  # the view shares x's version counter: the tile statistics the producing conv left on
+                y._favae_gnstats = st           # x stay valid for the GroupNorm behind the mark (ops.gn_stats), as without marks
+            return y
+
         def pre_hook(i):
             def hook(mod, args):
                 x = args[0]
                 if torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
-                    return (_GradMark.apply(x, mark(i)),) + tuple(args[1:])
+                    return (marked(x, i),) + tuple(args[1:])
                 return None
             return hook
 
         def enc_out_hook(mod, args, out):
             h = out[0]
             if torch.is_grad_enabled() and h.requires_grad:
-                return (_GradMark.apply(h, mark(1)),) + tuple(out[1:])
+                return (marked(h, 1),) + tuple(out[1:])
             return None
         dec.up.register_forward_pre_hook(pre_hook(0))
         enc.register_forward_hook(enc_out_hook)

@@ -46,10 +46,11 @@ def _worker(rank, world, port, q):
 
     for _ in range(2):
         res = tr.step(x, all_reduce=dist.all_reduce, grad_all_reduce=grad_avg)
-    out = {"embed": tr.P["quantizer._codebook.embed"].clone(), "cluster": tr.P["quantizer._codebook.cluster_size"].clone(),
-           "w": tr.P["encoder.conv_in.weight"].detach().clone(), "sig": tr.P["decoder.sigmas"].detach().clone(),
-           "g": res["grads"]["decoder.final.2.weight"].clone()}
-    q.put((rank, out))
+    # numpy arrays are pickled BY VALUE; torch tensors would travel as shared-memory file descriptors that die with this process
+    # (ConnectionResetError in q.get when the producer exits first: 2 of 11 runs in round 2)
+    out = {"embed": tr.P["quantizer._codebook.embed"], "cluster": tr.P["quantizer._codebook.cluster_size"],
+           "w": tr.P["encoder.conv_in.weight"], "sig": tr.P["decoder.sigmas"], "g": res["grads"]["decoder.final.2.weight"]}
+    q.put((rank, {k: v.detach().cpu().numpy().copy() for k, v in out.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,6 +67,7 @@ def test_two_rank_step_equals_global_batch_step():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    got = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in got.items()}
     # single process, global batch
     cfg = O.OracleConfig(**TINY)
     tr = O.OracleTrainer(cfg, O.StepConfig(lr=1e-3, dsl_weight=0.01), dtype=torch.float64)
@@ -112,26 +114,43 @@ def test_trainstep_flat_views():
 # flat buffers, segment tiling, hook placement, firing order, collectives -- is the product code.
 # ---------------------------------------------------------------------------------------------------------------------------
 class _ToyEnc(torch.nn.Module):
+    """EncoderGauss layout (models/codec.py:193-314): conv_in/down, mid, final and its OWN `sigmas`, whose taps sit before AND after
+    `mid` -- the taps before `mid` run their backward after the gradient mark on mid's input has fired."""
+
     def __init__(self):
         super().__init__()
         self.down = torch.nn.Linear(6, 8)
         self.mid = torch.nn.Linear(8, 8)
         self.final = torch.nn.Linear(8, 4)
+        self.sigmas = torch.nn.Parameter(torch.tensor([3.0, 2.0, 1.5, 1.0]))
 
     def forward(self, x):
-        h = self.final(torch.tanh(self.mid(torch.tanh(self.down(x)))))
-        return h, [h]
+        feats = []
+        h = torch.tanh(self.down(x))
+        feats.append(h * self.sigmas[0])
+        feats.append(torch.sin(h) * self.sigmas[1])
+        h = torch.tanh(self.mid(h))
+        feats.append(h * self.sigmas[2])
+        h = self.final(h)
+        feats.append(h * self.sigmas[3])
+        return h, feats
 
 
 class _ToyDec(torch.nn.Module):
+    """decoder with its own sigmas registered FIRST (models/codec.py:882-1004) and taps before and after `up`"""
+
     def __init__(self):
         super().__init__()
+        self.sigmas = torch.nn.Parameter(torch.tensor([1.0, 2.0]))
         self.head = torch.nn.Linear(4, 8)
         self.up = torch.nn.Linear(8, 8)
         self.final = torch.nn.Linear(8, 6)
 
     def forward(self, z):
-        return self.final(torch.tanh(self.up(torch.tanh(self.head(z)))))
+        h = torch.tanh(self.head(z))
+        t0 = h * self.sigmas[0]
+        h = torch.tanh(self.up(h))
+        return self.final(h), [t0, h * self.sigmas[1]]
 
 
 class _ToyModel(torch.nn.Module):
@@ -142,8 +161,10 @@ class _ToyModel(torch.nn.Module):
         self.register_buffer("codebook", torch.randn(5, 4))
 
     def forward(self, x):
-        h, _ = self.encoder(x)
-        return self.decoder(self.quantizer(h))
+        h, ef = self.encoder(x)
+        y, df = self.decoder(self.quantizer(h))
+        self.taps = sum((f ** 2).mean() for f in ef + df)         # the DSL terms: every tap reaches the loss
+        return y
 
 
 def _exchange_worker(rank, world, port, q, overlap):
@@ -162,16 +183,30 @@ def _exchange_worker(rank, world, port, q, overlap):
         fire0 = ts.exchange.fire
         ts.exchange.fire = lambda i: (order.append(i) if not ts.exchange.fired[i] else None, fire0(i))[1]
     xs = torch.randn(4, 6, generator=torch.Generator().manual_seed(7))
-    x = xs[2 * rank:2 * rank + 2]
+    per = 4 // world
+    x = xs[per * rank:per * rank + per]
     ts.gflat.zero_()
-    loss = ((model(x) - x) ** 2).mean()
+    snaps = {}
+    if overlap:                                              # the invariant of the scheme: a segment is FINAL when it is fired
+        fire1 = ts.exchange.fire
+
+        def fire_snap(i):
+            if not ts.exchange.fired[i] and world == 1:      # world 1: the all-reduce is the identity, the buffer stays local
+                snaps[i] = [ts.gflat[a:b].clone() for a, b in ts.exchange.segments[i]]
+            return fire1(i)
+        ts.exchange.fire = fire_snap
+    loss = ((model(x) - x) ** 2).mean() + 0.1 * model.taps
     ts.backward({"loss_g": loss})
+    for i, parts in snaps.items():
+        for (a, b), t in zip(ts.exchange.segments[i], parts):
+            assert torch.equal(t, ts.gflat[a:b]), "segment %d [%d, %d) was exchanged before its gradient was complete" % (i, a, b)
     local = ts.gflat.clone() if not overlap else None
     if ts.exchange is not None:
         ts.exchange.finish()
     else:
         dist.all_reduce(ts.gflat)
-    q.put((rank, {"state0": state0, "g": ts.gflat.clone().numpy(), "order": order, "segments": ts.exchange.segments if overlap else None}))
+    q.put((rank, {"state0": state0, "g": ts.gflat.clone().numpy(), "order": order, "segments": ts.exchange.segments if overlap else None,
+                  "snapshots": len(snaps)}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -196,7 +231,7 @@ def test_trainstep_host_logic_two_ranks(overlap):
         assert np.array_equal(got[0]["state0"][k], v.numpy()) and np.array_equal(got[1]["state0"][k], v.numpy()), k
     # (2) the exchanged flat gradient = sum over ranks of the local gradients = world x the global-batch gradient
     xs = torch.randn(4, 6, generator=torch.Generator().manual_seed(7))
-    loss = ((ref_model(xs) - xs) ** 2).mean()
+    loss = ((ref_model(xs) - xs) ** 2).mean() + 0.1 * ref_model.taps
     loss.backward()
     main = list(ref_model.encoder.parameters()) + list(ref_model.decoder.parameters()) + list(ref_model.quantizer.parameters())
     gref = torch.cat([p.grad.reshape(-1) for p in main]) * world           # mean over 4 samples vs sum of two means over 2
@@ -209,6 +244,32 @@ def test_trainstep_host_logic_two_ranks(overlap):
         segs = got[0]["segments"]
         n = gref.numel()
         assert sorted(r for s in segs for r in s)[0][0] == 0 and sorted(r for s in segs for r in s)[-1][1] == n
+        # (4) the sigmas of encoder and decoder (taps on both sides of the marks) are exchanged with the LAST segment only
+        sig_ranges, pos = [], 0
+        for mod in (ref_model.encoder, ref_model.decoder, ref_model.quantizer):        # the flat layout of TrainStep
+            for name, p in mod.named_parameters():
+                if name == "sigmas":
+                    sig_ranges.append((pos, pos + p.numel()))
+                pos += p.numel()
+        assert len(sig_ranges) == 2
+        for a, b in sig_ranges:
+            owners = [i for i, sg in enumerate(segs) for (lo, hi) in sg if lo < b and a < hi]
+            assert owners == [3], (a, b, owners)
+
+
+def test_segments_are_final_when_fired():
+    """World 1 (the all-reduce is the identity): what fire(i) hands to the collective equals the gradient at the end of backward,
+    for every segment.  A layout that puts the encoder's sigmas into the encoder.mid segment fails here: the taps in front of `mid`
+    add their dsigma after mark 2 has fired -- TrainStep therefore assigns segments per owning module and sends
+    every parameter registered directly on encoder / decoder / model with the last segment."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_exchange_worker, args=(0, 1, _free_port(), q, True))
+    p.start()
+    rank, got = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert got["order"] == [0, 1, 2, 3] and got["snapshots"] == 4
 
 
 def test_grad_exchange_rejects_bad_tilings():
