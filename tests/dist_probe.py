@@ -3,7 +3,11 @@ TrainStep(distributed=True) -- initial broadcast, codebook all-reduces inside th
 bucketed all-reduce -- on each rank's slice of a global batch, against ONE non-distributed TrainStep on the whole batch
 (favae_scripts/train_favae.py:239-259,344-347: what DDP + sync_codebook give the reference).  Checked: identical codebooks on every
 rank and equal to the global-batch EMA; all-reduced gradients / world == global-batch gradients; after a full step() the
-parameters of all ranks are identical.  world_size 1 (the single-GPU box) must be bit-identical to the non-distributed step."""
+parameters of all ranks are identical.  world_size 1 (the single-GPU box) must be bit-identical to the non-distributed step.
+
+FAVAE_PROBE_BACKEND=gloo: the same probe with gloo collectives on device tensors and every rank on cuda:0 -- a world-2 run of the
+real model + HIP kernels + GradExchange marks + codebook all-reduces on a box with ONE GPU (gloo stages device tensors through the
+host; the collectives' results are the same sums RCCL produces, the product code path is unchanged)."""
 import os
 import sys
 
@@ -20,9 +24,15 @@ from models.vqgan_fcm import VQGANFCM
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+BACKEND = os.environ.get("FAVAE_PROBE_BACKEND", "nccl")
+if BACKEND == "gloo":
+    local = local % max(1, torch.cuda.device_count())       # all ranks share the GPU(s) of the box
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
-dist.init_process_group("nccl", device_id=dev)
+if BACKEND == "gloo":
+    dist.init_process_group("gloo")
+else:
+    dist.init_process_group("nccl", device_id=dev)
 VARIANT = os.environ.get("FAVAE_PROBE_VARIANT", "gauss_resblock")
 flag = {"gauss_resblock": "use_gauss_resblock", "same_conv_gauss": "use_same_conv_gauss"}[VARIANT]
 mk = dict(codebook_size=256, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True, use_l2_quantizer=True,
@@ -61,12 +71,28 @@ def grads(ts, x):
 
 model, ts = make(True, perturb=rank > 0)
 assert ts.distributed and ts.world == world
+snaps = {}
+if ts.exchange is not None and world == 1:       # the all-reduce is the identity: what fire(i) hands over must already be final
+    _fire = ts.exchange.fire
+
+    def _fire_snap(i):
+        if not ts.exchange.fired[i]:
+            K.sync_side_stream()                  # weight gradients of the segment are queued on the side stream
+            snaps[i] = [ts.gflat[a:b].clone() for a, b in ts.exchange.segments[i]]
+        return _fire(i)
+    ts.exchange.fire = _fire_snap
 expect_overlap = os.environ.get("FAVAE_OVERLAP_COMM", "1") != "0"
 assert (ts.exchange is not None) == expect_overlap
 x = xg[PER * rank:PER * (rank + 1)].to(dev)
 out = grads(ts, x)
 if ts.exchange is not None:
     assert all(ts.exchange.fired), ts.exchange.fired
+    for i, parts in snaps.items():
+        for (a, b), t in zip(ts.exchange.segments[i], parts):
+            assert torch.equal(t, ts.gflat[a:b]), "segment %d [%d, %d) was exchanged before its gradient was complete" % (i, a, b)
+    if world == 1:
+        assert len(snaps) == len(ts.exchange.segments)
+        ts.exchange.fire = _fire
 g_dist = ts.gflat.clone() / world
 embed = model.quantizer._codebook.embed.clone()
 cluster = model.quantizer._codebook.cluster_size.clone()
@@ -100,5 +126,6 @@ dist.broadcast(p0, 0)
 assert torch.equal(p0, ts.pflat), "rank %d: parameters diverged after step()" % rank
 dist.barrier()
 if rank == 0:
-    print("DIST PROBE OK world=%d variant=%s overlap=%s grad_err=%.2e embed_err=%.2e" % (world, VARIANT, expect_overlap, err, e_err))
+    print("DIST PROBE OK world=%d backend=%s variant=%s overlap=%s grad_err=%.2e embed_err=%.2e"
+          % (world, BACKEND, VARIANT, expect_overlap, err, e_err))
 dist.destroy_process_group()

@@ -36,8 +36,9 @@ def test_model_under_torch_ddp():
     assert "DDP PROBE OK" in out.stdout
 
 
-def _run_probe(world, variant, overlap, port):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FAVAE_PROBE_VARIANT=variant, FAVAE_OVERLAP_COMM="1" if overlap else "0")
+def _run_probe(world, variant, overlap, port, backend="nccl"):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FAVAE_PROBE_VARIANT=variant, FAVAE_OVERLAP_COMM="1" if overlap else "0",
+               FAVAE_PROBE_BACKEND=backend)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_probe.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -60,6 +61,16 @@ def test_product_trainstep_two_ranks_equal_global_batch(variant):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs on the node (this box has %d)" % torch.cuda.device_count())
     _run_probe(2, variant, True, 29563)
+
+
+@pytest.mark.parametrize("variant,overlap", [("gauss_resblock", True), ("same_conv_gauss", True), ("gauss_resblock", False)])
+def test_product_trainstep_two_ranks_on_one_gpu(variant, overlap):
+    """World size 2 of the REAL product path on the single-GPU box: two fresh child processes share cuda:0 and exchange through gloo
+    on device tensors -- real VQGANFCM + HIP kernels + gradient marks / GradExchange + the two codebook all-reduces
+    (models/l2_quantize.py:419,427; favae_scripts/train_favae.py:344-347), 2 ranks x batch 2 against one rank on the concatenated
+    batch: gradients <= 2e-5 of the max, codebooks <= 1e-6, cluster sizes equal, parameters identical on both ranks after step()."""
+    out = _run_probe(2, variant, overlap, 29571, backend="gloo")
+    assert "backend=gloo" in out
 
 
 def test_bench_gpus_flag_launches_ranks():
