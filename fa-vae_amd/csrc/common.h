@@ -64,6 +64,23 @@ __device__ __forceinline__ double block_sum_d256(double v, double* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// ---- buffer addressing: wave-uniform descriptor + per-lane 32-bit byte offset (VGPR) + scalar byte offset (SGPR); offsets at or
+// beyond the descriptor's size (FAVAE_OOB) load zeros / drop the store in hardware (no exec-mask predication, no 64-bit address math)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#define FAVAE_OOB 0x80000000u
+
+template <typename R>
+__device__ __forceinline__ float4 bload(R rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+template <typename R>
+__device__ __forceinline__ void bstore(R rsrc, unsigned voff, unsigned soff, float4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, voff, soff, 0);
+}
+__device__ __forceinline__ auto make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+
 __device__ __forceinline__ float silu_f(float y) { return y / (1.0f + __expf(-y)); }
 
 // d act(y) / dy of the fused input activations (FAVAE_ACT_*: 1 SiLU, 2 LeakyReLU(0.2), 3 ReLU)

@@ -57,6 +57,16 @@ bool use_row3() {
     if (v < 0) { const char* e = getenv("FAVAE_WGRAD_ROW3"); v = (e && e[0] == '0') ? 0 : 1; }
     return v == 1;
 }
+// FAVAE_WGRAD_NINE=0 sends the 3x3 weight gradients back to the three-taps-per-workgroup kernel (A/B switch)
+// 1 (default) = 128 co x 64 ci, 8 waves, prefetch distance 1 (204 registers: 96 of a SIMD lane's 512 stay free next to its two waves,
+// which is what lets the <= 96-register GroupNorm-backward / bias-gradient passes of the main stream run beside it) | 2 = the same with
+// prefetch distance 2 (220 registers) | 3 = 64 x 64, 4 waves, one workgroup per CU (A/B: half the rate, a single wave per SIMD)
+int nine_mode() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FAVAE_WGRAD_NINE"); v = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1; }
+    return v;
+}
+bool use_nine() { return nine_mode() != 0; }
 // FAVAE_CONV_HALO=0 disables the LDS-halo 3x3 kernel (A/B switch)
 bool use_halo() {
     static int v = -1;
@@ -695,6 +705,27 @@ int row3_splitk(const favae_conv_desc* d, int tiles3, int sk_max, int* chunk) {
     return (int)((M + ch - 1) / ch);
 }
 
+// Split-K of the nine-tap kernel (one 512-thread workgroup per CU): slabs are whole 16-pixel column strips of the images
+// (N * Wout / 16 of them); the grid should be a whole number of 256-CU rounds, with equal strips per slab.
+int nine_splitk(const favae_conv_desc* d, int tiles, int sk_max, int per_round, int* strips_per_slab) {
+    const long NS = (long)d->N * (d->Wout / 16);
+    long best_sk = 1, best_sps = NS;
+    double best_eff = -1.0;
+    for (int r = 1; r <= 3; ++r) {
+        long sk = ((long)per_round * r) / tiles;
+        if (sk < 1) sk = 1;
+        if (sk > sk_max) sk = sk_max;
+        if (sk > NS) sk = NS;
+        const long sps = (NS + sk - 1) / sk;
+        sk = (NS + sps - 1) / sps;
+        const long total = sk * tiles;
+        const double eff = ((double)total / ((double)per_round * ((total + per_round - 1) / per_round))) * ((double)NS / (double)(sk * sps));
+        if (eff > best_eff + 0.01 || (r == 2 && eff >= best_eff - 0.01)) { best_eff = eff; best_sk = sk; best_sps = sps; }
+    }
+    *strips_per_slab = (int)best_sps;
+    return (int)best_sk;
+}
+
 void wgrad_tiles(const favae_conv_desc* d, int* bco, int* bci) {
     *bco = d->Cout <= 32 ? 32 : 128;
     *bci = (d->Cin <= 32 && *bco == 128) ? 32 : 128;
@@ -1226,7 +1257,36 @@ static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float
     } while (0)
     const bool row3 = !special && buf_ok && use_b6() && use_row3() && bco == 128 && bci == 128 && d->gather == FAVAE_GATHER_PLAIN &&
                       d->KH == 3 && d->KW == 3 && d->pad == 1;
-    if (row3) {
+    const bool nine = row3 && use_nine() && !x_planes && !dy_planes && d->Hout == d->Hin && d->Wout == d->Win;
+    if (nine) {
+        // all nine taps per workgroup (BCO co x 64 ci), split-K over whole 16-pixel column strips
+        const int nm = nine_mode();
+        const int bco9 = nm == 3 ? 64 : 128;
+        a.tiles_co = cdiv(d->Cout, bco9);
+        a.tiles_ci = cdiv(d->Cin, 64);
+        const int tiles9 = a.tiles_co * a.tiles_ci;
+        int sps;
+        a.splitk = nine_splitk(d, tiles9, a.splitk, 256, &sps);
+        a.chunk = sps;
+        const dim3 g9((unsigned)(tiles9 * ((a.splitk + 7) / 8) * 8));
+#define FAVAE_LAUNCH_NINE_M(X, P)                                                                                   \
+    do {                                                                                                            \
+        if (nm == 1) FAVAE_KLAUNCH((conv_wgrad_nine_sp_kernel<X, P, 128, false, 1>), g9, dim3(512), 0, s, a);        \
+        else if (nm == 2) FAVAE_KLAUNCH((conv_wgrad_nine_sp_kernel<X, P, 128, false, 2>), g9, dim3(512), 0, s, a);   \
+        else FAVAE_KLAUNCH((conv_wgrad_nine_sp_kernel<X, P, 64, true, 2>), g9, dim3(256), 0, s, a);             \
+    } while (0)
+#define FAVAE_LAUNCH_NINE(X)                                  \
+    do {                                                      \
+        if (np == 2) FAVAE_LAUNCH_NINE_M(X, 2);               \
+        else if (np == 1) FAVAE_LAUNCH_NINE_M(X, 1);          \
+        else FAVAE_LAUNCH_NINE_M(X, 3);                       \
+    } while (0)
+        if (xf == 0) FAVAE_LAUNCH_NINE(0);
+        else if (xf == 1) FAVAE_LAUNCH_NINE(1);
+        else FAVAE_LAUNCH_NINE(2);
+#undef FAVAE_LAUNCH_NINE
+#undef FAVAE_LAUNCH_NINE_M
+    } else if (row3) {
         // three taps per workgroup: grid.x = tiles * 3 filter rows; split-K sized for the smaller grid
         const int tiles3 = a.tiles_co * a.tiles_ci * 3;
         a.splitk = row3_splitk(d, tiles3, a.splitk, &chunk);
@@ -1509,6 +1569,15 @@ extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, int ac
         FAVAE_KLAUNCH(colsum_partial_kernel, dim3(cdiv(C, 256), nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb, amax);
     FAVAE_CHECK_LAUNCH();
     FAVAE_KLAUNCH(reduce_slabs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const float*)ws, out, (size_t)C, nb, accumulate);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+// second stage of a column sum whose per-block partials part[blocks][C] came out of another pass (favae_gn_act_bwd_colsum):
+// out[c] (+)= sum_b part[b][c], blocks in ascending order (deterministic)
+extern "C" int favae_colsum_finish(const float* part, int blocks, int C, float* out, int accumulate, favae_stream_t stream) {
+    FAVAE_REQUIRE(part && out && blocks > 0 && C > 0);
+    FAVAE_KLAUNCH(reduce_slabs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, part, out, (size_t)C, blocks, accumulate);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }

@@ -12,16 +12,7 @@
 // Wout % 16 == 0, Cout % 4 == 0.
 #pragma once
 
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-#define FAVAE_OOB 0x80000000u
-
-template <typename R>
-__device__ __forceinline__ float4 bload(R rsrc, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
-}
-__device__ __forceinline__ auto make_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
-}
+// buffer addressing helpers (make_rsrc, bload, bstore, FAVAE_OOB): common.h
 
 // XFORM: 0 none | 1 affine | 2 affine + SiLU | 3 affine + LeakyReLU(0.2) or ReLU (act = FAVAE_ACT_RELU: slope 0)
 __device__ __forceinline__ float leaky_slope(int act) { return act == FAVAE_ACT_RELU ? 0.0f : 0.2f; }

@@ -778,3 +778,209 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_sp_kernel(WgradArgs a) {
             }
         }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 weight gradient, ALL NINE taps per workgroup, every operand element loaded / transformed / split ONCE (round 3).
+// A workgroup owns (128 co x 64 ci x 9 taps) and walks DOWN 16-pixel-wide column strips of the images: per step it stages one
+// 16-pixel row segment of dy and one 18-pixel (halo) row segment of x; the x rows live in a 4-slot LDS ring, so the three filter
+// rows kh = 0,1,2 of step h read the ring slots of rows h-1, h, h+1 and every x row is fetched from HBM / L2 once instead of by
+// three filter-row workgroups (conv_wgrad_row3_sp_kernel: 3.5x the algorithmic traffic, and GroupNorm+SiLU + plane split of every
+// x element three times).  27 MFMA product blocks (x planes products) per wave and step against one dy float4 and 0.56 x
+// float4 staged per thread: 2.75x less vector-ALU work per MFMA than the row3 kernel.
+// 8 waves = 4 (co) x 2 (ci), each 32 co x 32 ci x 9 taps = 144 accumulator registers.
+// Split-K over whole strips (slab z = strips [z sps, (z+1) sps)); the tiles of one slab sit on ONE XCD (blockIdx % 8) next to each
+// other in dispatch order, so the dy rows shared by the ci tiles and the x rows shared by the co tiles are served by that L2.
+// Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, Wout % 16 == 0, channels % 4 == 0, operands < 2 GiB.
+// ---------------------------------------------------------------------------------------------------------------
+namespace sp {
+constexpr int XPITCH = 192;                // bytes per pixel of an x ring plane: 64 ci x 2 B + 64 B pad (conflict-free tr reads:
+                                           // the 4 pixel rows of a 32-lane half land on the four 64-byte quarters of the 256-byte bank line)
+}
+// BCO = output channels per workgroup: 128 (8 waves, 4 co x 2 ci) or 64 (4 waves, 2 x 2).  CAP1 = declare > 80 KB of LDS per
+// workgroup: a residency cap of ONE workgroup per CU (160 KB), so that the HBM-bound kernels of the main stream find free wave slots and registers next
+// to this register-heavy kernel (it runs on the weight-gradient stream, meant to overlap exactly those kernels).
+// PF = global prefetch distance in steps: the loads of stage j + PF are issued before the products of step j and stored to LDS one
+// step before they are used (PF register stages).  One step is 27 MFMA blocks per wave (~0.9k cycles), a loaded HBM round trip
+// is longer: with PF = 1 the step time IS the load latency (measured: the 4-wave variant ran at half the rate of the 8-wave one).
+namespace sp {
+template <int I> struct IC { static constexpr int value = I; };
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IC<I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+}  // namespace sp
+template <int XFORM, int NP, int BCO = 128, bool CAP1 = false, int PF = 2>
+__global__ __launch_bounds__(BCO * 4) void conv_wgrad_nine_sp_kernel(WgradArgs a) {
+    using S = sp::Scheme<NP>;
+    static_assert(PF >= 1 && PF <= 3, "prefetch distance in steps");
+    constexpr int T = BCO * 4;                                       // threads
+    constexpr int OPITCH = BCO == 128 ? sp::RSB : sp::XPITCH;        // bytes per pixel of a dy plane
+    constexpr int OPL = 16 * OPITCH, OB = NP * OPL;                  // dy: plane, buffer (16 px x BCO co)
+    constexpr int IPL = 18 * sp::XPITCH, IROW = NP * IPL;            // x: plane of one ring row (18 px x 64 ci), ring row
+    constexpr int NXS = (18 * 16 + T - 1) / T;                       // x staging slots per thread (288 float4 per row)
+    constexpr int LUSE = 2 * OB + 4 * IROW;
+    constexpr int LPAD = (CAP1 && LUSE < 82 * 1024) ? 82 * 1024 - LUSE : 0;      // > 80 KB per workgroup: one workgroup per CU
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LUSE + LPAD];
+    unsigned char* Os = lds;                                         // [2][NP][16][OPITCH]
+    unsigned char* Is = lds + 2 * OB;                                // [4][NP][18][XPITCH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wo = wid >> 1, wi = wid & 1;
+    // blockIdx -> (tile, slab): XCD = blockIdx % 8; inside an XCD consecutive workgroups are the tiles of one slab
+    const int tiles = a.tiles_co * a.tiles_ci;
+    const int q = blockIdx.x >> 3;
+    const int tile = q % tiles;
+    const int z = (q / tiles) * 8 + (blockIdx.x & 7);
+    if (z >= a.splitk) return;
+    const int ci0 = (tile % a.tiles_ci) * 64;
+    const int co0 = (tile / a.tiles_ci) * BCO;
+    const int strips_w = a.Wout >> 4;
+    const int NS = a.N * strips_w;
+    const int s_begin = z * a.chunk, s_end = min(NS, s_begin + a.chunk);       // chunk = strips per slab
+    const int H = a.Hout;
+    const float So = S::SCALED ? sp::pow2_scale(a.dy_amax) : 1.f, Si = S::SCALED ? sp::pow2_scale(a.x_amax) : 1.f;
+    if (LPAD && a.M < 0) lds[LUSE + LPAD - 1 - tid] = 0;                      // never true: keeps the padding allocated
+
+    const auto rx = make_rsrc(a.x, a.x_bytes);
+    const auto rdy = make_rsrc(a.dy, (unsigned)a.M * (unsigned)a.Cout * 4u);
+    const auto rsc_d = make_rsrc(XFORM ? a.scale : a.x, XFORM ? a.aff_bytes : 0u);
+    const auto rsh_d = make_rsrc(XFORM ? a.shift : a.x, XFORM ? a.aff_bytes : 0u);
+
+    // staging slots: dy float4 i = tid -> pixel tid / (BCO/4), co quad tid % (BCO/4); x float4 i = tid + j T < 288 -> pixel i / 16, ci quad i % 16
+    const int opx = tid / (BCO / 4), oq = (tid % (BCO / 4)) * 4;
+    const unsigned voo = (co0 + oq < a.Cout) ? (unsigned)((opx * a.Cout + co0 + oq) * 4) : FAVAE_OOB;
+    const int iq = (tid & 15) * 4;                                   // T % 16 == 0: the same channel quad in every slot
+    const bool ci_ok = ci0 + iq < a.Cin;
+    const unsigned vsc = ci_ok ? (unsigned)((ci0 + iq) * 4) : FAVAE_OOB;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int s16 = lane & 15, g = lane >> 4;
+    const unsigned char* Ofr = Os + (8 * (g >> 1) + (s16 >> 2)) * OPITCH + (16 * (g & 1) + 4 * (s16 & 3)) * 2 + wo * 64;
+    const unsigned char* Ifr = Is + (8 * (g >> 1) + (s16 >> 2)) * sp::XPITCH + (16 * (g & 1) + 4 * (s16 & 3)) * 2 + wi * 64;
+
+    // virtual step stream: every strip contributes v = -1 (seed: x rows -1 and 0, no product) and v = 0 .. H-1
+    // stage(v) brings dy row v (v >= 0) and x row v + 1 (zeros when v + 1 == H) -- and zeros for x row -1 when v == -1
+    // Every stage issues the SAME loads, unconditionally (stages behind the end of the slab, absent dy rows and the lanes without a
+    // second x slot use the out-of-range offset: no memory traffic): with branch-free load / store sequences the compiler's
+    // s_waitcnt insertion can count -- behind conditional loads it waited for the stage issued one step earlier right before issuing
+    // the next one, which turned the prefetch distance back into one exposed round trip per step.
+    int ld_s = s_begin, ld_v = -1;            // the stage the NEXT load_stage() call fetches
+    int ld_n = s_begin / strips_w, ld_w0 = (s_begin - (s_begin / strips_w) * strips_w) << 4;
+    float4 ro[PF], ri[PF][NXS], rsc[PF], rsh[PF];     // PF register stages; stage k sits in stage registers k % PF
+    bool x_ok[PF][NXS];
+    int st_v[PF];
+    auto load_stage = [&](auto SL) {
+        constexpr int L = decltype(SL)::value;
+        const bool live = ld_s < s_end;
+        st_v[L] = ld_v;
+        const unsigned img = (unsigned)(ld_n * H) * (unsigned)a.Wout;
+        // dy row v: pixels (n, v, w0 .. w0 + 15)
+        ro[L] = bload(rdy, (live && ld_v >= 0) ? voo : FAVAE_OOB, (img + (unsigned)(max(ld_v, 0) * a.Wout + ld_w0)) * (unsigned)a.Cout * 4u);
+        // x row v + 1: pixels (n, v + 1, w0 - 1 .. w0 + 16)
+        const int xr = ld_v + 1;
+        const unsigned sx = (img + (unsigned)(min(xr, H - 1) * a.Wout)) * (unsigned)a.Cin * 4u;
+#pragma unroll
+        for (int j = 0; j < NXS; ++j) {
+            const int ipx = (tid + j * T) >> 4, iw = ld_w0 - 1 + ipx;
+            x_ok[L][j] = live && ipx < 18 && ci_ok && xr < H && (unsigned)iw < (unsigned)a.Win;
+            ri[L][j] = bload(rx, x_ok[L][j] ? (unsigned)((iw * a.Cin + ci0 + iq) * 4) : FAVAE_OOB, sx);
+        }
+        if (XFORM) {                          // GroupNorm affine of (image, channel quad): an L1 hit after the first step of a strip
+            const unsigned ss = (unsigned)(ld_n * a.aff_stride) * 4u;
+            rsc[L] = bload(rsc_d, live ? vsc : FAVAE_OOB, ss);
+            rsh[L] = bload(rsh_d, live ? vsc : FAVAE_OOB, ss);
+        }
+        if (++ld_v == H) {
+            ld_v = -1;
+            ++ld_s;
+            ld_n = ld_s / strips_w;
+            ld_w0 = (ld_s - ld_n * strips_w) << 4;
+        }
+    };
+    auto store_stage = [&](auto SL) {
+        constexpr int L = decltype(SL)::value;
+        const int sv = st_v[L];
+        uint2 p[NP];
+        S::split4(ro[L], So, p);
+        sp::store_planes<NP>(Os + (sv & 1) * OB + opx * OPITCH + oq * 2, OPL, p);   // sv == -1: zeros into the idle buffer 1
+#pragma unroll
+        for (int j = 0; j < NXS; ++j) {
+            if (tid + j * T >= 18 * 16) continue;
+            float4 t = xform4_t<XFORM>(ri[L][j], rsc[L], rsh[L], a.act);
+            if (XFORM && !x_ok[L][j]) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            S::split4(t, Si, p);
+            unsigned char* d = Is + ((tid + j * T) >> 4) * sp::XPITCH + iq * 2;
+            sp::store_planes<NP>(d + ((sv + 2) & 3) * IROW, IPL, p);            // row v + 1 -> slot (v + 2) & 3
+            if (sv == -1) {                                                     // row -1 of the strip -> slot 0: the top padding
+#pragma unroll
+                for (int k = 0; k < NP; ++k) p[k] = make_uint2(0u, 0u);
+                sp::store_planes<NP>(d, IPL, p);
+            }
+        }
+    };
+
+    const int J = (s_end - s_begin) * (H + 1);
+    // prologue: stage 0 into LDS, stages 1 .. PF-1 into their registers
+    sp::static_for<PF>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        load_stage(sp::IC<u>{});
+        if (u == 0) store_stage(sp::IC<0>{});
+    });
+    __syncthreads();
+    int v = -1;
+    for (int j0 = 0; j0 < J; j0 += PF) {
+        sp::static_for<PF>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            if (j0 + u < J) {
+                load_stage(sp::IC<u>{});                                        // stage j + PF -> the registers stage j just left
+                if (v >= 0) {
+                    // fragments of filter row kh + 1 are requested before the products of row kh are issued (two register sets)
+                    bf16x8_t af[NP], bf[2][3][NP];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) af[p] = sp::tr_frag_p<OPITCH>(Ofr + (v & 1) * OB + p * OPL);
+                    auto read_row = [&](int kh, bf16x8_t (&dst)[3][NP]) {
+                        const unsigned char* row = Ifr + ((v + kh) & 3) * IROW; // x row v - 1 + kh
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) dst[kw][p] = sp::tr_frag_p<sp::XPITCH>(row + p * IPL + kw * sp::XPITCH);
+                    };
+                    read_row(0, bf[0]);
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        if (kh < 2) read_row(kh + 1, bf[(kh + 1) & 1]);
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) S::mma(af, bf[kh & 1][kw], acc[kh * 3 + kw]);
+                    }
+                }
+                // the seed stage of the next strip overwrites ring slots 0 and 1, which the last step of this strip may still read
+                if (v == H - 1) __syncthreads();
+                store_stage(sp::IC<(u + 1) % PF>{});
+                __syncthreads();
+                if (++v == H) v = -1;
+            }
+        });
+    }
+
+    float un_o = 1.f, un_i = 1.f;
+    if constexpr (S::SCALED) { un_o = sp::pow2_inv(So); un_i = sp::pow2_inv(Si); }
+    const int ci = ci0 + wi * 32 + (lane & 31);
+    if (ci >= a.Cin) return;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float val = acc[t][r];
+            if constexpr (S::SCALED) val = val * un_o * un_i;
+            if (co < a.Cout) a.part[(((size_t)z * a.Cout + co) * 9 + t) * a.Cin + ci] = val;
+        }
+}

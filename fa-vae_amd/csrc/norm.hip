@@ -206,8 +206,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
 // per-tile partials of the data-gradient epilogue, where one thread per channel took 60 us.)
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
                                                                float* __restrict__ k1, float* __restrict__ k2,
-                                                               double* __restrict__ acc, long HW, int C, int G, int S) {
+                                                               double* __restrict__ acc, long HW, int C, int G, int S,
+                                                               unsigned* __restrict__ zero_out) {
     __shared__ double sl[2 * 256];
+    if (zero_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_out = 0u;   // max |dx| of the apply pass behind
     const int n = blockIdx.x;
     const int cpg = C / G;
     const int GS = G / gridDim.y, gb = blockIdx.y * GS, ge = gb + GS, cb = gb * cpg, ce = ge * cpg;   // slab of whole groups
@@ -311,62 +313,106 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 // Same result as gn_bwd_apply_kernel<true>, organised like gn_partial_kernel: thread = (channel quad, row lane) of image
 // blockIdx.y, so the per-channel constants live in registers (no per-element parameter loads, no 64-bit index divisions)
 // and four rows are in flight per thread.  Requires C % 4 == 0, C / 4 <= 256 and 16-byte aligned tensors.
-__global__ __launch_bounds__(256) void gn_bwd_apply_rows_kernel(const float* __restrict__ da, const float* __restrict__ x,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                const float* __restrict__ k1, const float* __restrict__ k2,
-                                                                const float* __restrict__ dx_add, float* __restrict__ dx,
-                                                                long HW, int C, int G, int act, long rows_per_block) {
+// Round 3: at most 96 registers (launch bound 5 waves per SIMD): the kernel has to find a wave slot NEXT to the register-heavy
+// weight-gradient kernel of the second stream (2 x 208 of the 512 registers of a SIMD lane), which is the whole point of that stream.
+// CS: the pass also emits, for the tensor dx it writes, the per-block column sums cs_part[block][C] (block = blockIdx.y * gridDim.x
+// + blockIdx.x) and max |dx| -- dx is the `dy` of the conv in front of this GroupNorm, whose bias gradient and fp16 operand
+// range are exactly these two (favae_colsum read the tensor once more for them).
+template <bool SKIP, bool CS>
+__global__ __launch_bounds__(256, 5) void gn_bwd_apply_rows_kernel(const float* __restrict__ da, const float* __restrict__ x,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   const float* __restrict__ k1, const float* __restrict__ k2,
+                                                                   const float* __restrict__ dx_add, float* __restrict__ dx,
+                                                                   long HW, int C, int G, int act, long rows_per_block,
+                                                                   float* __restrict__ cs_part, unsigned* __restrict__ cs_amax) {
+    __shared__ float4 sm[CS ? 256 : 1];
     const int n = blockIdx.y;
     const int Q = C / 4, RL = 256 / Q;
     const int qi = threadIdx.x % Q, li = threadIdx.x / Q;
-    if (li >= RL) return;
+    const bool on = li < RL;
     const int cpg = C / G, c = qi * 4;
-    float a_[4], b_[4], k_[4], ga[4], be[4];          // xh = x*a + b ; dx = rs*ga*dy - (rs*k1 + rs*k2*xh)
-    float rsg[4], rk1[4], rk2[4];
+    float mu[4], rs[4], ga[4], be[4], rk1[4], rk2[4];                // xh = (x - mu) rs ; dx = rs (dy ga - k1 - xh k2)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int g = (c + e) / cpg;
-        const float mu = mean[n * G + g], rs = rstd[n * G + g];
-        a_[e] = rs; b_[e] = mu; ga[e] = gamma[c + e]; be[e] = beta[c + e];
-        rsg[e] = rs; rk1[e] = k1[n * G + g]; rk2[e] = k2[n * G + g];
-        k_[e] = 0.f;
+        mu[e] = mean[n * G + g];
+        rs[e] = rstd[n * G + g];
+        ga[e] = gamma[c + e];
+        be[e] = beta[c + e];
+        rk1[e] = k1[n * G + g];
+        rk2[e] = k2[n * G + g];
     }
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(HW, r0 + rows_per_block);
-    const size_t base = ((size_t)n * HW) * C + c;
+    // per-image descriptors (an image is < 4 GiB); lane offset = (row lane, channel quad), the row block advances in an SGPR
+    const size_t img = ((size_t)n * HW) * C;
+    const unsigned img_bytes = (unsigned)((size_t)HW * C * 4);
+    const auto rx = make_rsrc(x + img, img_bytes), rda = make_rsrc(da + img, img_bytes), rdx = make_rsrc(dx + img, img_bytes);
+    const auto rsk = make_rsrc(SKIP ? dx_add + img : x, SKIP ? img_bytes : 0u);
+    const unsigned voff = on ? (unsigned)((li * C + c) * 4) : FAVAE_OOB;
+    const unsigned row_b = (unsigned)C * 4u;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    float mx = 0.f;
     auto one = [&](const float4 t, const float4 d, const float4 q) -> float4 {
         const float xv[4] = {t.x, t.y, t.z, t.w}, dv[4] = {d.x, d.y, d.z, d.w}, av[4] = {q.x, q.y, q.z, q.w};
         float ov[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float xh = (xv[e] - b_[e]) * a_[e];
+            // explicit fused multiply-adds: every instantiation rounds the same way (left to the compiler, the contraction of
+            // rs (dy ga - k1 - xh k2) changed with the code around it)
+            const float xh = (xv[e] - mu[e]) * rs[e];
             const float y = fmaf(xh, ga[e], be[e]);
             const float dy = dv[e] * act_grad(y, act);
-            float o = rsg[e] * (dy * ga[e] - rk1[e] - xh * rk2[e]);
-            if (dx_add) o += av[e];
-            ov[e] = o;
+            const float t = fmaf(-xh, rk2[e], fmaf(dy, ga[e], -rk1[e]));
+            ov[e] = SKIP ? fmaf(rs[e], t, av[e]) : rs[e] * t;
         }
         return make_float4(ov[0], ov[1], ov[2], ov[3]);
     };
+    auto tally = [&](const float4 o) {
+        cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+    };
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int U = 4;
-    long r = r0 + li;
-    for (; r + (U - 1) * RL < r1; r += U * RL) {
+    // rows r0 + li + k RL (k = 0, 1, ...) of this lane; rows >= r1 must not be touched: their lane offset becomes out-of-range
+    for (long rb = r0; rb < r1; rb += U * RL) {
         float4 t[U], d[U], q[U];
+        unsigned vo[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const size_t o = base + (size_t)(r + u * RL) * C;
-            t[u] = *reinterpret_cast<const float4*>(x + o);
-            d[u] = *reinterpret_cast<const float4*>(da + o);
-            q[u] = dx_add ? *reinterpret_cast<const float4*>(dx_add + o) : z4;
+            vo[u] = (rb + u * RL + li < r1) ? voff : FAVAE_OOB;
+            const unsigned so = (unsigned)(rb + u * RL) * row_b;
+            t[u] = bload(rx, vo[u], so);
+            d[u] = bload(rda, vo[u], so);
+            q[u] = SKIP ? bload(rsk, vo[u], so) : z4;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) *reinterpret_cast<float4*>(dx + base + (size_t)(r + u * RL) * C) = one(t[u], d[u], q[u]);
+        for (int u = 0; u < U; ++u) {
+            const float4 o = one(t[u], d[u], q[u]);
+            bstore(rdx, vo[u], (unsigned)(rb + u * RL) * row_b, o);
+            if (CS && vo[u] != FAVAE_OOB) tally(o);
+        }
     }
-    for (; r < r1; r += RL) {
-        const size_t o = base + (size_t)r * C;
-        const float4 q = dx_add ? *reinterpret_cast<const float4*>(dx_add + o) : z4;
-        *reinterpret_cast<float4*>(dx + o) = one(*reinterpret_cast<const float4*>(x + o), *reinterpret_cast<const float4*>(da + o), q);
+    if constexpr (CS) {
+        // column sums of this block's rows: the RL row lanes of a channel quad in ascending order (fixed order: deterministic)
+        sm[threadIdx.x] = cs;
+        mx = wave_max(mx);
+        __syncthreads();
+        if (on && li == 0) {
+            for (int l = 1; l < RL; ++l) {
+                const float4 v = sm[l * Q + qi];
+                cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+            }
+            const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            reinterpret_cast<float4*>(cs_part + blk * C)[qi] = cs;
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) reinterpret_cast<float*>(sm)[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {                  // one same-address atomic per block; non-negative floats order like their bits
+            const float* w = reinterpret_cast<const float*>(sm);
+            atomicMax(cs_amax, __float_as_uint(fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]))));
+        }
     }
 }
 
@@ -468,7 +514,33 @@ extern "C" int favae_gn_stats_tiles(const void* part, int tiles, const float* ga
 static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, const float* beta, const float* mean,
                            const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
                            float* dgamma, float* dbeta, int accumulate, int tile_partials, void* ws, size_t ws_bytes,
-                           favae_stream_t stream);
+                           favae_stream_t stream, float* cs_part = nullptr, float* cs_amax = nullptr);
+
+// blocks per image of the row-organised apply pass (0: the shape does not run it)
+static long apply_rows_blocks(int N, int64_t HW, int C) {
+    if (C % 4 != 0 || C / 4 > 256 || 256 % (C / 4) != 0 || (size_t)HW * C * 4 >= ((size_t)1 << 31)) return 0;
+    long S = (HW + 255) / 256;                           // >= 256 pixels per block, ~2048 blocks in total
+    const long cap = (2048 + N - 1) / N;
+    return S > cap ? cap : (S < 1 ? 1 : S);
+}
+
+extern "C" int favae_gn_bwd_colsum_blocks(int N, int64_t HW, int C) {
+    if (N <= 0 || HW <= 0 || C <= 0) return 0;
+    return (int)(apply_rows_blocks(N, HW, C) * N);
+}
+
+// favae_gn_act_bwd / favae_gn_act_bwd_tiles (tiles == 0 / > 0) whose apply pass also emits, for the dx it writes, per-block column
+// sums cs_part[favae_gn_bwd_colsum_blocks(N, HW, C)][C] and max |dx| (cs_absmax, one float): the bias gradient (favae_colsum_finish)
+// and the fp16 operand range of the conv whose output gradient dx is -- no second pass over the tensor.
+extern "C" int favae_gn_act_bwd_colsum(const float* da, const float* x, const float* gamma, const float* beta, const float* mean,
+                                       const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
+                                       float* dgamma, float* dbeta, int accumulate, int tiles, void* ws, size_t ws_bytes,
+                                       float* cs_part, float* cs_absmax, favae_stream_t stream) {
+    FAVAE_REQUIRE(cs_part && cs_absmax && tiles >= 0);
+    if (!favae_gn_bwd_colsum_blocks(N, HW, C)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    return gn_act_bwd_impl(da, x, gamma, beta, mean, rstd, N, HW, C, G, act, dx_add, dx, dgamma, dbeta, accumulate, tiles, ws, ws_bytes,
+                           stream, cs_part, cs_absmax);
+}
 
 extern "C" size_t favae_gn_bwd_tiles_workspace(int N, int tiles, int C) {
     return (size_t)N * tiles * C * 2 * sizeof(double) + acc_bytes(N, C) + 2 * (size_t)N * C * sizeof(float) + 512;
@@ -494,7 +566,7 @@ extern "C" int favae_gn_act_bwd_tiles(const float* da, const float* x, const flo
 static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, const float* beta, const float* mean,
                            const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
                            float* dgamma, float* dbeta, int accumulate, int tile_partials, void* ws, size_t ws_bytes,
-                           favae_stream_t stream) {
+                           favae_stream_t stream, float* cs_part, float* cs_amax) {
     FAVAE_REQUIRE(da && x && gamma && beta && mean && rstd && dx && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
     FAVAE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr));
     if (ws_bytes < (tile_partials ? favae_gn_bwd_tiles_workspace(N, tile_partials, C) : favae_gn_workspace(N, HW, C)))
@@ -509,7 +581,7 @@ static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, 
         FAVAE_CHECK_LAUNCH();
     }
     FAVAE_KLAUNCH(gn_bwd_finalize_kernel, dim3(N, gn_slabs(G)), dim3(256), 0, s, (const double*)part, gamma, k1, k2, acc, (long)HW, C, G,
-                       tile_partials ? tile_partials : gn_splits(N, HW));
+                       tile_partials ? tile_partials : gn_splits(N, HW), (unsigned*)cs_amax);
     FAVAE_CHECK_LAUNCH();
     if (dgamma) {
         FAVAE_KLAUNCH(gn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)acc, dgamma, dbeta, N, C, accumulate);
@@ -518,13 +590,19 @@ static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, 
     const size_t total = (size_t)N * HW * C;
     FAVAE_PROF_NOTE(0, (dx_add ? 16.0 : 12.0) * total);                   // reads da, x (+ dx_add), writes dx
     const bool vec = (C % 4 == 0) && (((((uintptr_t)da) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)dx_add)) & 15) == 0);
-    if (vec && C / 4 <= 256 && 256 % (C / 4) == 0) {
-        long S = (HW + 255) / 256;                           // >= 256 pixels per block, ~2048 blocks in total
-        const long cap = (2048 + N - 1) / N;
-        S = S > cap ? cap : (S < 1 ? 1 : S);
+    const long S = apply_rows_blocks(N, HW, C);
+    if (cs_part && !(vec && S)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (vec && S) {
         const long rpb = (HW + S - 1) / S;
-        FAVAE_KLAUNCH(gn_bwd_apply_rows_kernel, dim3((unsigned)S, N), dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2,
-                           dx_add, dx, (long)HW, C, G, act, rpb);
+        const dim3 grid((unsigned)S, N);
+#define FAVAE_LAUNCH_APPLY(SK, CS)                                                                                             \
+    FAVAE_KLAUNCH((gn_bwd_apply_rows_kernel<SK, CS>), grid, dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2, dx_add, dx, \
+                  (long)HW, C, G, act, rpb, cs_part, (unsigned*)cs_amax)
+        if (dx_add && cs_part) FAVAE_LAUNCH_APPLY(true, true);
+        else if (dx_add) FAVAE_LAUNCH_APPLY(true, false);
+        else if (cs_part) FAVAE_LAUNCH_APPLY(false, true);
+        else FAVAE_LAUNCH_APPLY(false, false);
+#undef FAVAE_LAUNCH_APPLY
     } else if (vec) {
         int blocks = (int)((total / 4 + 255) / 256);
         if (blocks > 8192) blocks = 8192;

@@ -111,10 +111,13 @@ __device__ __forceinline__ void store_planes(unsigned char* d, int plane_stride,
 constexpr int RSB = 320;                   // bytes per pixel row of a plane (128 ch x 2 B + 64 B pad: conflict-free tr reads)
 constexpr int PLB = 16 * RSB;              // bytes per plane (16 pixels)
 
-__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* p) {
+// PITCH = bytes per pixel row of the plane the fragment is read from
+template <int PITCH>
+__device__ __forceinline__ bf16x8_t tr_frag_p(const unsigned char* p) {
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + 4 * RSB));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + 4 * PITCH));
     const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8_t, v);
 }
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* p) { return tr_frag_p<RSB>(p); }
 }  // namespace sp

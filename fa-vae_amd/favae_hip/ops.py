@@ -337,6 +337,43 @@ _PLANES = os.environ.get("FAVAE_WGRAD_PLANES", "0") == "1"
 
 # GroupNorm-backward pass 1 (two tensor reads per GroupNorm) inside the epilogue of the data-gradient conv (A/B switch)
 _GNBWD_FUSE = os.environ.get("FAVAE_GNBWD_FUSE", "1") != "0"
+# Bias gradient + operand range of dy as by-products of the GroupNorm-backward apply pass that WRITES dy (A/B switch).  They ride on
+# the gradient tensor as `_favae_dycs` = (per-block column sums, blocks, max|dy| device scalar, tensor version); the conv whose
+# output gradient the tensor is picks them up when the version counter is unchanged (nothing accumulated into it in place).
+_DYCS_FUSE = os.environ.get("FAVAE_DYCS_FUSE", "1") != "0"
+
+
+def _dy_byproducts(dy, C):
+    pre = getattr(dy, "_favae_dycs", None) if _DYCS_FUSE else None
+    if pre is not None and pre[3] == dy._version and pre[0].numel() == pre[1] * C and dy.shape[1] == C:
+        return pre
+    return None
+
+
+def _bias_grad_and_range(dy, p_b, need_b, want_range, M, Cout, dev):
+    """db (or None when accumulated into the flat buffer) and the device scalar max|dy| (None unless asked for): from the
+    by-products of the pass that wrote dy when it left them, else one streaming pass over dy (favae_colsum / favae_absmax)."""
+    db = None
+    dyb = None
+    pre = _dy_byproducts(dy, Cout)
+    if pre is not None:
+        if need_b:
+            tgt = _direct_grad(p_b)
+            if tgt is None:
+                db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+            call("favae_colsum_finish", ptr(pre[0]), pre[1], Cout, ptr(db if tgt is None else tgt), 0 if tgt is None else 1)
+        return db, (pre[2] if want_range else None)
+    if want_range:
+        dyb = torch.empty((1,), dtype=torch.float32, device=dev)
+    if need_b:
+        ws = workspace(query("favae_colsum_workspace", M, Cout), dev)
+        tgt = _direct_grad(p_b)
+        if tgt is None:
+            db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        call("favae_colsum", ptr(dy), ptr(db if tgt is None else tgt), M, Cout, 0 if tgt is None else 1, ptr(dyb), ptr(ws), ws.numel())
+    elif want_range:
+        call("favae_absmax", ptr(dy), dy.numel(), ptr(dyb))
+    return db, dyb
 
 
 def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=None, planes_out=None, gnbwd=None, stats_out=None):
@@ -485,19 +522,9 @@ class FusedConvFn(torch.autograd.Function):
         gather = GATHER_UPSAMPLE2 if cfg.upsample else GATHER_PLAIN
         act = cfg.act if ctx.has_xform else ACT_NONE
         p_w, p_b, p_gw, p_gb = ctx.params
-        # range of dy for the fp16 split scheme: read off the bias-gradient pass when there is one
+        # bias gradient + range of dy for the fp16 split scheme: by-products of the pass that wrote dy, else one pass over dy
         want_range = xb is not None and _fp16_planes()
-        dyb = torch.empty((1,), dtype=torch.float32, device=dev) if want_range else None
-        if need_b:
-            M = N * Ho * Wo
-            ws = workspace(query("favae_colsum_workspace", M, Cout), dev)
-            tgt = _direct_grad(p_b)
-            if tgt is None:
-                db = torch.empty((Cout,), dtype=torch.float32, device=dev)
-            call("favae_colsum", ptr(dy), ptr(db if tgt is None else tgt), M, Cout, 0 if tgt is None else 1, ptr(dyb), ptr(ws),
-                 ws.numel())
-        elif want_range:
-            call("favae_absmax", ptr(dy), dy.numel(), ptr(dyb))
+        db, dyb = _bias_grad_and_range(dy, p_b, need_b, want_range, N * Ho * Wo, Cout, dev)
         # The weight gradient runs AFTER this conv's data gradient: the data-gradient kernel stores dy as pre-split planes on its
         # way (dys), the forward kernel stored T(x) (xs), and the weight-gradient kernel then loads both without any arithmetic.
         run_wgrad = None
@@ -596,15 +623,24 @@ class FusedConvFn(torch.autograd.Function):
                     dgb = torch.empty_like(dgw)
                 # BatchNorm = GroupNorm with one channel per group over the batch folded into the pixel dimension
                 gN, gHW, gG = (1, N * Hin * Win, Cin) if cfg.norm == "batch" else (N, Hin * Win, cfg.groups)
-                if gn_tiles:                                  # pass 1 came out of the data-gradient conv's epilogue
+                cs_blocks = query("favae_gn_bwd_colsum_blocks", gN, gHW, Cin) if _DYCS_FUSE else 0
+                if not gn_tiles:
+                    gn_ws = workspace(query("favae_gn_workspace", gN, gHW, Cin), dev)
+                if cs_blocks:                                 # the apply pass also leaves colsum / max|dx| for the conv in front
+                    cs_part = torch.empty((cs_blocks * Cin,), dtype=torch.float32, device=dev)
+                    cs_amax = torch.empty((1,), dtype=torch.float32, device=dev)
+                    call("favae_gn_act_bwd_colsum", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin, gG, act,
+                         ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0, gn_tiles,
+                         ptr(gn_ws), gn_ws.numel(), ptr(cs_part), ptr(cs_amax))
+                    dx._favae_dycs = (cs_part, cs_blocks, cs_amax, dx._version)
+                elif gn_tiles:                                # pass 1 came out of the data-gradient conv's epilogue
                     call("favae_gn_act_bwd_tiles", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin,
                          gG, act, ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,
                          gn_tiles, ptr(gn_ws), gn_ws.numel())
                 else:
-                    ws = workspace(query("favae_gn_workspace", gN, gHW, Cin), dev)
                     call("favae_gn_act_bwd", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin,
                          gG, act, ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,
-                         ptr(ws), ws.numel())
+                         ptr(gn_ws), gn_ws.numel())
                 dskip = None                                  # consumed by the kernel (dx = GN-backward + dskip)
             elif ctx.has_xform:                               # activation without normalisation
                 dx = new_cl(N, Cin, Hin, Win, dev)
@@ -667,17 +703,7 @@ class UpsampleConvFn(torch.autograd.Function):
         planes = ctx.planes
         p_w, p_b = ctx.params
         dx = dw = db = None
-        dyb = torch.empty((1,), dtype=torch.float32, device=dev) if planes in (1, 2) else None
-        if ctx.has_b and ctx.needs_input_grad[2]:
-            M = N * 4 * H * W
-            ws = workspace(query("favae_colsum_workspace", M, Cout), dev)
-            tgt = _direct_grad(p_b)
-            if tgt is None:
-                db = torch.empty((Cout,), dtype=torch.float32, device=dev)
-            call("favae_colsum", ptr(dy), ptr(db if tgt is None else tgt), M, Cout, 0 if tgt is None else 1, ptr(dyb), ptr(ws),
-                 ws.numel())
-        elif dyb is not None:
-            call("favae_absmax", ptr(dy), dy.numel(), ptr(dyb))
+        db, dyb = _bias_grad_and_range(dy, p_b, ctx.has_b and ctx.needs_input_grad[2], planes in (1, 2), N * 4 * H * W, Cout, dev)
         late = None
         if ctx.needs_input_grad[1]:
             tgt = _direct_grad(p_w)

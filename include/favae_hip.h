@@ -170,6 +170,20 @@ int favae_gn_act_bwd(const float* da, const float* x, const float* gamma, const 
                      const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
                      float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream);
 
+/* The same backward (tiles == 0: as favae_gn_act_bwd; tiles > 0: as favae_gn_act_bwd_tiles, pass 1 taken from the data-gradient
+ * conv's epilogue) whose apply pass ALSO emits two by-products of the tensor dx it writes: per-block column sums
+ * cs_part[favae_gn_bwd_colsum_blocks(N, HW, C)][C] and max |dx| (cs_absmax, one device float).  dx is the output gradient `dy` of the
+ * conv in front of this GroupNorm (models/codec.py:38-46: conv -> GroupNorm -> SiLU -> conv), whose bias gradient is
+ * favae_colsum_finish(cs_part) and whose fp16 operand range is cs_absmax -- favae_colsum's extra read of the tensor goes away.
+ * favae_gn_bwd_colsum_blocks returns 0 when the shape does not run the row-organised apply pass (C % 4, C > 1024, image >= 2 GiB). */
+int favae_gn_bwd_colsum_blocks(int N, int64_t HW, int C);
+int favae_gn_act_bwd_colsum(const float* da, const float* x, const float* gamma, const float* beta, const float* mean,
+                            const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
+                            float* dgamma, float* dbeta, int accumulate, int tiles, void* ws, size_t ws_bytes, float* cs_part,
+                            float* cs_absmax, favae_stream_t stream);
+/* out[c] (+)= sum_b part[b][c], b ascending (second stage of favae_colsum for partials produced by another pass) */
+int favae_colsum_finish(const float* part, int blocks, int C, float* out, int accumulate, favae_stream_t stream);
+
 /* BatchNorm2d running-stat update (momentum m, unbiased variance), models/discriminator.py:207 in train mode */
 int favae_bn_update_running(const float* mean, const float* rstd, int C, int64_t count, float eps, float momentum,
                             float* running_mean, float* running_var, favae_stream_t stream);

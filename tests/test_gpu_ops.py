@@ -399,6 +399,59 @@ def test_gn_epilogue_fusions_match_streaming_passes(K, N, C1, C2, H, W):
         check(a, b, 2e-5 if nm in ("db1",) else 3e-6, nm)      # db1 = sum of a GroupNorm input gradient: cancels to noise level
 
 
+@pytest.mark.parametrize("N,C1,C2,H,W,skip", [(2, 128, 128, 16, 32, False), (1, 128, 256, 8, 16, True), (3, 64, 128, 24, 48, True)])
+def test_dy_byproducts_of_the_gn_backward_pass(K, N, C1, C2, H, W, skip):
+    """The GroupNorm-backward apply pass leaves the column sums and max|.| of the gradient tensor it writes on that tensor
+    (favae_gn_act_bwd_colsum -> `_favae_dycs`); the conv in front of the GroupNorm takes its bias gradient (favae_colsum_finish) and
+    its fp16 operand range from them instead of streaming its dy once more (favae_colsum).  conv1 -> GN+SiLU -> conv2 (+ skip):
+    every gradient as without the by-products; the range is bit-identical (a maximum), db1 differs by its summation order only."""
+    import favae_hip as H_
+    d = dev()
+    x = rnd((N, C1, H, W), 91)
+    w1 = rnd((C2, C1, 3, 3), 92, 0.03)
+    b1 = rnd((C2,), 93, 0.1)
+    gw = 1 + rnd((C2,), 94, 0.2)
+    gb = rnd((C2,), 95, 0.2)
+    w2 = rnd((C2, C2, 3, 3), 96, 0.03)
+    b2 = rnd((C2,), 97, 0.1)
+    gy = rnd((N, C2, H, W), 98)
+    cfg0, cfg = K.ConvCfg(3, 3, 1, 1), K.ConvCfg(3, 3, 1, 1, act=1, groups=32)
+    outs, seen = [], []
+    for fuse in (True, False):
+        prev = K._DYCS_FUSE
+        K._DYCS_FUSE = fuse
+        calls = []
+        H_.set_call_hook(lambda name, args, launch: (calls.append(name), launch())[1])
+        try:
+            xs = x.to(d).requires_grad_(True)
+            ps = [t.to(d).requires_grad_(True) for t in (w1, b1, gw, gb, w2, b2)]
+            h = K.fused_conv(xs, ps[0], ps[1], cfg=cfg0)
+            if skip:                                             # ResnetBlock wiring: the skip gradient is added inside the apply pass
+                y, ha = K.fused_conv(h, ps[4], ps[5], ps[2], ps[3], None, cfg, True)
+                y = K.add(y, ha)
+            else:
+                y = K.fused_conv(h, ps[4], ps[5], ps[2], ps[3], None, cfg)
+            gr = torch.autograd.grad(y, [xs] + ps, gy.to(d))
+            K.sync_side_stream()
+            torch.cuda.synchronize()
+            outs.append([y.detach().cpu()] + [g.cpu() for g in gr])
+            seen.append(calls)
+        finally:
+            K._DYCS_FUSE = prev
+            H_.set_call_hook(None)
+    # with the by-products conv1's backward runs no pass of its own over dy: one favae_colsum (conv2's) instead of two
+    assert seen[0].count("favae_colsum") == 1 and seen[1].count("favae_colsum") == 2, (seen[0].count("favae_colsum"), seen[1].count("favae_colsum"))
+    assert seen[0].count("favae_colsum_finish") == 1 and "favae_gn_act_bwd_colsum" in seen[0]
+    names = ["y", "dx", "dw1", "db1", "dgamma", "dbeta", "dw2", "db2"]
+    for nm, a, b in zip(names, outs[0], outs[1]):
+        if nm == "db1" and not skip:                             # sum of a GroupNorm input gradient: cancels to rounding noise
+            assert float((a - b).abs().max()) <= 2e-5 * float(outs[0][2].abs().max()) + 1e-6, nm
+        elif nm == "db1":
+            check(a, b, 2e-5, nm)
+        else:
+            assert torch.equal(a, b), nm                         # same range scalar, same kernels: bit-identical
+
+
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("M,N,Kd", [(128, 128, 16), (200, 136, 72), (64, 516, 260), (36, 40, 4)])
 def test_bgemm_sp_vs_fp64(K, ta, tb, M, N, Kd):
