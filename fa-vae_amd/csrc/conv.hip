@@ -1121,7 +1121,17 @@ extern "C" size_t favae_conv_wgrad_workspace(const favae_conv_desc* d) {
 
 static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float* dy, const float* scale, const float* shift,
                            const float* x_absmax, const float* dy_absmax, const void* x_planes, const void* dy_planes, float* dw,
-                           int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream);
+                           int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream, int* slabs_out = nullptr);
+
+// Weight gradient WITHOUT its slab reduction: the partial slabs stay in `ws` ([*slabs][Cout][KH][KW][Cin] floats, *slabs written on
+// the host) for a later favae_reduce_slabs_grouped -- one launch for the slabs of many layers instead of one latency-bound launch
+// per layer (214 per step).  The sums are taken in the same order either way: bit-identical gradients.
+extern "C" int favae_conv_wgrad_slabs(const favae_conv_desc* d, const float* x, const float* dy, const float* scale,
+                                      const float* shift, const float* x_absmax, const float* dy_absmax, void* ws, size_t ws_bytes,
+                                      int* slabs, favae_stream_t stream) {
+    FAVAE_REQUIRE(slabs);
+    return conv_wgrad_impl(d, x, dy, scale, shift, x_absmax, dy_absmax, nullptr, nullptr, (float*)ws, 0, ws, ws_bytes, stream, slabs);
+}
 
 extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const float* dy, const float* scale,
                                 const float* shift, const float* x_absmax, const float* dy_absmax, float* dw, int accumulate,
@@ -1157,7 +1167,7 @@ static bool wgrad_row3_ok(const favae_conv_desc* d) {          // mirrors the `r
 
 static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float* dy, const float* scale, const float* shift,
                            const float* x_absmax, const float* dy_absmax, const void* x_planes, const void* dy_planes, float* dw,
-                           int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream) {
+                           int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream, int* slabs_out) {
     FAVAE_REQUIRE(desc_ok(d) && x && dy && dw && ws);
     // fp16 planes need both operand maxima; without them the bf16 scheme (no range restrictions) runs
     const int cm = conv_mode();
@@ -1201,6 +1211,7 @@ static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float
                 else FAVAE_KLAUNCH((thin_out_kernel<3, 2, true>), dim3(blocks), dim3(256), shm, s, t);
             }
             FAVAE_CHECK_LAUNCH();
+            if (slabs_out) { *slabs_out = blocks; return FAVAE_OK; }
             const size_t nw = (size_t)d->Cout * 9 * d->Cin;
             FAVAE_KLAUNCH(reduce_slabs_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, s, (const float*)ws, dw, nw, blocks, accumulate);
             FAVAE_CHECK_LAUNCH();
@@ -1337,9 +1348,72 @@ static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float
 #undef FAVAE_LAUNCH_WGRAD
 #undef FAVAE_LAUNCH_WBUF
     FAVAE_CHECK_LAUNCH();
+    if (slabs_out) { *slabs_out = a.splitk; return FAVAE_OK; }
     const size_t n = (size_t)d->Cout * d->KH * d->KW * d->Cin;
     FAVAE_KLAUNCH(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, dw, n, a.splitk, accumulate);
     FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+namespace {
+// out_j[i] (+)= sum_z part_j[z][i] for up to FAVAE_REDUCE_JOBS_MAX jobs in ONE launch: block -> (job, 256-element chunk) through the
+// prefix table of the jobs' block counts; the same four interleaved partial sums as reduce_slabs_kernel (bit-identical results)
+struct ReduceTable {
+    favae_reduce_job job[FAVAE_REDUCE_JOBS_MAX];
+    unsigned first_block[FAVAE_REDUCE_JOBS_MAX + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void reduce_slabs_grouped_kernel(ReduceTable t) {
+    int j = 0;
+    while (j + 1 < t.njobs && blockIdx.x >= t.first_block[j + 1]) ++j;
+    const favae_reduce_job jb = t.job[j];
+    const size_t n = (size_t)jb.n;
+    const size_t i = (size_t)(blockIdx.x - t.first_block[j]) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* part = jb.part;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 7 < jb.slabs; z += 8) {                  // eight loads in flight, summed in reduce_slabs_kernel's order
+        const float v0 = part[(size_t)z * n + i], v1 = part[(size_t)(z + 1) * n + i], v2 = part[(size_t)(z + 2) * n + i],
+                    v3 = part[(size_t)(z + 3) * n + i], v4 = part[(size_t)(z + 4) * n + i], v5 = part[(size_t)(z + 5) * n + i],
+                    v6 = part[(size_t)(z + 6) * n + i], v7 = part[(size_t)(z + 7) * n + i];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+    }
+    for (; z + 3 < jb.slabs; z += 4) {
+        s0 += part[(size_t)z * n + i];
+        s1 += part[(size_t)(z + 1) * n + i];
+        s2 += part[(size_t)(z + 2) * n + i];
+        s3 += part[(size_t)(z + 3) * n + i];
+    }
+    for (; z < jb.slabs; ++z) s0 += part[(size_t)z * n + i];
+    const float sum = (s0 + s1) + (s2 + s3);
+    jb.out[i] = jb.accumulate ? jb.out[i] + sum : sum;
+}
+}  // namespace
+
+// jobs: HOST array.  Jobs of one call must have distinct `out` ranges (two jobs accumulating into the same gradient would race).
+extern "C" int favae_reduce_slabs_grouped(const favae_reduce_job* jobs, int njobs, favae_stream_t stream) {
+    FAVAE_REQUIRE(jobs && njobs > 0);
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < njobs; base += FAVAE_REDUCE_JOBS_MAX) {
+        ReduceTable t;
+        t.njobs = njobs - base < FAVAE_REDUCE_JOBS_MAX ? njobs - base : FAVAE_REDUCE_JOBS_MAX;
+        unsigned blocks = 0;
+        double bytes = 0.0;
+        for (int j = 0; j < t.njobs; ++j) {
+            const favae_reduce_job& jb = jobs[base + j];
+            FAVAE_REQUIRE(jb.part && jb.out && jb.n > 0 && jb.slabs > 0);
+            t.job[j] = jb;
+            t.first_block[j] = blocks;
+            blocks += (unsigned)cdiv(jb.n, 256);
+            bytes += 4.0 * jb.n * (jb.slabs + (jb.accumulate ? 2 : 1));
+        }
+        t.first_block[t.njobs] = blocks;
+        FAVAE_PROF_NOTE(0, bytes);
+        FAVAE_KLAUNCH(reduce_slabs_grouped_kernel, dim3(blocks), dim3(256), 0, s, t);
+        FAVAE_CHECK_LAUNCH();
+    }
     return FAVAE_OK;
 }
 

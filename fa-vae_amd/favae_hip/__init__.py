@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FAVAE_HIP_LIB") or os.path.join(_HERE, "libfavae_hip.so")     # FAVAE_HIP_LIB: same-box A/B of two builds
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02, ACT_RELU = 0, 1, 2, 3
@@ -26,6 +26,10 @@ class ConvDesc(Structure):
     _fields_ = [(n, c_int32) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "KH", "KW", "stride", "pad",
                                        "gather", "act", "affine_per_image", "lat_step", "lat_side", "lat_oh", "lat_ow",
                                        "pad_dw", "w_rec_offset")]
+
+
+class ReduceJob(Structure):
+    _fields_ = [("part", c_void_p), ("out", c_void_p), ("n", c_int64), ("slabs", c_int32), ("accumulate", c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/favae_hip.h one to one (tests/test_abi.py checks the symbol list)
@@ -116,6 +120,8 @@ SIGNATURES = {
     "favae_gn_act_bwd_colsum": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P,
                                         c_size_t, _P, _P, _S]),
     "favae_colsum_finish": (c_int, [_P, c_int, c_int, _P, c_int, _S]),
+    "favae_conv_wgrad_slabs": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, POINTER(c_int), _S]),
+    "favae_reduce_slabs_grouped": (c_int, [POINTER(ReduceJob), c_int, _S]),
     "favae_prof_enable": (c_int, [c_int]),
     "favae_prof_reset": (c_int, []),
     "favae_prof_report": (c_int64, [ctypes.c_char_p, c_int64]),

@@ -12,8 +12,8 @@ from ctypes import byref
 
 import torch
 
-from . import (ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SILU, GATHER_DILATE2, GATHER_PLAIN, GATHER_UPSAMPLE2, call, make_conv_desc,
-               ptr, query, workspace)
+from . import (ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SILU, GATHER_DILATE2, GATHER_PLAIN, GATHER_UPSAMPLE2, ReduceJob, call,
+               make_conv_desc, ptr, query, workspace)
 
 CL = torch.channels_last
 
@@ -218,7 +218,12 @@ _SUBPIXEL_DGRAD = os.environ.get("FAVAE_SUBPIXEL_DGRAD", "1") != "0"     # Downs
 # reads stays referenced in _SIDE["pending"] until an event recorded behind that launch has completed (or the main stream has
 # waited for the side stream): a live reference forces the engine's out-of-place add and keeps the block out of the allocator.
 # _SIDE["delay"] > 0 (tests only) puts a busy-wait of that many cycles in front of every side-stream launch.
-_SIDE = {"stream": None, "used": False, "on": os.environ.get("FAVAE_WGRAD_STREAM", "1") != "0", "pending": [], "delay": 0}
+_SIDE = {"stream": None, "used": False, "on": os.environ.get("FAVAE_WGRAD_STREAM", "1") != "0", "pending": [], "delay": 0,
+         "jobs": [], "targets": set()}
+# Split-K slab reductions of the side-stream weight gradients are collected and run as ONE grouped launch per flush (end of backward,
+# or right before a gradient segment is handed to the all-reduce) instead of one latency-bound launch per layer.  FAVAE_DEFER_REDUCE=0:
+# every weight gradient reduces its own slabs (A/B switch; the sums are taken in the same order: bit-identical).
+_DEFER_REDUCE = os.environ.get("FAVAE_DEFER_REDUCE", "1") != "0"
 
 
 def _side_stream():
@@ -227,10 +232,44 @@ def _side_stream():
     return _SIDE["stream"]
 
 
+def _defer_reduction(part, out, n, slabs, accumulate):
+    """queue out[:n] (+)= sum of the `slabs` slabs in `part` for the next flush_reductions() (side stream)"""
+    key = out.data_ptr()
+    if key in _SIDE["targets"]:            # a second gradient for the same parameter in this pass (a module applied twice): the
+        flush_reductions()                 # grouped kernel must not accumulate twice into one range concurrently
+    _SIDE["targets"].add(key)
+    _SIDE["jobs"].append((part, out, int(n), int(slabs), int(accumulate)))
+
+
+def flush_reductions():
+    """one grouped launch (side stream, behind the weight-gradient kernels that wrote the slabs) for every queued slab reduction"""
+    jobs = _SIDE["jobs"]
+    if not jobs:
+        return
+    arr = (ReduceJob * len(jobs))()
+    for a, (part, out, n, slabs, acc) in zip(arr, jobs):
+        a.part, a.out, a.n, a.slabs, a.accumulate = part.data_ptr(), out.data_ptr(), n, slabs, acc
+    side = _side_stream()
+    with torch.cuda.stream(side):
+        call("favae_reduce_slabs_grouped", arr, len(jobs))
+        ev = torch.cuda.Event()
+        ev.record(side)
+    _SIDE["pending"].append((ev, [t for j in jobs for t in j[:2]]))
+    _SIDE["jobs"] = []
+    _SIDE["targets"] = set()
+
+
+def side_stream_flushed():
+    """the weight-gradient stream with every queued slab reduction launched on it (what a gradient exchange has to wait for)"""
+    flush_reductions()
+    return _SIDE["stream"]
+
+
 def sync_side_stream():
     """make the current stream wait for everything queued on the side stream.  Queued automatically as an end-of-backward
     callback of the autograd engine by the first conv that uses the side stream, so gradients are complete (in stream order)
     whenever .backward() / autograd.grad() returns."""
+    flush_reductions()
     if _SIDE["used"]:
         torch.cuda.current_stream().wait_stream(_SIDE["stream"])
         _SIDE["used"] = False
@@ -543,8 +582,15 @@ class FusedConvFn(torch.autograd.Function):
             wd, wws, wtgt = d, ws, (tgt if tgt is not None else dwk)
             acc = 1 if tgt is not None else 0
 
+            defer = _DEFER_REDUCE and tgt is not None and _SIDE["on"] and not use_planes
+
             def launch_wgrad(dys):
-                if use_planes and (xs is not None or dys is not None):
+                if defer:                                     # slabs stay in the workspace until flush_reductions()
+                    slabs = ctypes.c_int(0)
+                    call("favae_conv_wgrad_slabs", byref(wd), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(wws),
+                         wws.numel(), byref(slabs))
+                    _defer_reduction(wws, wtgt, Cout * cfg.kh * cfg.kw * Cin, slabs.value, acc)
+                elif use_planes and (xs is not None or dys is not None):
                     call("favae_conv_wgrad_planes", byref(wd), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(xs),
                          ptr(dys), ptr(wtgt), acc, ptr(wws), wws.numel())
                 else:

@@ -210,7 +210,7 @@ class TrainStep:
                 segs[i].append((pos, pos + n))
             pos += n
         assert pos == total
-        self.exchange = GradExchange(self.gflat, segs, side_stream=lambda: K._SIDE["stream"])
+        self.exchange = GradExchange(self.gflat, segs, side_stream=K.side_stream_flushed)
         self._armed = False
 
         def mark(i):

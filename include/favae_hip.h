@@ -115,6 +115,24 @@ int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const float* dy, 
                      const float* x_absmax, const float* dy_absmax, float* dw, int accumulate, void* ws, size_t ws_bytes,
                      favae_stream_t stream);
 
+/* The same weight gradient with the slab reduction left to the caller: the kernel's partial slabs stay in `ws`
+ * ([*slabs][Cout][KH][KW][Cin] floats; *slabs is written on the host) until favae_reduce_slabs_grouped sums the slabs of MANY layers
+ * in one launch -- per layer the reduction is a latency-bound 40-60 us launch (214 of them per training step), grouped it is one
+ * bandwidth-bound pass at the end of backward.  Same summation order as favae_conv_wgrad: bit-identical gradients. */
+int favae_conv_wgrad_slabs(const favae_conv_desc* d, const float* x, const float* dy, const float* scale, const float* shift,
+                           const float* x_absmax, const float* dy_absmax, void* ws, size_t ws_bytes, int* slabs,
+                           favae_stream_t stream);
+typedef struct favae_reduce_job {
+    const float* part;              /* [slabs][n] */
+    float* out;                     /* [n]: out[i] (+)= sum_z part[z][i], z ascending in four interleaved partial sums */
+    int64_t n;
+    int32_t slabs;
+    int32_t accumulate;
+} favae_reduce_job;
+#define FAVAE_REDUCE_JOBS_MAX 96
+/* jobs: host array (any length; launched in groups of FAVAE_REDUCE_JOBS_MAX).  The `out` ranges of one call must be disjoint. */
+int favae_reduce_slabs_grouped(const favae_reduce_job* jobs, int njobs, favae_stream_t stream);
+
 /* wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci]  (weights of the data-gradient convolution) */
 int favae_weight_flip(const float* w, float* wt, int Cout, int KH, int KW, int Cin, favae_stream_t stream);
 /* the same, written directly as pre-split records for favae_conv_fwd_split (favae_split_weights_bytes(Cout*KH*KW*Cin, planes)
