@@ -224,6 +224,7 @@ _SIDE = {"stream": None, "used": False, "on": os.environ.get("FAVAE_WGRAD_STREAM
 # or right before a gradient segment is handed to the all-reduce) instead of one latency-bound launch per layer.  FAVAE_DEFER_REDUCE=0:
 # every weight gradient reduces its own slabs (A/B switch; the sums are taken in the same order: bit-identical).
 _DEFER_REDUCE = os.environ.get("FAVAE_DEFER_REDUCE", "1") != "0"
+_FLUSH_EVERY = int(os.environ.get("FAVAE_FLUSH_EVERY", "12"))
 
 
 def _side_stream():
@@ -239,6 +240,8 @@ def _defer_reduction(part, out, n, slabs, accumulate):
         flush_reductions()                 # grouped kernel must not accumulate twice into one range concurrently
     _SIDE["targets"].add(key)
     _SIDE["jobs"].append((part, out, int(n), int(slabs), int(accumulate)))
+    if len(_SIDE["jobs"]) >= _FLUSH_EVERY:      # keep the flushes inside backward: only the last, short one is exposed at its end
+        flush_reductions()
 
 
 def flush_reductions():
@@ -291,6 +294,11 @@ def _side_launch(fn, operands):
         ev = torch.cuda.Event()
         ev.record(side)
     pend.append((ev, [t for t in operands if t is not None]))
+    _mark_side_used()
+
+
+def _mark_side_used():
+    """the running backward pass ends with the main stream waiting for the side stream (and the queued reductions flushed)"""
     if not _SIDE["used"]:
         _SIDE["used"] = True
         torch.autograd.Variable._execution_engine.queue_callback(sync_side_stream)
@@ -398,9 +406,17 @@ def _bias_grad_and_range(dy, p_b, need_b, want_range, M, Cout, dev):
     if pre is not None:
         if need_b:
             tgt = _direct_grad(p_b)
-            if tgt is None:
-                db = torch.empty((Cout,), dtype=torch.float32, device=dev)
-            call("favae_colsum_finish", ptr(pre[0]), pre[1], Cout, ptr(db if tgt is None else tgt), 0 if tgt is None else 1)
+            if tgt is not None and _DEFER_REDUCE and _SIDE["on"]:
+                # second stage of the column sum (2048 partial rows of C floats: one latency-bound 80 us launch per layer when run
+                # alone) joins the grouped slab reductions of the side stream; the partials were written on THIS stream
+                side = _side_stream()
+                side.wait_stream(torch.cuda.current_stream())
+                _defer_reduction(pre[0], tgt, Cout, pre[1], 1)
+                _mark_side_used()
+            else:
+                if tgt is None:
+                    db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+                call("favae_colsum_finish", ptr(pre[0]), pre[1], Cout, ptr(db if tgt is None else tgt), 0 if tgt is None else 1)
         return db, (pre[2] if want_range else None)
     if want_range:
         dyb = torch.empty((1,), dtype=torch.float32, device=dev)
