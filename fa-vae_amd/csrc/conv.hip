@@ -818,25 +818,75 @@ extern "C" int favae_absmax(const float* x, int64_t n, float* out, favae_stream_
     return FAVAE_OK;
 }
 
+namespace {
+// max |x| per segment of a flat buffer: seg_off[nseg + 1] element offsets (ascending); one block per 4096-element chunk of a segment
+// (chunks never straddle segments: chunk_seg / chunk_first map the block to its segment and first element), one atomicMax per block
+__global__ __launch_bounds__(256) void segment_absmax_kernel(const float* __restrict__ x, const int64_t* __restrict__ seg_off,
+                                                             const int* __restrict__ chunk_seg, const int64_t* __restrict__ chunk_first,
+                                                             unsigned* __restrict__ out) {
+    const int sg = chunk_seg[blockIdx.x];
+    const int64_t b = chunk_first[blockIdx.x], e = min(seg_off[sg + 1], b + 4096);
+    float m = 0.f;
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out + sg, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
+}  // namespace
+
+// out[s] = max |x[seg_off[s] .. seg_off[s+1])| for nseg segments of one flat buffer in ONE launch (the |max| of every weight tensor of
+// a model whose parameters are views of a flat buffer: refreshed once per optimizer step instead of once per conv call).
+// seg_off / chunk_seg / chunk_first: DEVICE arrays built by the caller (chunks of <= 4096 elements, none across a segment boundary).
+extern "C" int favae_segment_absmax(const float* x, const int64_t* seg_off, int nseg, const int* chunk_seg, const int64_t* chunk_first,
+                                    int nchunks, float* out, favae_stream_t stream) {
+    FAVAE_REQUIRE(x && seg_off && chunk_seg && chunk_first && out && nseg > 0 && nchunks > 0);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float) * nseg, s) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
+    FAVAE_KLAUNCH(segment_absmax_kernel, dim3(nchunks), dim3(256), 0, s, x, seg_off, chunk_seg, chunk_first, (unsigned*)out);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
+static int split_weights_impl(const float* in, void* out, int64_t n, int planes, const float* amax, favae_stream_t stream);
+
 extern "C" int favae_split_weights(const float* in, void* out, int64_t n, int planes, favae_stream_t stream) {
+    return split_weights_impl(in, out, n, planes, nullptr, stream);
+}
+
+// favae_split_weights with max |in| supplied by the caller (device float, e.g. from favae_segment_absmax): no reduction pass
+extern "C" int favae_split_weights_amax(const float* in, void* out, int64_t n, int planes, const float* amax, favae_stream_t stream) {
+    FAVAE_REQUIRE(amax);
+    return split_weights_impl(in, out, n, planes, amax, stream);
+}
+
+static int split_weights_impl(const float* in, void* out, int64_t n, int planes, const float* amax, favae_stream_t stream) {
     FAVAE_REQUIRE(in && out && n > 0 && n % 4 == 0 && planes >= 1 && planes <= 3);
     FAVAE_REQUIRE((((uintptr_t)out) & 15) == 0);
     hipStream_t s = (hipStream_t)stream;
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     unsigned* rec = (unsigned*)((char*)out + sp::WHDR);
-    if (planes <= 2) {
+    if (planes <= 2 && amax) {                 // the header must hold the maximum (later kernels read it there): the kernel copies it
+        if (planes == 2)
+            FAVAE_KLAUNCH((split_w_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4), amax,
+                          (float*)out);
+        else
+            FAVAE_KLAUNCH((split_w_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4), amax,
+                          (float*)out);
+    } else if (planes <= 2) {
         const int rc = launch_absmax(in, n, (float*)out, s);
         if (rc != FAVAE_OK) return rc;
         if (planes == 2)
             FAVAE_KLAUNCH((split_w_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
-                               (const float*)out);
+                               (const float*)out, (float*)nullptr);
         else
             FAVAE_KLAUNCH((split_w_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
-                               (const float*)out);
+                               (const float*)out, (float*)nullptr);
     } else {
         FAVAE_KLAUNCH((split_w_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
-                           (const float*)nullptr);
+                           (const float*)nullptr, (float*)nullptr);
     }
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;

@@ -375,8 +375,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_sp_kernel(WgradArgs a) {
 // out: WREC-byte records {plane0[4], plane1[4] (, plane2[4])} per 4 consecutive floats of `in` (n % 4 == 0)
 template <int NP>
 __global__ __launch_bounds__(256) void split_w_kernel(const float4* __restrict__ in, unsigned* __restrict__ out, size_t n4,
-                                                      const float* __restrict__ amax) {
+                                                      const float* __restrict__ amax, float* __restrict__ hdr_out = nullptr) {
     const float Sw = sp::Scheme<NP>::SCALED ? sp::pow2_scale(amax) : 1.f;
+    if (hdr_out && blockIdx.x == 0 && threadIdx.x == 0) *hdr_out = *amax;      // a maximum supplied by the caller goes into the header
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         uint2 p[NP];
         sp::Scheme<NP>::split4(in[i], Sw, p);

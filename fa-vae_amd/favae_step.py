@@ -150,6 +150,12 @@ class TrainStep:
         if self.distributed:
             self._broadcast_initial_state()
             self._setup_overlapped_exchange()
+        # max |w| of every conv / linear weight, refreshed with the parameters (one launch per optimizer step)
+        self.wmax = [K.WeightMaxima(self.pflat, self.params)] if dev.type == "cuda" else []
+        if train_disc and dev.type == "cuda":
+            self.wmax.append(K.WeightMaxima(self.dpflat, self.dparams))
+        for wm in self.wmax:
+            wm.refresh()
 
     # ------------------------------------------------------------------------------------------------------------
     # data parallelism: one process per GPU, each on its own slice of the global batch
@@ -400,6 +406,8 @@ class TrainStep:
             dist.all_reduce(self.dgflat)
         self.t_d += 1
         K.adam_step(self.dpflat, self.dgflat, self.dmflat, self.dvflat, self.t_d, self.lr, self.betas, self.eps, 1.0 / self.world)
+        if len(self.wmax) > 1:
+            self.wmax[1].refresh()
         return {"loss_d": loss_d, "logits_real": logits_real, "logits_fake_d": logits_fake}
 
     def step(self, x):
@@ -420,6 +428,8 @@ class TrainStep:
         if self.pflat.numel() > nm:
             K.adam_step(self.pflat[nm:], self.gflat[nm:], self.mflat[nm:], self.vflat[nm:], self.t, self.sigma_lr, self.betas,
                         self.eps, gs)
+        if self.wmax:
+            self.wmax[0].refresh()
         if self.train_disc:
             out.update(self.disc_step(x))
         return out

@@ -100,6 +100,13 @@ int favae_get_conv_mode(void);
 int favae_conv_wants_split_weights(const favae_conv_desc* d, int has_affine);
 size_t favae_split_weights_bytes(int64_t n, int planes);
 int favae_split_weights(const float* in, void* out, int64_t n, int planes, favae_stream_t stream);
+/* The same with max |in| supplied by the caller (device float), so that no reduction pass runs per conv call; and the pass that
+ * produces such maxima for EVERY weight tensor of a model at once: out[s] = max |x[seg_off[s] .. seg_off[s+1])| over a flat parameter
+ * buffer (favae_step.TrainStep refreshes them once per optimizer step).  seg_off [nseg + 1], chunk_seg / chunk_first [nchunks]: device
+ * arrays; chunk c covers elements chunk_first[c] .. +4096 (clipped to its segment chunk_seg[c]); chunks never straddle segments. */
+int favae_split_weights_amax(const float* in, void* out, int64_t n, int planes, const float* amax, favae_stream_t stream);
+int favae_segment_absmax(const float* x, const int64_t* seg_off, int nseg, const int* chunk_seg, const int64_t* chunk_first, int nchunks,
+                         float* out, favae_stream_t stream);
 int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, const void* wsplit, int planes, const float* x_absmax,
                          const float* bias, const float* resid, const float* scale, const float* shift, float* y,
                          favae_stream_t stream);
