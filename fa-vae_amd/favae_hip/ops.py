@@ -172,7 +172,6 @@ class WeightMaxima:
     parameter's entry is used only while the parameter's version counter is the one seen at refresh time (load_state_dict, .copy_())."""
 
     def __init__(self, flat, params):
-        import numpy as np
         self.flat, self.params = flat, [p for p in params if p.dim() >= 2]
         dev = flat.device
         base = flat.data_ptr()
@@ -184,7 +183,6 @@ class WeightMaxima:
             for f in range(o, o + p.numel(), 4096):
                 cseg.append(i)
                 cfirst.append(f)
-        # segment s = [offs[s], offs[s] + numel): seg_off has 2 entries per segment packed as consecutive pairs through a dummy gap
         ends = [o + p.numel() for o, p in zip(offs, self.params)]
         self.nseg = len(self.params)
         # the kernel reads seg_off[s + 1] as the END of segment s: store ends shifted by one (seg_off[0] unused)
@@ -237,53 +235,6 @@ def set_conv_mode(mode):
     if query("favae_set_conv_mode", _chk_mode) != 0:
         raise RuntimeError("favae_set_conv_mode failed")
     _FP16_PLANES = None
-
-
-class WeightMaxima:
-    """max |w| of every parameter that is a view of one flat buffer, refreshed by ONE launch (favae_segment_absmax) -- the fp16
-    split-precision convs need the maximum of their weight tensor on every call; without this each conv call runs its own reduction
-    (98 launches + 98 memsets per training step).  refresh() is called by the owner of the flat buffer after every update of it; a
-    parameter's entry is used only while the parameter's version counter is the one seen at refresh time (load_state_dict, .copy_())."""
-
-    def __init__(self, flat, params):
-        import numpy as np
-        self.flat, self.params = flat, [p for p in params if p.dim() >= 2]
-        dev = flat.device
-        base = flat.data_ptr()
-        offs, cseg, cfirst = [], [], []
-        self.params.sort(key=lambda p: p.data_ptr())
-        for i, p in enumerate(self.params):
-            o = (p.data_ptr() - base) // 4
-            offs.append(o)
-            for f in range(o, o + p.numel(), 4096):
-                cseg.append(i)
-                cfirst.append(f)
-        # segment s = [offs[s], offs[s] + numel): seg_off has 2 entries per segment packed as consecutive pairs through a dummy gap
-        ends = [o + p.numel() for o, p in zip(offs, self.params)]
-        self.nseg = len(self.params)
-        # the kernel reads seg_off[s + 1] as the END of segment s: store ends shifted by one (seg_off[0] unused)
-        self.seg_off = torch.tensor([0] + ends, dtype=torch.int64, device=dev)
-        self.chunk_seg = torch.tensor(cseg, dtype=torch.int32, device=dev)
-        self.chunk_first = torch.tensor(cfirst, dtype=torch.int64, device=dev)
-        self.out = torch.zeros((self.nseg,), dtype=torch.float32, device=dev)
-        self.versions = [None] * self.nseg
-        for i, p in enumerate(self.params):
-            p._favae_wmax = (self, i)
-
-    def refresh(self):
-        call("favae_segment_absmax", ptr(self.flat), ptr(self.seg_off), self.nseg, ptr(self.chunk_seg), ptr(self.chunk_first),
-             self.chunk_seg.numel(), ptr(self.out))
-        self.versions = [p._version for p in self.params]
-
-
-def _weight_amax(w):
-    ent = getattr(w, "_favae_wmax", None)
-    if ent is None:
-        return None
-    wm, i = ent
-    if wm.versions[i] != w._version:
-        return None
-    return wm.out[i:i + 1]
     return {v: k for k, v in CONV_MODES.items()}[prev]
 
 
