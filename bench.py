@@ -45,7 +45,7 @@ PEAK_HBM_TBS = 8.0                    # HBM3E (MI355X_MICROARCH.md)
 MFMA_WALL_RANDOM_TFLOPS = 1400.0      # measured: register-resident v_mfma_f32_32x32x16_f16 loop on random operands, 1.34-1.44 PFLOP/s
                                       # over 3 ms .. 1.5 s runs (tools/experiments/mfma_power.hip; 1.84-1.92 on zeros): what the matrix
                                       # pipe sustains on real data
-SPLIT_PRODUCTS = {0: None, 1: 1, 2: 3, 3: 6}   # 16-bit MFMA products per fp32 multiply-add: planes -> products (conv_split.h)
+SPLIT_PRODUCTS = {0: None, 1: 1, 2: 3, 3: 6, 4: 1}   # 16-bit MFMA products per multiply-add by scheme id (conv_split.h): h1, h3, b6, b1
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
 MAX_LINE_BYTES = 4096                 # the driver keeps an 8 KB tail of stdout: the JSON line must stay far below it
 NOTES = {
@@ -472,7 +472,7 @@ def main():
             tf, gb = work
             a_f = tf * args.batch * args.steps / dt                                  # per GPU
             a_b = gb * 1e-3 * args.batch * args.steps / dt
-            planes = {"fp32": 2, "fp16": 1, "bf16": 1}[args.precision]
+            planes = {"fp32": 2, "fp16": 1, "bf16": 4}[args.precision]
             peak = PEAK_16BIT_MFMA_TFLOPS / SPLIT_PRODUCTS[planes]
             res["roofline_step"] = {"tflop_per_image": tf, "gb_per_image": gb,
                                     "mfma": {"achieved": rnd(a_f), "peak": rnd(peak), "unit": "TFLOP/s", "frac": rnd(a_f / peak)},

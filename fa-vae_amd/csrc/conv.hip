@@ -29,15 +29,17 @@ bool force_generic() {
 }
 // 128-wide convs run on the split-precision matrix path (conv_split.h).  FAVAE_CONV_MODE = h3 (default: two scaled fp16
 // planes, 3 MFMAs, needs operand maxima) | b6 (three bf16 planes, 6 MFMAs) | fp32 (the fp32-MFMA kernels; also FAVAE_CONV_B6=0).
-// h1 = ONE scaled fp16 plane, 1 MFMA: the 16-bit mixed-precision mode, not fp32-grade (BASELINE config 5).
-// Returns the number of planes: 1, 2, 3 or 0.  favae_set_conv_mode overrides the environment at run time.
+// h1 = ONE scaled fp16 plane, 1 MFMA: the 16-bit mixed-precision mode, not fp32-grade (BASELINE config 5); b1 = ONE bf16 plane
+// (scheme id 4): the bf16 mixed-precision mode.
+// Returns the scheme id: 0 fp32 | 1 h1 | 2 h3 | 3 b6 | 4 b1.  favae_set_conv_mode overrides the environment at run time.
 static int g_conv_mode = -1;
 int conv_mode() {
     if (g_conv_mode < 0) {
         const char* e = getenv("FAVAE_CONV_MODE");
         const char* b = getenv("FAVAE_CONV_B6");
         int v = 2;
-        if (e && e[0] == 'b') v = 3;
+        if (e && e[0] == 'b' && e[1] == '1') v = 4;
+        else if (e && e[0] == 'b') v = 3;
         else if (e && e[0] == 'h' && e[1] == '1') v = 1;
         else if ((e && e[0] == 'f') || (b && b[0] == '0')) v = 0;
         g_conv_mode = v;
@@ -760,11 +762,11 @@ static bool sp_fwd_eligible(const favae_conv_desc* d, bool has_affine) {
 }
 
 static int wrec_bytes(int planes) {
-    return planes == 1 ? sp::Scheme<1>::WREC : (planes == 2 ? sp::Scheme<2>::WREC : sp::Scheme<3>::WREC);
+    return planes == 1 ? sp::Scheme<1>::WREC : (planes == 2 ? sp::Scheme<2>::WREC : (planes == 4 ? sp::Scheme<4>::WREC : sp::Scheme<3>::WREC));
 }
 
 extern "C" int favae_set_conv_mode(int planes) {
-    FAVAE_REQUIRE(planes >= 0 && planes <= 3);
+    FAVAE_REQUIRE(planes >= 0 && planes <= 4);
     g_conv_mode = planes;
     return FAVAE_OK;
 }
@@ -776,7 +778,7 @@ extern "C" int favae_conv_wants_split_weights(const favae_conv_desc* d, int has_
 }
 
 extern "C" size_t favae_split_weights_bytes(int64_t n, int planes) {
-    if (n <= 0 || n % 4 || planes < 1 || planes > 3) return 0;
+    if (n <= 0 || n % 4 || planes < 1 || planes > 4) return 0;
     return (size_t)sp::WHDR + (size_t)(n / 4) * wrec_bytes(planes);
 }
 
@@ -862,12 +864,18 @@ extern "C" int favae_split_weights_amax(const float* in, void* out, int64_t n, i
 }
 
 static int split_weights_impl(const float* in, void* out, int64_t n, int planes, const float* amax, favae_stream_t stream) {
-    FAVAE_REQUIRE(in && out && n > 0 && n % 4 == 0 && planes >= 1 && planes <= 3);
+    FAVAE_REQUIRE(in && out && n > 0 && n % 4 == 0 && planes >= 1 && planes <= 4);
     FAVAE_REQUIRE((((uintptr_t)out) & 15) == 0);
     hipStream_t s = (hipStream_t)stream;
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     unsigned* rec = (unsigned*)((char*)out + sp::WHDR);
+    if (planes == 4) {                          // one bf16 plane: no range
+        FAVAE_KLAUNCH((split_w_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4),
+                      (const float*)nullptr, (float*)nullptr);
+        FAVAE_CHECK_LAUNCH();
+        return FAVAE_OK;
+    }
     if (planes <= 2 && amax) {                 // the header must hold the maximum (later kernels read it there): the kernel copies it
         if (planes == 2)
             FAVAE_KLAUNCH((split_w_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)in, rec, (size_t)(n / 4), amax,
@@ -911,7 +919,7 @@ extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, co
                                     const float* x_absmax, const float* bias, const float* resid, const float* scale,
                                     const float* shift, float* y, favae_stream_t stream) {
     if (!sp_fwd_eligible(d, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-    FAVAE_REQUIRE(wsplit && (planes == 3 || ((planes == 2 || planes == 1) && x_absmax)));
+    FAVAE_REQUIRE(wsplit && (planes == 3 || planes == 4 || ((planes == 2 || planes == 1) && x_absmax)));
     return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr);
 }
 
@@ -924,7 +932,7 @@ static bool halo3_fp16_ok(const favae_conv_desc* d, bool has_affine);
 static bool planes_producer_ok(const favae_conv_desc* d, bool has_affine) { return conv_mode() == 2 && halo3_fp16_ok(d, has_affine); }
 
 static bool halo3_fp16_ok(const favae_conv_desc* d, bool has_affine) {
-    if (!sp_fwd_eligible(d, has_affine) || (conv_mode() != 2 && conv_mode() != 1) || desc_special(d) || !use_halo()) return false;
+    if (!sp_fwd_eligible(d, has_affine) || conv_mode() == 3 || conv_mode() == 0 || desc_special(d) || !use_halo()) return false;
     const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, wb = (size_t)d->Cout * 9 * d->Cin * 4;
     if (has_affine && d->act != FAVAE_ACT_NONE && d->act != FAVAE_ACT_SILU) return false;
     return d->Cout > 64 && d->Cin % 16 == 0 && d->stride == 1 && d->gather == FAVAE_GATHER_PLAIN && d->KH == 3 && d->KW == 3 &&
@@ -964,9 +972,9 @@ extern "C" int favae_conv_stats_tiles(const favae_conv_desc* d, int has_affine) 
 extern "C" int favae_conv_fwd_split_stats(const favae_conv_desc* d, const float* x, const void* wsplit, int planes,
                                           const float* x_absmax, const float* bias, const float* resid, const float* scale,
                                           const float* shift, float* y, void* part, size_t part_bytes, favae_stream_t stream) {
-    FAVAE_REQUIRE(desc_ok(d) && wsplit && x_absmax && part);
+    FAVAE_REQUIRE(desc_ok(d) && wsplit && (x_absmax || planes == 4) && part);
     const int tiles = favae_conv_stats_tiles(d, scale != nullptr);
-    if (!tiles || (planes != 2 && planes != 1)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (!tiles || (planes != 2 && planes != 1 && planes != 4)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr, nullptr,
                          (double*)part);
@@ -976,9 +984,9 @@ extern "C" int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy,
                                       const float* dy_absmax, float* da, const float* x, const float* mean, const float* rstd,
                                       const float* gamma, const float* beta, int groups, int act, void* part, size_t part_bytes,
                                       favae_stream_t stream) {
-    FAVAE_REQUIRE(desc_ok(d) && dy && wsplit && dy_absmax && da && x && mean && rstd && gamma && beta && part && groups > 0);
+    FAVAE_REQUIRE(desc_ok(d) && dy && wsplit && (dy_absmax || planes == 4) && da && x && mean && rstd && gamma && beta && part && groups > 0);
     const int tiles = favae_conv_gnbwd_tiles(d);
-    if (!tiles || (planes != 2 && planes != 1) || d->Cout % groups != 0) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (!tiles || (planes != 2 && planes != 1 && planes != 4) || d->Cout % groups != 0) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     GnBwdEpi gb{x, mean, rstd, gamma, beta, (double*)part, groups, act};
     return conv_fwd_impl(d, dy, (const float*)wsplit, nullptr, nullptr, nullptr, nullptr, da, planes, dy_absmax, stream, nullptr, &gb);
@@ -1091,17 +1099,21 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     do {                                                                                                      \
         if (wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 2, KS>), hgrid, dim3(512), 0, s, a);  \
         else if (wplanes == 1) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 1, KS>), hgrid, dim3(512), 0, s, a); \
+        else if (wplanes == 4) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 4, KS>), hgrid, dim3(512), 0, s, a); \
         else FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 3, KS>), hgrid, dim3(512), 0, s, a);               \
     } while (0)
 #define FAVAE_LAUNCH_HALO(X) FAVAE_LAUNCH_HALO_K(X, 3)
         if (planes_out && !(halo_ok && wplanes == 2 && xf != 3)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-        const bool fp16p = wplanes == 2 || wplanes == 1;
+        const bool fp16p = wplanes == 2 || wplanes == 1 || wplanes == 4;           // schemes with the epilogue variants
         if (gb && !(halo_ok && fp16p && xf == 0 && !planes_out && !bias && !resid)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (stats_part && !(halo_ok && fp16p && (xf == 0 || xf == 2) && !planes_out && !gb)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (gb && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (gb && wplanes == 4) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 4, 3, false, true>), hgrid, dim3(512), 0, s, a);
         else if (gb) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 1, 3, false, true>), hgrid, dim3(512), 0, s, a);
         else if (stats_part && xf == 0 && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
         else if (stats_part && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 2, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (stats_part && xf == 0 && wplanes == 4) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 4, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (stats_part && wplanes == 4) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 4, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
         else if (stats_part && xf == 0) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 1, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
         else if (stats_part) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 1, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
         else
@@ -1120,6 +1132,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     do {                                                                                          \
         if (wplanes == 2) FAVAE_KLAUNCH((conv_fwd_sp_kernel<G, X, true, 8, 2>), grid, dim3(512), 0, s, a);        \
         else if (wplanes == 1) FAVAE_KLAUNCH((conv_fwd_sp_kernel<G, X, true, 8, 1>), grid, dim3(512), 0, s, a);   \
+        else if (wplanes == 4) FAVAE_KLAUNCH((conv_fwd_sp_kernel<G, X, true, 8, 4>), grid, dim3(512), 0, s, a);   \
         else if (b6_waves() == 8) {                                                               \
             if (w6) FAVAE_KLAUNCH((conv_fwd_sp_kernel<G, X, true, 8, 3>), grid, dim3(512), 0, s, a);   \
             else FAVAE_KLAUNCH((conv_fwd_sp_kernel<G, X, false, 8, 3>), grid, dim3(512), 0, s, a);     \
@@ -1221,7 +1234,7 @@ static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float
     FAVAE_REQUIRE(desc_ok(d) && x && dy && dw && ws);
     // fp16 planes need both operand maxima; without them the bf16 scheme (no range restrictions) runs
     const int cm = conv_mode();
-    const int np = ((cm == 2 || cm == 1) && x_absmax && dy_absmax) ? cm : 3;
+    const int np = cm == 4 ? 4 : (((cm == 2 || cm == 1) && x_absmax && dy_absmax) ? cm : 3);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     if (ws_bytes < favae_conv_wgrad_workspace(d)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     // roofline numerators: same FLOPs as the forward conv; one read of x and of dy, one write of dw
@@ -1340,6 +1353,7 @@ static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float
     do {                                                      \
         if (np == 2) FAVAE_LAUNCH_NINE_M(X, 2);               \
         else if (np == 1) FAVAE_LAUNCH_NINE_M(X, 1);          \
+        else if (np == 4) FAVAE_LAUNCH_NINE_M(X, 4);          \
         else FAVAE_LAUNCH_NINE_M(X, 3);                       \
     } while (0)
         if (xf == 0) FAVAE_LAUNCH_NINE(0);
@@ -1357,6 +1371,7 @@ static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float
     do {                                                                                                  \
         if (np == 2) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<X, 2>), g3, dim3(512), 0, s, a);       \
         else if (np == 1) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<X, 1>), g3, dim3(512), 0, s, a);  \
+        else if (np == 4) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<X, 4>), g3, dim3(512), 0, s, a);  \
         else FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<X, 3>), g3, dim3(512), 0, s, a);               \
     } while (0)
         const int pre = np == 2 ? ((dy_planes ? 1 : 0) | (x_planes ? 2 : 0)) : 0;
@@ -1374,6 +1389,7 @@ static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float
     do {                                                                                                  \
         if (np == 2) FAVAE_KLAUNCH((conv_wgrad_sp_kernel<X, U, 2>), grid, dim3(256), 0, s, a);       \
         else if (np == 1) FAVAE_KLAUNCH((conv_wgrad_sp_kernel<X, U, 1>), grid, dim3(256), 0, s, a);  \
+        else if (np == 4) FAVAE_KLAUNCH((conv_wgrad_sp_kernel<X, U, 4>), grid, dim3(256), 0, s, a);  \
         else FAVAE_KLAUNCH((conv_wgrad_sp_kernel<X, U, 3>), grid, dim3(256), 0, s, a);               \
     } while (0)
         if (d->gather == FAVAE_GATHER_UPSAMPLE2) FAVAE_LAUNCH_WSP(0, true);
@@ -1551,7 +1567,7 @@ namespace {
 // weight_flip_kernel + split_w_kernel in one pass: the flipped weights of the data-gradient convolution go straight into
 // pre-split records.  The range of the flipped tensor is the range of w: `amax_src` is the header of the forward's record
 // buffer (no second maximum reduction).  Cout % 4 == 0.
-template <int NP>
+template <int SCH>
 __global__ __launch_bounds__(256) void weight_flip_split_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
                                                                 int Cout, int KH, int KW, int Cin,
                                                                 const float* __restrict__ amax_src) {
@@ -1567,7 +1583,8 @@ __global__ __launch_bounds__(256) void weight_flip_split_kernel(const float* __r
         tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * KH * KW + tap) * Cin + ci] : 0.f;
     }
     __syncthreads();
-    const float Sw = (sp::Scheme<NP>::SCALED && amax_src) ? sp::pow2_scale(amax_src) : 1.f;
+    constexpr int NP = sp::Scheme<SCH>::NPL;
+    const float Sw = (sp::Scheme<SCH>::SCALED && amax_src) ? sp::pow2_scale(amax_src) : 1.f;
     const int tapf = (KH - 1 - kh) * KW + (KW - 1 - kw);
     // 32 ci x 8 co-quads = 256 records per tile: thread -> (ci = tid / 8, quad = tid % 8)
     const int r = threadIdx.x >> 3, qd = threadIdx.x & 7;
@@ -1575,7 +1592,7 @@ __global__ __launch_bounds__(256) void weight_flip_split_kernel(const float* __r
     if (ci < Cin && co < Cout) {
         const float4 v = make_float4(tile[4 * qd][r], tile[4 * qd + 1][r], tile[4 * qd + 2][r], tile[4 * qd + 3][r]);
         uint2 p[NP];
-        sp::Scheme<NP>::split4(v, Sw, p);
+        sp::Scheme<SCH>::split4(v, Sw, p);
         unsigned* o = reinterpret_cast<unsigned*>(out + sp::WHDR) + ((((size_t)ci * KH * KW + tapf) * Cout + co) / 4) * (2 * NP);
 #pragma unroll
         for (int k = 0; k < NP; ++k) { o[2 * k] = p[k].x; o[2 * k + 1] = p[k].y; }
@@ -1585,7 +1602,8 @@ __global__ __launch_bounds__(256) void weight_flip_split_kernel(const float* __r
 
 extern "C" int favae_weight_flip_split(const float* w, void* out, int Cout, int KH, int KW, int Cin, int planes,
                                        const float* absmax_src, favae_stream_t stream) {
-    FAVAE_REQUIRE(w && out && Cout > 0 && KH > 0 && KW > 0 && Cin > 0 && Cout % 4 == 0 && (planes == 3 || ((planes == 2 || planes == 1) && absmax_src)));
+    FAVAE_REQUIRE(w && out && Cout > 0 && KH > 0 && KW > 0 && Cin > 0 && Cout % 4 == 0 &&
+                  (planes == 3 || planes == 4 || ((planes == 2 || planes == 1) && absmax_src)));
     FAVAE_REQUIRE((((uintptr_t)out) & 15) == 0);
     dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), KH * KW);
     if (planes == 2)
@@ -1593,6 +1611,9 @@ extern "C" int favae_weight_flip_split(const float* w, void* out, int Cout, int 
                            Cin, absmax_src);
     else if (planes == 1)
         FAVAE_KLAUNCH((weight_flip_split_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, Cout, KH, KW,
+                           Cin, absmax_src);
+    else if (planes == 4)
+        FAVAE_KLAUNCH((weight_flip_split_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, Cout, KH, KW,
                            Cin, absmax_src);
     else
         FAVAE_KLAUNCH((weight_flip_split_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out, Cout, KH, KW,
@@ -1607,11 +1628,12 @@ namespace {
 // four convs over dy with 2x2 / 2x1 / 1x2 / 1x1 kernels -- 9 instead of 36 taps per 2x2 block of dx.  This kernel writes the
 // four weight sets as pre-split records, one after the other: wph[ci][a][b][co] = w[co][kh(py,a)][kw(px,b)][ci] with
 // kh(even,0) = 2, kh(even,1) = 0, kh(odd,0) = 1.  One thread per record (4 consecutive co).
-template <int NP>
+template <int SCH>
 __global__ __launch_bounds__(256) void downsample_dgrad_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
                                                                        int Cout, int Cin, const float* __restrict__ amax_src) {
     if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(out)[0] = amax_src ? amax_src[0] : 0.f;
-    const float Sw = (sp::Scheme<NP>::SCALED && amax_src) ? sp::pow2_scale(amax_src) : 1.f;
+    constexpr int NP = sp::Scheme<SCH>::NPL;
+    const float Sw = (sp::Scheme<SCH>::SCALED && amax_src) ? sp::pow2_scale(amax_src) : 1.f;
     const size_t q = Cout / 4, per_tap = (size_t)Cin * q;          // records per (phase tap)
     const size_t total = 9 * per_tap;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -1633,7 +1655,7 @@ __global__ __launch_bounds__(256) void downsample_dgrad_weights_kernel(const flo
         const size_t cs = (size_t)9 * Cin;                      // stride between output channels of w
         const float4 v = make_float4(src[0], src[cs], src[2 * cs], src[3 * cs]);
         uint2 p[NP];
-        sp::Scheme<NP>::split4(v, Sw, p);
+        sp::Scheme<SCH>::split4(v, Sw, p);
         unsigned* o = reinterpret_cast<unsigned*>(out + sp::WHDR) + i * (2 * NP);
 #pragma unroll
         for (int k = 0; k < NP; ++k) { o[2 * k] = p[k].x; o[2 * k + 1] = p[k].y; }
@@ -1643,7 +1665,7 @@ __global__ __launch_bounds__(256) void downsample_dgrad_weights_kernel(const flo
 
 extern "C" int favae_downsample_dgrad_weights(const float* w, void* out, int Cout, int Cin, int planes, const float* absmax_src,
                                               favae_stream_t stream) {
-    FAVAE_REQUIRE(w && out && Cout > 0 && Cin > 0 && Cout % 4 == 0 && (planes == 3 || ((planes == 2 || planes == 1) && absmax_src)));
+    FAVAE_REQUIRE(w && out && Cout > 0 && Cin > 0 && Cout % 4 == 0 && (planes == 3 || planes == 4 || ((planes == 2 || planes == 1) && absmax_src)));
     FAVAE_REQUIRE((((uintptr_t)out) & 15) == 0);
     const size_t total = (size_t)9 * Cin * (Cout / 4);
     const unsigned blocks = (unsigned)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256));
@@ -1652,6 +1674,9 @@ extern "C" int favae_downsample_dgrad_weights(const float* w, void* out, int Cou
                            Cout, Cin, absmax_src);
     else if (planes == 1)
         FAVAE_KLAUNCH((downsample_dgrad_weights_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
+                           Cout, Cin, absmax_src);
+    else if (planes == 4)
+        FAVAE_KLAUNCH((downsample_dgrad_weights_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
                            Cout, Cin, absmax_src);
     else
         FAVAE_KLAUNCH((downsample_dgrad_weights_kernel<3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,

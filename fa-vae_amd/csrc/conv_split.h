@@ -42,10 +42,11 @@ __device__ __forceinline__ void load_wrec(R rw, unsigned voff, unsigned soff, ui
 // NW = waves per workgroup: 4 (2x2 waves of 64x64) or 8 (4x2 waves of 32x64: twice the resident waves for the same LDS
 // footprint, which is what hides the load -> split -> ds_write -> barrier -> ds_read chain of this short-MFMA kernel).
 // ---------------------------------------------------------------------------------------------------------------
-template <int GATHER, int XFORM, bool WS, int NW, int NP>
+template <int GATHER, int XFORM, bool WS, int NW, int SCH>
 __global__ __launch_bounds__(64 * NW) void conv_fwd_sp_kernel(ConvArgs a) {
-    using S = sp::Scheme<NP>;
-    static_assert(WS || NP == 3, "in-kernel weight split exists for the bf16 scheme only");
+    using S = sp::Scheme<SCH>;
+    constexpr int NP = S::NPL;                 // operand planes of the scheme
+    static_assert(WS || SCH == 3, "in-kernel weight split exists for the bf16x3 scheme only");
     constexpr int BN = 128, WTM = (NW == 4 ? 64 : 32), WTN = 64, MI = WTM / 32, NI = 2;
     constexpr int R = 8 / NW;                      // staged rows per thread and operand (128 rows x 4 quads / threads)
     constexpr int RSTEP = 16 * NW;                 // row distance between a thread's staged rows
@@ -215,9 +216,10 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_sp_kernel(ConvArgs a) {
 // Preconditions as conv_wgrad_buf_kernel (plain gather, stride 1, Wout % 16 == 0, channels % 4 == 0), 128x128 tiles.
 // UPS: the conv input is the nearest-x2 upsampling of x (Upsample, models/codec.py:17) -- source pixel = virtual >> 1
 // ---------------------------------------------------------------------------------------------------------------
-template <int XFORM, bool UPS, int NP>
+template <int XFORM, bool UPS, int SCH>
 __global__ __launch_bounds__(256) void conv_wgrad_sp_kernel(WgradArgs a) {
-    using S = sp::Scheme<NP>;
+    using S = sp::Scheme<SCH>;
+    constexpr int NP = S::NPL;                 // operand planes of the scheme
     constexpr int BCO = 128, BCI = 128, BKP = 16, MI = 2, NI = 2;
     constexpr int OPB = NP * sp::PLB;          // bytes per operand buffer
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * OPB];
@@ -373,14 +375,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_sp_kernel(WgradArgs a) {
 
 // ---- weight pre-split ---------------------------------------------------------------------------------------------------
 // out: WREC-byte records {plane0[4], plane1[4] (, plane2[4])} per 4 consecutive floats of `in` (n % 4 == 0)
-template <int NP>
+template <int SCH>
 __global__ __launch_bounds__(256) void split_w_kernel(const float4* __restrict__ in, unsigned* __restrict__ out, size_t n4,
                                                       const float* __restrict__ amax, float* __restrict__ hdr_out = nullptr) {
-    const float Sw = sp::Scheme<NP>::SCALED ? sp::pow2_scale(amax) : 1.f;
+    constexpr int NP = sp::Scheme<SCH>::NPL;
+    const float Sw = sp::Scheme<SCH>::SCALED ? sp::pow2_scale(amax) : 1.f;
     if (hdr_out && blockIdx.x == 0 && threadIdx.x == 0) *hdr_out = *amax;      // a maximum supplied by the caller goes into the header
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         uint2 p[NP];
-        sp::Scheme<NP>::split4(in[i], Sw, p);
+        sp::Scheme<SCH>::split4(in[i], Sw, p);
         unsigned* o = out + i * (2 * NP);
 #pragma unroll
         for (int k = 0; k < NP; ++k) { o[2 * k] = p[k].x; o[2 * k + 1] = p[k].y; }
@@ -399,13 +402,14 @@ __global__ __launch_bounds__(256) void split_w_kernel(const float4* __restrict__
 // ---------------------------------------------------------------------------------------------------------------
 // PL: also store the staged operand planes (ConvArgs::planes_out).  GB: GroupNorm-backward partial sums in the epilogue (gb_*)
 // SE: per-tile (sum y, sum y^2) of the output in the epilogue (gs_part): pass 1 of the GroupNorm that consumes this conv's output
-template <int XFORM, int NP, int KS = 3, bool PL = false, bool GB = false, bool SE = false>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6 : 4, 8))) void conv3x3_halo_sp_kernel(ConvArgs a) {
-    static_assert(!PL || (NP == 2 && KS == 3), "operand planes: dense 3x3 conv with two fp16 planes");
+template <int XFORM, int SCH, int KS = 3, bool PL = false, bool GB = false, bool SE = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 6 : 4, 8))) void conv3x3_halo_sp_kernel(ConvArgs a) {
+    static_assert(!PL || (SCH == 2 && KS == 3), "operand planes: dense 3x3 conv with two fp16 planes");
     static_assert(!GB || (XFORM == 0 && KS == 3 && !PL), "GroupNorm-backward sums: plain dense 3x3 data gradient");
-    static_assert(!SE || (KS == 3 && !PL && !GB && NP <= 2), "output statistics: dense 3x3 forward conv, fp16 planes");
-    static_assert(!GB || NP <= 2, "GroupNorm-backward sums: fp16 planes");
-    using S = sp::Scheme<NP>;
+    static_assert(!SE || (KS == 3 && !PL && !GB && SCH != 3), "output statistics: dense 3x3 forward conv, one or two planes");
+    static_assert(!GB || SCH != 3, "GroupNorm-backward sums: one or two planes");
+    using S = sp::Scheme<SCH>;
+    constexpr int NP = S::NPL;                 // operand planes of the scheme
     // KS = 3: the 3x3 stride-1 pad-1 conv.  KS = 2: a 2x2 phase conv of an Upsample / of the Downsample data gradient (top / left
     // padding a.pad / a.pad_w in {0, 1}, ONE side of the conv on every second pixel of a tensor of twice the size: a.in_* / a.out_*).
     constexpr int TH = 8, TW = 16, HW = TW + KS - 1, HROWS = (TH + KS - 1) * HW, TAPS = KS * KS;   // 3x3: 180 halo pixels
@@ -638,9 +642,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP <= 2 ? 6
 // LDS stores per MFMA than the tap-per-workgroup conv_wgrad_sp_kernel.  8 waves (4 co x 2 ci, 32 x 64 each, 3 taps).
 // Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, Wout % 16 == 0, channels % 4 == 0, operands < 2 GiB.
 // ---------------------------------------------------------------------------------------------------------------
-template <int XFORM, int NP, int PRE = 0>
+template <int XFORM, int SCH, int PRE = 0>
 __global__ __launch_bounds__(512) void conv_wgrad_row3_sp_kernel(WgradArgs a) {
-    using S = sp::Scheme<NP>;
+    using S = sp::Scheme<SCH>;
+    constexpr int NP = S::NPL;                 // operand planes of the scheme
     constexpr int OPL = 16 * sp::RSB, IPL = 18 * sp::RSB;           // bytes per plane (dy: 16 px, x: 18 px)
     constexpr int OB = NP * OPL, IB = NP * IPL;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (OB + IB)];
@@ -710,7 +715,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_sp_kernel(WgradArgs a) {
     };
     auto store_tiles = [&](int buf) {
         uint2 p[NP];
-        if constexpr ((PRE & 1) && NP == 2) {     // {hi[4], lo[4]} record -> the two planes
+        if constexpr ((PRE & 1) && SCH == 2) {     // {hi[4], lo[4]} record -> the two planes
             p[0] = make_uint2(__float_as_uint(ro.x), __float_as_uint(ro.y));
             p[1] = make_uint2(__float_as_uint(ro.z), __float_as_uint(ro.w));
         } else S::split4(ro, So, p);
@@ -718,7 +723,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_row3_sp_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && !two) continue;
-            if constexpr ((PRE & 2) && NP == 2) {
+            if constexpr ((PRE & 2) && SCH == 2) {
                 p[0] = make_uint2(__float_as_uint(ri[j].x), __float_as_uint(ri[j].y));
                 p[1] = make_uint2(__float_as_uint(ri[j].z), __float_as_uint(ri[j].w));
             } else S::split4(xform4_t<XFORM>(ri[j], rsc[j], rsh[j], a.act), Si, p);
@@ -813,9 +818,10 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 }  // namespace sp
-template <int XFORM, int NP, int BCO = 128, bool CAP1 = false, int PF = 2>
+template <int XFORM, int SCH, int BCO = 128, bool CAP1 = false, int PF = 2>
 __global__ __launch_bounds__(BCO * 4) void conv_wgrad_nine_sp_kernel(WgradArgs a) {
-    using S = sp::Scheme<NP>;
+    using S = sp::Scheme<SCH>;
+    constexpr int NP = S::NPL;                 // operand planes of the scheme
     static_assert(PF >= 1 && PF <= 3, "prefetch distance in steps");
     constexpr int T = BCO * 4;                                       // threads
     constexpr int OPITCH = BCO == 128 ? sp::RSB : sp::XPITCH;        // bytes per pixel of a dy plane

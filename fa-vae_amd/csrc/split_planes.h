@@ -29,6 +29,7 @@ __device__ __forceinline__ float pow2_inv(float S) {
 template <int NP> struct Scheme;
 
 template <> struct Scheme<3> {
+    static constexpr int NPL = 3;          // operand planes
     static constexpr bool SCALED = false;  // bf16 keeps the fp32 exponent: no operand ranges needed
     static constexpr int ROWB = 112;       // LDS row: 3 planes x 32 B (16 k) + 16 B pad -> conflict-free ds_read_b128
     static constexpr int WREC = 24;        // bytes per pre-split 4-float weight record {plane0[4], plane1[4], plane2[4]}
@@ -61,6 +62,7 @@ template <> struct Scheme<3> {
 };
 
 template <> struct Scheme<2> {
+    static constexpr int NPL = 2;
     static constexpr bool SCALED = true;
     static constexpr int ROWB = 80;        // 2 planes x 32 B + 16 B pad (20-bank row stride: conflict-free ds_read_b128)
     static constexpr int WREC = 16;        // {plane0[4 fp16], plane1[4]}
@@ -89,6 +91,7 @@ template <> struct Scheme<2> {
 // significand, fp32 accumulation; BASELINE config 5 asks for 16-bit compute).  Same power-of-two scaling as h3, so the fp16
 // exponent range is never the limit.  NOT fp32-grade: per-product relative error ~2^-12 (FAVAE_CONV_MODE=h1 / favae_set_conv_mode(1)).
 template <> struct Scheme<1> {
+    static constexpr int NPL = 1;
     static constexpr bool SCALED = true;
     static constexpr int ROWB = 48;        // 32 B + 16 B pad (12-bank row stride: 16 consecutive rows hit 16 distinct bank quads)
     static constexpr int WREC = 8;         // {plane0[4 fp16]}
@@ -98,6 +101,28 @@ template <> struct Scheme<1> {
     }
     static __device__ __forceinline__ void mma(const bf16x8_t (&a)[1], const bf16x8_t (&b)[1], f32x16& c) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a[0]), __builtin_bit_cast(half8_t, b[0]), c, 0, 0, 0);
+    }
+};
+
+// "b1": ONE bf16 plane (round to nearest even), one MFMA per product block -- the bf16 mixed-precision mode BASELINE configs[4] names
+// (what `accelerate --mixed_precision bf16` gives the reference's convs: bf16 operands, fp32 accumulation).  bf16 carries the fp32
+// exponent: no operand ranges, no scaling.  8-bit significand: per-product relative error ~2^-9 (h1's fp16 plane: ~2^-12).
+// Scheme id 4 (FAVAE_CONV_MODE=b1 / favae_set_conv_mode(4)); one plane: NPL = 1.
+template <> struct Scheme<4> {
+    static constexpr int NPL = 1;
+    static constexpr bool SCALED = false;
+    static constexpr int ROWB = 48;        // as Scheme<1>
+    static constexpr int WREC = 8;         // {plane0[4 bf16]}
+    static __device__ __forceinline__ unsigned rne_hi(float f) {             // fp32 -> bf16 bits in the upper half, round to nearest even
+        const unsigned u = __float_as_uint(f);
+        return (u & 0x7F800000u) == 0x7F800000u ? u : u + 0x7FFFu + ((u >> 16) & 1u);   // inf / nan pass through
+    }
+    static __device__ __forceinline__ void split4(const float4 v, float, uint2 (&p)[1]) {
+        const unsigned a = rne_hi(v.x), b = rne_hi(v.y), c = rne_hi(v.z), d = rne_hi(v.w);
+        p[0] = make_uint2(__builtin_amdgcn_perm(b, a, 0x07060302u), __builtin_amdgcn_perm(d, c, 0x07060302u));
+    }
+    static __device__ __forceinline__ void mma(const bf16x8_t (&a)[1], const bf16x8_t (&b)[1], f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
     }
 };
 

@@ -220,15 +220,16 @@ def _fp16_planes():
     return _FP16_PLANES
 
 
-_WREC = {1: 8, 2: 16, 3: 24}          # bytes of one pre-split record (4 weights) per plane count
-CONV_MODES = {"fp32": 0, "h1": 1, "h3": 2, "b6": 3}
+_WREC = {1: 8, 2: 16, 3: 24, 4: 8}    # bytes of one pre-split record (4 weights) per scheme id
+CONV_MODES = {"fp32": 0, "h1": 1, "h3": 2, "b6": 3, "b1": 4}
 
 
 def set_conv_mode(mode):
     """Select the conv arithmetic at run time (same meaning as FAVAE_CONV_MODE): "h3" (default, fp32-grade, two scaled fp16
-    planes), "b6" (fp32-grade, three bf16 planes), "fp32" (fp32-MFMA kernels) or "h1" -- ONE scaled fp16 plane with fp32
-    accumulation: the 16-bit mixed-precision mode (what `accelerate --mixed_precision` gives the reference's convs), not
-    fp32-grade.  Returns the previous mode name."""
+    planes), "b6" (fp32-grade, three bf16 planes), "fp32" (fp32-MFMA kernels), "h1" -- ONE scaled fp16 plane with fp32
+    accumulation -- or "b1" -- ONE bf16 plane (round to nearest even) with fp32 accumulation: the 16-bit mixed-precision modes
+    (b1 is what `accelerate --mixed_precision bf16` gives the reference's convs, BASELINE configs[4]; h1 keeps three more
+    significand bits), not fp32-grade.  Returns the previous mode name."""
     global _FP16_PLANES
     prev = query("favae_get_conv_mode")
     _chk_mode = CONV_MODES[mode]
@@ -486,7 +487,7 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
     planes = query("favae_conv_wants_split_weights", byref(d), 0 if scale is None else 1)
     w_amax = None
     if planes:
-        if flip_of is not None and (planes == 3 or flip_of[5] is not None) and os.environ.get("FAVAE_FLIP_SPLIT", "1") != "0":
+        if flip_of is not None and (planes in (3, 4) or flip_of[5] is not None) and os.environ.get("FAVAE_FLIP_SPLIT", "1") != "0":
             w, co, kh, kw, ci, w_amax = flip_of
             n = w.numel()
             wsp = torch.empty(query("favae_split_weights_bytes", n, planes), dtype=torch.uint8, device=w.device)
@@ -679,7 +680,7 @@ class FusedConvFn(torch.autograd.Function):
                 # Downsample: data gradient by output parity (favae_downsample_dgrad_weights) instead of a zero-dilated input
                 d00 = make_conv_desc(N, Ho, Wo, Cout, Ho, Wo, Cin, 2, 2, 1, 1, GATHER_PLAIN, ACT_NONE, 1, lattice=(2, 1, 0, 0))
                 planes = query("favae_conv_wants_split_weights", byref(d00), 0)
-                if planes == 3 or (planes in (1, 2) and w_amax is not None):
+                if planes in (3, 4) or (planes in (1, 2) and w_amax is not None):
                     phased = planes
             if phased:
                 planes = phased
@@ -711,7 +712,7 @@ class FusedConvFn(torch.autograd.Function):
                     dys = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=dev)
                 gnb = None
                 if (_GNBWD_FUSE and has_gn and cfg.norm == "group" and not cfg.upsample and dys is None and mean is not None
-                        and dyb is not None):
+                        and (dyb is not None or not _fp16_planes())):
                     gn_tiles = query("favae_conv_gnbwd_tiles", byref(d2))
                     if gn_tiles:
                         gn_ws = workspace(query("favae_gn_bwd_tiles_workspace", N, gn_tiles, Cin), dev)

@@ -92,8 +92,11 @@ int favae_conv_fwd(const favae_conv_desc* d, const float* x, const float* w, con
  * planes == 1 ("h1") is the 16-bit mixed-precision mode: ONE scaled fp16 plane per operand (11-bit significand), fp32
  * accumulation, same range arguments as planes == 2 -- what `accelerate launch --mixed_precision fp16|bf16` turns the reference's
  * F.conv2d calls into (favae_scripts/train_favae.py:240 builds the Accelerator; BASELINE config 5).  Not fp32-grade.
- * favae_set_conv_mode(planes) selects the scheme for subsequent calls (0 = fp32-MFMA kernels, 1, 2 = default, 3); it overrides
- * the FAVAE_CONV_MODE environment variable (fp32 | h1 | h3 | b6) read on first use.  Process-wide, not thread-safe against
+ * planes == 4 ("b1") is the bf16 form of it: ONE bf16 plane per operand (round to nearest even, 8-bit significand, the fp32
+ * exponent: no range arguments, x_absmax may be NULL), v_mfma_f32_32x32x16_bf16, fp32 accumulation -- the arithmetic BASELINE
+ * configs[4] names ("bf16").  4 is a scheme id, not a plane count: records are 8 bytes per 4 weights as for planes == 1.
+ * favae_set_conv_mode(planes) selects the scheme for subsequent calls (0 = fp32-MFMA kernels, 1, 2 = default, 3, 4); it overrides
+ * the FAVAE_CONV_MODE environment variable (fp32 | h1 | h3 | b6 | b1) read on first use.  Process-wide, not thread-safe against
  * concurrent launches. */
 int favae_set_conv_mode(int planes);
 int favae_get_conv_mode(void);

@@ -517,11 +517,13 @@ def test_train_step_is_deterministic():
     assert torch.equal(e1, e2)
 
 
-def test_mixed_precision_step_tracks_fp32_grade_step():
-    """16-bit mixed-precision mode (ops.set_conv_mode("h1"): conv operands in one scaled fp16 plane, fp32 accumulation --
-    BASELINE configs[4] "bf16").  Not a parity mode: the bar is that one full training step (forward, every loss, backward,
-    Adam) stays within fp16-operand tolerance of the default fp32-grade step on identical state and input, and that it is
-    not bit-identical to it (the h1 kernels ran)."""
+@pytest.mark.parametrize("mode,tol_x,tol_l", [("h1", 3e-2, 2e-2), ("b1", 1e-1, 5e-2)])
+def test_mixed_precision_step_tracks_fp32_grade_step(mode, tol_x, tol_l):
+    """16-bit mixed-precision modes: ops.set_conv_mode("h1") = conv operands in one scaled fp16 plane, "b1" = in one bf16 plane
+    (BASELINE configs[4] "bf16"), fp32 accumulation either way.  Not parity modes: the bar is that one full training step (forward,
+    every loss, backward, Adam) stays within 16-bit-operand tolerance of the default fp32-grade step on identical state and input
+    (bf16 has three significand bits less than the fp16 plane: with it a few tokens pick another code, so its reconstruction is
+    held to an rms bar instead of a per-pixel one), and that it is not bit-identical to it (the one-plane kernels ran)."""
     from models.vqgan_fcm import VQGANFCM
     from favae_step import TrainStep
     from favae_hip import ops as K
@@ -540,12 +542,19 @@ def test_mixed_precision_step_tracks_fp32_grade_step():
         finally:
             K.set_conv_mode(prev)
 
-    a, b = run("h3"), run("h1")
+    a, b = run("h3"), run(mode)
     assert K.get_conv_mode() == "h3"
     assert not torch.equal(a["x_recon"], b["x_recon"])
-    close(b["x_recon"], a["x_recon"], 3e-2, "x_recon h1 vs h3")
+    print("\n%s vs h3: x_recon %.3e" % (mode, float((b["x_recon"] - a["x_recon"]).abs().max() / a["x_recon"].abs().max())),
+          {k: "%.3e" % float((b[k] - a[k]).abs().max() / a[k].abs().max()) for k in ("loss_l1", "loss_ffl", "loss_dsl", "loss_g")})
+    if mode == "h1":
+        close(b["x_recon"], a["x_recon"], tol_x, "x_recon %s vs h3" % mode)
+    else:
+        rms = float(((b["x_recon"] - a["x_recon"]).pow(2).mean() / a["x_recon"].pow(2).mean()).sqrt())
+        print("x_recon rms-rel %.3e" % rms)
+        assert rms < tol_x, rms
     for k in ("loss_l1", "loss_ffl", "loss_dsl", "loss_g"):
-        close(b[k], a[k], 2e-2, k + " h1 vs h3")
+        close(b[k], a[k], tol_l, k + " %s vs h3" % mode)
     assert torch.isfinite(b["loss_quant"]).all()
 
 

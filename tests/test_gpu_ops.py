@@ -97,6 +97,21 @@ def test_conv_mixed_precision_h1(K, case):
     assert K.get_conv_mode() == prev
 
 
+@pytest.mark.parametrize("case", CONV_CASES[12:23], ids=[str(i) for i in range(12, 23)])
+def test_conv_mixed_precision_b1(K, case):
+    """bf16 mixed-precision mode (ops.set_conv_mode("b1"): one bf16 plane per operand, round to nearest even, fp32 accumulation --
+    the arithmetic BASELINE configs[4] names): every split-path kernel family within bf16-operand tolerance of the fp32 reference
+    (8-bit significand: eight times the bar of the fp16 plane), and measurably coarser than fp32-grade."""
+    prev = K.set_conv_mode("b1")
+    try:
+        assert K.get_conv_mode() == "b1"
+        errs = _conv_case(K, case, 800.0)
+        assert max(errs["y"], errs["dx"], errs["dw"]) > 2e-4, errs
+    finally:
+        K.set_conv_mode(prev)
+    assert K.get_conv_mode() == prev
+
+
 def _conv_case(K, case, tol_scale):
     N, Cin, H, W, Cout, k, s, p, pbr, up, groups, use_res = case
     x = rnd((N, Cin, H, W), 1).requires_grad_(True)
