@@ -349,25 +349,44 @@ __global__ __launch_bounds__(256) void softmax_rows_lse_kernel(float* s, float* 
 //   s  <- p  = exp(s - lse)                              (the forward probabilities, recomputed)
 //   dp <- ds = alpha * p * (dp - delta),  delta = rowsum(dO * O)     (softmax backward with the 1/sqrt(C) of the scores folded in)
 // and max|ds| (bit-pattern atomicMax: order-independent) for the operand scaling of the GEMMs that consume ds.
+// One wave per row, rows strided over the grid; 16-byte accesses when L % 4 == 0 (VEC); ONE atomicMax per block (the round-2 version
+// issued one same-address atomic per row: 8192 of them serialised at ~10 ns each and held the pass at 4 % of the HBM rate).
+template <bool VEC>
 __global__ __launch_bounds__(256) void attn_bwd_point_kernel(float* s, float* dp, const float* lse, const float* delta, long rows,
                                                              int L, int rq, int r0, int Ltot, float alpha, unsigned* ds_amax) {
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const long qi = (row / rq) * (long)Ltot + r0 + (row % rq);
-    const float l = lse[qi], dl = delta[qi];
-    float* sr = s + row * L;
-    float* dr = dp + row * L;
     float mx = 0.f;
-    for (int i = lane; i < L; i += 64) {
-        const float p = expf(sr[i] - l);
-        const float ds = alpha * p * (dr[i] - dl);
-        sr[i] = p;
-        dr[i] = ds;
-        mx = fmaxf(mx, fabsf(ds));
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+        const long qi = (row / rq) * (long)Ltot + r0 + (row % rq);
+        const float l = lse[qi], dl = delta[qi];
+        float* sr = s + row * L;
+        float* dr = dp + row * L;
+        if constexpr (VEC) {
+            for (int i = lane * 4; i < L; i += 256) {
+                const float4 sv = *reinterpret_cast<const float4*>(sr + i), dv = *reinterpret_cast<const float4*>(dr + i);
+                float4 p, ds;
+                p.x = expf(sv.x - l); p.y = expf(sv.y - l); p.z = expf(sv.z - l); p.w = expf(sv.w - l);
+                ds.x = alpha * p.x * (dv.x - dl); ds.y = alpha * p.y * (dv.y - dl);
+                ds.z = alpha * p.z * (dv.z - dl); ds.w = alpha * p.w * (dv.w - dl);
+                *reinterpret_cast<float4*>(sr + i) = p;
+                *reinterpret_cast<float4*>(dr + i) = ds;
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(ds.x), fabsf(ds.y))), fmaxf(fabsf(ds.z), fabsf(ds.w)));
+            }
+        } else {
+            for (int i = lane; i < L; i += 64) {
+                const float p = expf(sr[i] - l);
+                const float ds = alpha * p * (dr[i] - dl);
+                sr[i] = p;
+                dr[i] = ds;
+                mx = fmaxf(mx, fabsf(ds));
+            }
+        }
     }
     mx = wave_max(mx);
-    if (lane == 0) atomicMax(ds_amax, __float_as_uint(mx));
+    __shared__ float wm[4];
+    if (lane == 0) wm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(ds_amax, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 
 // out[row] = sum_c a[row][c] * b[row][c]   (delta = rowsum(dO * O)); one wave per row
@@ -460,8 +479,14 @@ extern "C" int favae_attn_bwd_point(float* s, float* dp, const float* lse, const
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(ds_absmax, 0, sizeof(float), st) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     FAVAE_PROF_NOTE(0, 16.0 * rows * L);
-    FAVAE_KLAUNCH(attn_bwd_point_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, s, dp, lse, delta, (long)rows, L, rows_per_batch,
-                  row0, Ltot, alpha, (unsigned*)ds_absmax);
+    long blocks = cdiv(rows, 4);
+    if (blocks > 2048) blocks = 2048;
+    if (L % 4 == 0 && aligned16(s) && aligned16(dp))
+        FAVAE_KLAUNCH((attn_bwd_point_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, s, dp, lse, delta, (long)rows, L,
+                      rows_per_batch, row0, Ltot, alpha, (unsigned*)ds_absmax);
+    else
+        FAVAE_KLAUNCH((attn_bwd_point_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, s, dp, lse, delta, (long)rows, L,
+                      rows_per_batch, row0, Ltot, alpha, (unsigned*)ds_absmax);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
