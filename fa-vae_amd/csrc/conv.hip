@@ -1317,8 +1317,10 @@ static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float
     const size_t ab = (size_t)(d->affine_per_image ? d->N : 1) * d->Cin * 4;
     const int xf = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_NONE ? 1 : 3)) : 0;
     const bool ups_b6 = d->gather == FAVAE_GATHER_UPSAMPLE2 && xf == 0 && use_b6() && bco == 128 && bci == 128;
+    // stride 2 (Downsample): only the per-tap split-precision kernel implements it
+    const bool s2_sp = d->stride == 2 && use_b6() && bco == 128 && bci == 128 && d->gather == FAVAE_GATHER_PLAIN && !special;
     const bool buf_ok = !force_generic() && !force_nobuf() && a.vec_i && a.vec_o && (d->gather == FAVAE_GATHER_PLAIN || ups_b6) &&
-                        d->stride == 1 && d->Wout % 16 == 0 && xb < (1u << 31) && yb < (1u << 31) && xf != 3;
+                        (d->stride == 1 || s2_sp) && d->Wout % 16 == 0 && xb < (1u << 31) && yb < (1u << 31) && xf != 3;
     a.x_bytes = (unsigned)xb; a.aff_bytes = (unsigned)ab;
     if (special && !(buf_ok && use_b6() && bco == 128 && bci == 128 && d->gather == FAVAE_GATHER_PLAIN &&
                      (size_t)d->N * a.dy_img * d->Cout * 4 < ((size_t)1 << 32)))
@@ -1330,7 +1332,7 @@ static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float
         else FAVAE_KLAUNCH((conv_wgrad_buf_kernel<128, 32, 4, 1, X>), grid, dim3(256), 0, s, a);                           \
     } while (0)
     const bool row3 = !special && buf_ok && use_b6() && use_row3() && bco == 128 && bci == 128 && d->gather == FAVAE_GATHER_PLAIN &&
-                      d->KH == 3 && d->KW == 3 && d->pad == 1;
+                      d->KH == 3 && d->KW == 3 && d->pad == 1 && d->stride == 1;
     const bool nine = row3 && use_nine() && !x_planes && !dy_planes && d->Hout == d->Hin && d->Wout == d->Win;
     if (nine) {
         // all nine taps per workgroup (BCO co x 64 ci), split-K over whole 16-pixel column strips

@@ -213,7 +213,8 @@ __global__ __launch_bounds__(64 * NW) void conv_fwd_sp_kernel(ConvArgs a) {
 // 4 consecutive channels of pixel row (s>>2), and lane c receives element (c&3) of the chunks of lanes
 // {c>>2, 4+(c>>2), 8+(c>>2), 12+(c>>2)}  (probed on hardware, tools/experiments/tr_b16.hip).
 // Pixel rows are padded to 320 B so that the 4 rows x 2 channel blocks a 32-lane half touches fall on different banks.
-// Preconditions as conv_wgrad_buf_kernel (plain gather, stride 1, Wout % 16 == 0, channels % 4 == 0), 128x128 tiles.
+// Preconditions as conv_wgrad_buf_kernel (plain gather, Wout % 16 == 0, channels % 4 == 0), 128x128 tiles; stride 1 or 2 (round 3:
+// the stride-2 Downsample convs, models/codec.py:26-29, ran their weight gradient on the fp32-MFMA kernel at 72 TFLOP/s).
 // UPS: the conv input is the nearest-x2 upsampling of x (Upsample, models/codec.py:17) -- source pixel = virtual >> 1
 // ---------------------------------------------------------------------------------------------------------------
 template <int XFORM, bool UPS, int SCH>
@@ -280,14 +281,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_sp_kernel(WgradArgs a) {
                                 : (unsigned)(s_n * a.dy_img + s_oh * a.dy_step * a.dy_row + s_ow * a.dy_step + a.dy_off) * (unsigned)a.Cout * 4u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) ro[j] = bload(rdy, voo[j], so);
-        const int vh = s_oh + kh - a.pad;
+        const int vh = s_oh * a.stride + kh - a.pad;               // stride 2: the Downsample conv (pad 0, zeros beyond the far edge)
         const bool row_ok = (unsigned)vh < (unsigned)(UPS ? 2 * a.Hin : a.Hin);
         const int ih = UPS ? vh >> 1 : vh;
         const unsigned sx = row_ok ? (unsigned)(((s_n * a.Hin + ih) * a.Win) * a.Cin) * 4u : 0u;
         const unsigned ss = (unsigned)(s_n * a.aff_stride) * 4u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int vw = s_ow + s_p[j] + kw - a.pad_w;
+            const int vw = (s_ow + s_p[j]) * a.stride + kw - a.pad_w;
             const int iw = UPS ? vw >> 1 : vw;
             const bool ok = row_ok && i_ok[j] && (unsigned)vw < (unsigned)(UPS ? 2 * a.Win : a.Win) && ld_pb + s_p[j] < p_end;
             const unsigned vx = ok ? (unsigned)((iw * a.Cin + ci0 + s_c[j]) * 4) : FAVAE_OOB;

@@ -271,6 +271,7 @@ _SIDE = {"stream": None, "used": False, "on": os.environ.get("FAVAE_WGRAD_STREAM
 # every weight gradient reduces its own slabs (A/B switch; the sums are taken in the same order: bit-identical).
 _DEFER_REDUCE = os.environ.get("FAVAE_DEFER_REDUCE", "1") != "0"
 _FLUSH_EVERY = int(os.environ.get("FAVAE_FLUSH_EVERY", "12"))
+_SERIALIZE_MFMA = os.environ.get("FAVAE_SERIALIZE_MFMA", "0") == "1"
 
 
 def _side_stream():
@@ -717,6 +718,9 @@ class FusedConvFn(torch.autograd.Function):
                     if gn_tiles:
                         gn_ws = workspace(query("favae_gn_bwd_tiles_workspace", N, gn_tiles, Cin), dev)
                         gnb = (x, mean, rstd, gn_w, gn_b, cfg.groups, act, gn_ws)
+                if _SERIALIZE_MFMA and gn_tiles and _SIDE["used"]:
+                    # experiment: the dense data gradient starts only after the weight gradient of the layer behind it has retired
+                    torch.cuda.current_stream().wait_stream(_SIDE["stream"])
                 _conv_launch(d2, dy, None, None, None, None, None, da, dyb, flip_of=(wk, Cout, cfg.kh, cfg.kw, Cin, w_amax),
                              planes_out=dys, gnbwd=gnb)
             if run_wgrad is not None:
