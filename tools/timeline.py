@@ -91,3 +91,36 @@ if steps:
         agg[(ka, kb)][1] += g / 1e3
     for (ka, kb), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
         print(f"  {us:9.1f} us in {n:4d} gaps   after {ka[:44]:44s} before {kb[:44]}")
+
+# phases of the last two-stream step on the main queue: forward | backward before the first dense 3x3 data gradient | the conv chain
+# (first .. last dense data gradient) | tail; per phase the wall time and the main-queue time by kernel
+if steps:
+    st = steps[min(len(steps) - 1, 2)] if len(steps) < 4 else steps[-3]
+    mainq = max(set(r[3] for r in st), key=lambda q: sum(1 for r in st if r[3] == q))
+    rows_q = sorted([r for r in st if r[3] == mainq], key=lambda r: r[1])
+    names = [short(r[0]) for r in rows_q]
+    def first(pred, default=None):
+        for i, n in enumerate(names):
+            if pred(n):
+                return i
+        return default
+    bwd0 = first(lambda n: n.startswith(("absdiff_bwd", "diff_bwd", "fft_lines_kernel<2", "blur9_stream_kernel<1", "sqdiff_bwd")), len(names) - 1)
+    is_dg = lambda n: n.startswith("conv3x3_halo_sp_kernel<0") and "true, false>" in n
+    dg = [i for i, n in enumerate(names) if is_dg(n)]
+    cuts = [0, bwd0, dg[0] if dg else bwd0, dg[-1] + 1 if dg else bwd0, len(names)]
+    labels = ["forward", "backward head (losses, blur / FFT backward, decoder tail)", "conv chain (first..last dense data gradient)", "backward tail + Adam"]
+    print("\nphases of the main queue (last two-stream step):")
+    for (a, b), lab in zip(zip(cuts[:-1], cuts[1:]), labels):
+        if b <= a:
+            continue
+        seg = rows_q[a:b]
+        wall = (seg[-1][2] - seg[0][1]) / 1e6
+        by = defaultdict(float)
+        for r in seg:
+            by[short(r[0])[:48]] += (r[2] - r[1]) / 1e6
+        top = sorted(by.items(), key=lambda kv: -kv[1])[:(40 if lab == "forward" else 12)]
+        print(f"  {lab}: wall {wall:.2f} ms, kernels {sum(by.values()):.2f} ms, n={len(seg)}")
+        cnt = defaultdict(int)
+        for r in seg:
+            cnt[short(r[0])[:48]] += 1
+        print("      " + "; ".join(f"{k} {v:.2f} (n={cnt[k]})" for k, v in top))
