@@ -28,6 +28,7 @@ struct BlurArgs {
     float* y;         // forward output
     float* dx;        // backward: may be null
     float* part;      // backward: [blocks][2k] partials of dg, may be null
+    const float* dx_add;  // backward: optional tensor added to dx (the other gradient of the blurred tensor's source)
     int N, H, W, C, k, TH, TW, CC, tiles_h, tiles_w, cchunks;
 };
 
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(256) void blur_sep_kernel(BlurArgs a) {
     }
     if (a.dx && c_ok) {
         float* out = a.dx + (size_t)n * a.H * a.W * a.C;
+        const float* add = a.dx_add ? a.dx_add + (size_t)n * a.H * a.W * a.C : nullptr;
         for (int q = pl; q < npix; q += PL) {
             const int py = q / a.TW, px = q - py * a.TW;
             const int y = y0 + py, x = x0 + px;
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(256) void blur_sep_kernel(BlurArgs a) {
                 const float* row = V + (py * HW + px + 2 * p) * CC + c;
 #pragma unroll
                 for (int v = 0; v < k; ++v) acc = fmaf(g[v], row[-v * CC], acc);
+                if (add) acc += add[((size_t)y * a.W + x) * a.C + c0 + c];
                 out[((size_t)y * a.W + x) * a.C + c0 + c] = acc;
                 continue;
             }
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(256) void blur_sep_kernel(BlurArgs a) {
                     if (rx < 0 || rx >= a.W || hx < 0 || hx >= HW) continue;
                     acc = fmaf(g[v], V[(py * HW + hx) * CC + c], acc);
                 }
+            if (add) acc += add[((size_t)y * a.W + x) * a.C + c0 + c];
             out[((size_t)y * a.W + x) * a.C + c0 + c] = acc;
         }
     }
@@ -329,15 +333,31 @@ extern "C" size_t favae_blur_bwd_workspace(int ksize, int N, int H, int W, int C
     return blocks * ksize * sizeof(float) + favae_colsum_workspace((int64_t)blocks, ksize) + MAXK * sizeof(float) + 512;
 }
 
+static int blur_bwd_impl(const float* x, const float* dy, const float* sigma, int ksize, int N, int H, int W, int C, const float* dx_add,
+                         float* dx, float* dsigma, void* ws, size_t ws_bytes, favae_stream_t stream);
+
 extern "C" int favae_blur_bwd(const float* x, const float* dy, const float* sigma, int ksize, int N, int H, int W, int C,
                               float* dx, float* dsigma, void* ws, size_t ws_bytes, favae_stream_t stream) {
+    return blur_bwd_impl(x, dy, sigma, ksize, N, H, W, C, nullptr, dx, dsigma, ws, ws_bytes, stream);
+}
+
+// favae_blur_bwd with dx = (adjoint blur of dy) + dx_add: the blurred tensor's source usually has a second consumer (the trunk of the
+// codec, models/codec.py:209-215), whose gradient autograd would add with one more pass over both tensors
+extern "C" int favae_blur_bwd_add(const float* x, const float* dy, const float* sigma, int ksize, int N, int H, int W, int C,
+                                  const float* dx_add, float* dx, float* dsigma, void* ws, size_t ws_bytes, favae_stream_t stream) {
+    FAVAE_REQUIRE(dx_add && dx);
+    return blur_bwd_impl(x, dy, sigma, ksize, N, H, W, C, dx_add, dx, dsigma, ws, ws_bytes, stream);
+}
+
+static int blur_bwd_impl(const float* x, const float* dy, const float* sigma, int ksize, int N, int H, int W, int C, const float* dx_add,
+                         float* dx, float* dsigma, void* ws, size_t ws_bytes, favae_stream_t stream) {
     FAVAE_REQUIRE(x && dy && sigma && ws && blur_ok(ksize, N, H, W, C));
     FAVAE_REQUIRE(dx || dsigma);
     BlurArgs a{};
     if (!plan(ksize, N, H, W, C, true, a)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (ws_bytes < favae_blur_bwd_workspace(ksize, N, H, W, C)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     StreamArgs sa{};
-    bool stream_path = stream_ok(ksize, N, H, W, C) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+    bool stream_path = stream_ok(ksize, N, H, W, C) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dx_add) & 15) == 0;
     long grid = (long)N * a.tiles_h * a.tiles_w * a.cchunks;
     if (stream_path) {
         stream_plan(N, H, W, C, sa);
@@ -351,7 +371,7 @@ extern "C" int favae_blur_bwd(const float* x, const float* dy, const float* sigm
     const size_t cws = favae_colsum_workspace(grid, ksize);
     float* dgv = (float*)(p2 + ((cws + 255) / 256) * 256);
     if ((char*)(dgv + ksize) > (char*)ws + ws_bytes) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
-    a.x = x; a.dy = dy; a.sigma = sigma; a.dx = dx; a.part = dsigma ? part : nullptr;
+    a.x = x; a.dy = dy; a.sigma = sigma; a.dx = dx; a.part = dsigma ? part : nullptr; a.dx_add = dx_add;
     const size_t shm = shm_floats(a, true) * sizeof(float);
     static bool attr = false;
     if (!attr) {
@@ -363,9 +383,9 @@ extern "C" int favae_blur_bwd(const float* x, const float* dy, const float* sigm
     }
     hipStream_t s = (hipStream_t)stream;
     const dim3 g3((unsigned)grid), b3(256);
-    FAVAE_PROF_NOTE(0, 12.0 * N * H * W * C);                              // reads x and dy, writes dx
+    FAVAE_PROF_NOTE(0, (dx_add ? 16.0 : 12.0) * N * H * W * C);            // reads x and dy (+ dx_add), writes dx
     if (stream_path) {
-        sa.x = x; sa.dy = dy; sa.sigma = sigma; sa.dx = dx; sa.part = a.part;
+        sa.x = x; sa.dy = dy; sa.sigma = sigma; sa.dx = dx; sa.part = a.part; sa.dx_add = dx_add;
         FAVAE_KLAUNCH((blur9_stream_kernel<1, STREAM_COLS>), g3, dim3(STREAM_COLS * 8), 0, s, sa);
     } else if (ksize == 9) FAVAE_KLAUNCH((blur_sep_kernel<1, 9>), g3, b3, shm, s, a);
     else if (ksize == 5) FAVAE_KLAUNCH((blur_sep_kernel<1, 5>), g3, b3, shm, s, a);

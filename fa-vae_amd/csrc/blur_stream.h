@@ -25,6 +25,7 @@ struct StreamArgs {
     float* y;         // forward output
     float* dx;        // backward: may be null
     float* part;      // backward: [blocks][9] partials of dg, may be null
+    const float* dx_add;  // backward: optional tensor added to dx
     int N, H, W, C, RS, strips, segs, cchunks;
 };
 
@@ -172,7 +173,12 @@ __global__ __launch_bounds__(COLS * 8) void blur9_stream_kernel(StreamArgs a) {
                 float4 o = zero4;
 #pragma unroll
                 for (int t = 0; t < K; ++t) o = f4_fma(wcol[t], Vs[buf][tid + (t - P) * 8], o);
-                *reinterpret_cast<float4*>(a.dx + ((img + (size_t)yp * a.W + gj) * a.C + coff)) = o;
+                const size_t oo = (img + (size_t)yp * a.W + gj) * a.C + coff;
+                if (a.dx_add) {
+                    const float4 q = *reinterpret_cast<const float4*>(a.dx_add + oo);
+                    o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+                }
+                *reinterpret_cast<float4*>(a.dx + oo) = o;
             }
         }
     }

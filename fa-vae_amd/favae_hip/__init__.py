@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FAVAE_HIP_LIB") or os.path.join(_HERE, "libfavae_hip.so")     # FAVAE_HIP_LIB: same-box A/B of two builds
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02, ACT_RELU = 0, 1, 2, 3
@@ -71,6 +71,7 @@ SIGNATURES = {
     "favae_blur_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _S]),
     "favae_blur_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "favae_blur_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _S]),
+    "favae_blur_bwd_add": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _S]),
     "favae_ffl_spec_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "favae_ffl_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "favae_ffl_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_size_t, _S]),

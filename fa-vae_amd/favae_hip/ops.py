@@ -1338,6 +1338,53 @@ def gaussian_blur(x, sigmas, index, ksize):
     return BlurFn.apply(x, sigmas, index, ksize)
 
 
+_BLUR_TAP = os.environ.get("FAVAE_BLUR_TAP", "1") != "0"       # A/B switch of BlurTapFn (0: plain blur node + autograd's accumulation)
+
+
+class BlurTapFn(torch.autograd.Function):
+    """(x, blur(x)) for a tap of the codec trunk (models/codec.py:209-215: the tensor is blurred for the DSL and ALSO flows on through
+    the trunk).  The caller continues the trunk on the returned alias of x, so both gradients of x arrive in THIS node's backward and the
+    trunk gradient is added inside the blur-backward kernel's store (favae_blur_bwd_add) -- autograd otherwise sums the two
+    full-size gradient tensors with an ATen add kernel (1.3 ms per step on the 256x256 taps)."""
+
+    @staticmethod
+    def forward(ctx, x, sigmas, index, ksize):
+        x = to_cl(x)
+        _require_gpu(sigmas)
+        N, C, H, W = x.shape
+        y = new_cl(N, C, H, W, x.device)
+        call("favae_blur_fwd", ptr(x), sigmas.data_ptr() + 4 * index, ksize, N, H, W, C, ptr(y))
+        ctx.save_for_backward(x, sigmas)
+        ctx.index, ctx.ksize = index, ksize
+        return x, y
+
+    @staticmethod
+    def backward(ctx, gx, gy):
+        x, sigmas = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dev = x.device
+        need_x, need_s = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if gy is None:                                   # the tap was not used by any loss
+            return gx, None, None, None
+        gy = to_cl(gy)
+        gx = to_cl(gx) if gx is not None else None
+        dx = new_cl(N, C, H, W, dev) if need_x else None
+        ds = torch.zeros_like(sigmas) if need_s else None
+        ws = workspace(query("favae_blur_bwd_workspace", ctx.ksize, N, H, W, C), dev)
+        sp = sigmas.data_ptr() + 4 * ctx.index
+        dsp = (ds.data_ptr() + 4 * ctx.index) if need_s else None
+        if need_x and gx is not None:
+            call("favae_blur_bwd_add", ptr(x), ptr(gy), sp, ctx.ksize, N, H, W, C, ptr(gx), ptr(dx), dsp, ptr(ws), ws.numel())
+        else:
+            call("favae_blur_bwd", ptr(x), ptr(gy), sp, ctx.ksize, N, H, W, C, ptr(dx), dsp, ptr(ws), ws.numel())
+        return dx, ds, None, None
+
+
+def blur_tap(x, sigmas, index, ksize):
+    """-> (alias of x to continue the trunk on, blurred x)"""
+    return BlurTapFn.apply(x, sigmas, index, ksize)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # focal frequency loss (pip focal-frequency-loss 0.3.0 semantics, alpha = 1)
 # ---------------------------------------------------------------------------------------------------------------

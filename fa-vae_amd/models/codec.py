@@ -169,6 +169,18 @@ class _BlurMixin:
     def _gaussian_blur(self, x, i):
         return K.gaussian_blur(x, self.sigmas, i, self.kernel_size)
 
+    def _blur_tap(self, h, i):
+        """(tensor to continue the trunk on, blurred tap): the trunk continues on an alias of h handed out by the blur node, so the
+        trunk's gradient is added inside the blur-backward kernel (ops.BlurTapFn).  The tile statistics the producing conv left on h
+        (ops.gn_stats) stay valid for the alias: same memory, same version counter."""
+        if not (K._BLUR_TAP and torch.is_grad_enabled() and h.requires_grad):
+            return h, self._gaussian_blur(h, i)
+        st = getattr(h, "_favae_gnstats", None)
+        h2, f = K.blur_tap(h, self.sigmas, i, self.kernel_size)
+        if st is not None:
+            h2._favae_gnstats = st
+        return h2, f
+
 
 class Encoder(nn.Module):
     def __init__(self, in_c=3, ch=128, ch_mult=[1, 1, 2, 2, 4], num_res_blocks=2, attn_resolutions=[16], dropout=0.0,
@@ -196,7 +208,8 @@ class Encoder(nn.Module):
         _conv_weights_channels_last(self)
 
     def _tap(self, h, i, inference):
-        return h
+        """-> (h to continue the trunk on, the tap appended to the feature list)"""
+        return h, h
 
     def _final_fwd(self, h):
         f = self.final
@@ -206,13 +219,14 @@ class Encoder(nn.Module):
     def forward(self, x, inference=False):
         feats = []
         h = K.fused_conv(K.as_cl(x), self.conv_in.weight, self.conv_in.bias, cfg=_C3)
-        feats.append(self._tap(h, 0, inference))
-        h = self.down(h)
-        feats.append(self._tap(h, 1, inference))
-        h = self.mid(h)
-        feats.append(self._tap(h, 2, inference))
-        h = self._final_fwd(h)
-        feats.append(self._tap(h, 3, inference))
+        h, f = self._tap(h, 0, inference)
+        feats.append(f)
+        h, f = self._tap(self.down(h), 1, inference)
+        feats.append(f)
+        h, f = self._tap(self.mid(h), 2, inference)
+        feats.append(f)
+        h, f = self._tap(self._final_fwd(h), 3, inference)
+        feats.append(f)
         return h, feats
 
 
@@ -228,7 +242,7 @@ class EncoderGauss(Encoder, _BlurMixin):
         self.padding = [kernel_size // 2] * 4
 
     def _tap(self, h, i, inference):
-        return h if inference else self._gaussian_blur(h, i)
+        return (h, h) if inference else self._blur_tap(h, i)
 
 
 class Decoder(nn.Module):
@@ -312,38 +326,39 @@ class _DecoderFcmBase(nn.Module, _BlurMixin):
         return NonResnetBlock(c, c, dropout=dropout, num_groups=num_groups)
 
     def _tap(self, h, i, inference):
+        """-> (h to continue on, the tap appended to the feature list)"""
         if not self.OWN_SIGMAS:
-            return h
+            return h, h
         if not inference:
-            return self._gaussian_blur(h, i)
-        return None if self.RES_FCM else h          # DecoderFcmResGauss appends None under inference (codec.py:973-1000)
+            return self._blur_tap(h, i)
+        return h, (None if self.RES_FCM else h)     # DecoderFcmResGauss appends None under inference (codec.py:973-1000)
 
     def forward(self, z, inference=False):
         feats = []
         conv_in = lambda t: K.fused_conv(t, self.conv_in.weight, self.conv_in.bias, cfg=_C3)
         z = K.as_cl(z)
         if self.RES_FCM:
-            h = self.fcm_1(z)
-            feats.append(self._tap(h, 0, inference))
-            h = self.fcm_2(conv_in(h))
-            feats.append(self._tap(h, 1, inference))
-            h = self.fcm_3(self.mid(h))
-            feats.append(self._tap(h, 2, inference))
-            h = self.fcm_4(self.up(h))
-            feats.append(self._tap(h, 3, inference))
+            h, f = self._tap(self.fcm_1(z), 0, inference)
+            feats.append(f)
+            h, f = self._tap(self.fcm_2(conv_in(h)), 1, inference)
+            feats.append(f)
+            h, f = self._tap(self.fcm_3(self.mid(h)), 2, inference)
+            feats.append(f)
+            h, f = self._tap(self.fcm_4(self.up(h)), 3, inference)
+            feats.append(f)
             trunk = h
         else:
-            h = self.fcm_1(z)
-            feats.append(self._tap(h, 0, inference))
+            h, f = self._tap(self.fcm_1(z), 0, inference)
+            feats.append(f)
             trunk = conv_in(K.add(h, z))
-            h = self.fcm_2(trunk)
-            feats.append(self._tap(h, 1, inference))
+            h, f = self._tap(self.fcm_2(trunk), 1, inference)
+            feats.append(f)
             trunk = self.mid(K.add(trunk, h))
-            h = self.fcm_3(trunk)
-            feats.append(self._tap(h, 2, inference))
+            h, f = self._tap(self.fcm_3(trunk), 2, inference)
+            feats.append(f)
             trunk = self.up(K.add(trunk, h))
-            h = self.fcm_4(trunk)
-            feats.append(self._tap(h, 3, inference))
+            h, f = self._tap(self.fcm_4(trunk), 3, inference)
+            feats.append(f)
             trunk = K.add(trunk, h)
         f = self.final
         out = K.fused_conv(trunk, f[2].weight, f[2].bias, f[0].weight, f[0].bias, None, _C3)

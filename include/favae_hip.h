@@ -257,6 +257,10 @@ size_t favae_blur_bwd_workspace(int ksize, int N, int H, int W, int C);
 /* dx = adjoint(reflect-pad o blur)(dy); dsigma (1 float, overwritten) = dL/dsigma */
 int favae_blur_bwd(const float* x, const float* dy, const float* sigma, int ksize, int N, int H, int W, int C,
                    float* dx, float* dsigma, void* ws, size_t ws_bytes, favae_stream_t stream);
+/* the same with dx = adjoint-blur(dy) + dx_add (both required): the gradient of the blurred tensor's other consumer (the codec's trunk,
+ * models/codec.py:209-215) folded into the store instead of a separate accumulation pass over two tensors */
+int favae_blur_bwd_add(const float* x, const float* dy, const float* sigma, int ksize, int N, int H, int W, int C, const float* dx_add,
+                       float* dx, float* dsigma, void* ws, size_t ws_bytes, favae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Focal-frequency / dynamic-spectrum loss.  Replaces focal_frequency_loss.FocalFrequencyLoss(loss_weight, alpha=1)
