@@ -171,11 +171,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
         rstd[n * G + g] = (float)(1.0 / sqrt(var + (double)eps));
     }
     __syncthreads();
-    float bound = 0.f;
     if (scale) {
-        // |gamma (x - mu) rstd + beta| <= |gamma| sqrt(count) + |beta|  (sum of squares of the normalised group = count), and
-        // |SiLU(t)|, |LeakyReLU(t)| <= |t|: an upper bound of the transformed activations for the fp16 split scale (conv_split.h)
-        const float root = sqrtf((float)cpg * (float)HW);
         for (int c = cb + threadIdx.x; c < ce; c += 256) {
             const int g = c / cpg;
             const float mu = mean[n * G + g], rs = rstd[n * G + g];
@@ -183,20 +179,23 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
             const float sc = rs * ga;
             scale[(size_t)n * C + c] = sc;
             shift[(size_t)n * C + c] = be - mu * sc;
-            bound = fmaxf(bound, fmaf(fabsf(ga), root, fabsf(be)));
         }
     }
-    if (absmax) {                            // one same-address atomic per block (they serialise at ~10 ns each)
+    if (absmax && blockIdx.x == 0 && blockIdx.y == 0) {
+        // |gamma (x - mu) rstd + beta| <= |gamma| sqrt(count) + |beta|  (sum of squares of the normalised group = count), and
+        // |SiLU(t)|, |LeakyReLU(t)| <= |t|: an upper bound of the transformed activations for the fp16 split scale (conv_split.h).
+        // It depends on gamma, beta and the group size only -- not on the data, not on the image: ONE block computes it over all
+        // channels and stores it (round 3: was an atomicMax from every block into a target zeroed by a memset launch per GroupNorm)
+        const float root = sqrtf((float)cpg * (float)HW);
+        float bound = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256)
+            bound = fmaxf(bound, fmaf(fabsf(gamma ? gamma[c] : 1.f), root, fabsf(beta ? beta[c] : 0.f)));
         bound = wave_max(bound);
         float* wm = reinterpret_cast<float*>(sl);
         __syncthreads();
         if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = bound;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            float b = 0.f;
-            for (int w = 0; w < 4; ++w) b = fmaxf(b, wm[w]);
-            atomicMax(absmax, __float_as_uint(b));
-        }
+        if (threadIdx.x == 0) *absmax = __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
     }
 }
 
@@ -483,7 +482,6 @@ extern "C" int favae_gn_stats(const float* x, const float* gamma, const float* b
     double* part = (double*)ws;
     double* acc = (double*)((char*)ws + part_bytes(N, HW, C));
     FAVAE_REQUIRE(!absmax_out || scale);
-    if (absmax_out && hipMemsetAsync(absmax_out, 0, sizeof(float), s) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     launch_partial<0>(x, nullptr, gamma, beta, nullptr, nullptr, part, N, (long)HW, C, G, 0, s);
     FAVAE_CHECK_LAUNCH();
     FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N, gn_slabs(G)), dim3(256), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
@@ -502,7 +500,6 @@ extern "C" int favae_gn_stats_tiles(const void* part, int tiles, const float* ga
     FAVAE_REQUIRE(!absmax_out || scale);
     if (ws_bytes < acc_bytes(N, C)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     hipStream_t s = (hipStream_t)stream;
-    if (absmax_out && hipMemsetAsync(absmax_out, 0, sizeof(float), s) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N, gn_slabs(G)), dim3(256), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
                        (double*)ws, (long)HW, C, G, tiles, eps, (unsigned*)absmax_out);
     FAVAE_CHECK_LAUNCH();
