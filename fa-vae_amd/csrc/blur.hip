@@ -384,7 +384,14 @@ static int blur_bwd_impl(const float* x, const float* dy, const float* sigma, in
     hipStream_t s = (hipStream_t)stream;
     const dim3 g3((unsigned)grid), b3(256);
     FAVAE_PROF_NOTE(0, (dx_add ? 16.0 : 12.0) * N * H * W * C);            // reads x and dy (+ dx_add), writes dx
-    if (stream_path) {
+    static int bwd2 = -1;                     // FAVAE_BLUR_BWD2=0: the round-2 backward with nine tap-gradient accumulators (A/B switch)
+    if (bwd2 < 0) { const char* e = getenv("FAVAE_BLUR_BWD2"); bwd2 = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
+    const bool direct = stream_path && bwd2;
+    if (direct) {
+        sa.x = x; sa.dy = dy; sa.sigma = sigma; sa.dx = dx; sa.part = a.part; sa.dx_add = dx_add;
+        if (bwd2 == 2) FAVAE_KLAUNCH((blur9_stream_bwd_kernel<STREAM_COLS, 2>), g3, dim3(STREAM_COLS * 8), 0, s, sa);
+        else FAVAE_KLAUNCH((blur9_stream_bwd_kernel<STREAM_COLS, 4>), g3, dim3(STREAM_COLS * 8), 0, s, sa);
+    } else if (stream_path) {
         sa.x = x; sa.dy = dy; sa.sigma = sigma; sa.dx = dx; sa.part = a.part; sa.dx_add = dx_add;
         FAVAE_KLAUNCH((blur9_stream_kernel<1, STREAM_COLS>), g3, dim3(STREAM_COLS * 8), 0, s, sa);
     } else if (ksize == 9) FAVAE_KLAUNCH((blur_sep_kernel<1, 9>), g3, b3, shm, s, a);
@@ -392,7 +399,10 @@ static int blur_bwd_impl(const float* x, const float* dy, const float* sigma, in
     else if (ksize == 3) FAVAE_KLAUNCH((blur_sep_kernel<1, 3>), g3, b3, shm, s, a);
     else FAVAE_KLAUNCH((blur_sep_kernel<1, 0>), g3, b3, shm, s, a);
     FAVAE_CHECK_LAUNCH();
-    if (dsigma) {
+    if (dsigma && direct) {                   // one d sigma partial per workgroup: their sum IS the gradient
+        int rc = favae_colsum(part, dsigma, grid, 1, 0, nullptr, p2, cws, stream);
+        if (rc) return rc;
+    } else if (dsigma) {
         int rc = favae_colsum(part, dgv, grid, ksize, 0, nullptr, p2, cws, stream);
         if (rc) return rc;
         FAVAE_KLAUNCH(blur_dsigma_kernel, dim3(1), dim3(64), 0, s, (const float*)dgv, sigma, ksize, dsigma);

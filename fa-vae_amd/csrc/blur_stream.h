@@ -198,6 +198,153 @@ __global__ __launch_bounds__(COLS * 8) void blur9_stream_kernel(StreamArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward, round 3: the same march with the sigma gradient formed DIRECTLY instead of through nine tap gradients.
+// With c_a = d g_a / d sigma (sum_a c_a = 0; g = normalised Gaussian taps):
+//   d sigma = sum_a c_a dg_a = < C_v^T dY , G_h Xe >  +  < G_v^T dY , C_h Xe >
+//   first term, per extended row r (the row-blurred row h = (G_h Xe)[r] this step produces anyway):
+//       w1[r] = sum_t c[8 - t] dy[r - 4 + t]      over the dy rows that belong to THIS workgroup's segment
+//   second term, per image row i: b = sum_t c[t] Xe[i, j - 4 + t]  (next to h, from the same LDS reads), v = V'[i] as before
+// Both need one extra 9-tap filter and ONE dot product per element where the round-2 kernel kept nine dot-product accumulators
+// against a 9-row register window of U (2 x 9 accumulators + 36 window registers + the 9 staged x quads): 200 -> ~120 registers,
+// two workgroups per CU instead of one; one partial per workgroup instead of nine.
+// ---------------------------------------------------------------------------------------------------------------
+template <int COLS, int WPE>      // WPE = waves per SIMD the register allocation is held to (4: two workgroups per CU; 2: one)
+__global__ __launch_bounds__(COLS * 8, WPE) void blur9_stream_bwd_kernel(StreamArgs a) {
+    constexpr int K = 9, P = 4, NT = COLS * 8, OUTC = COLS - 2 * P;
+    __shared__ float4 Xs[2][COLS * 8];
+    __shared__ float4 Vs[2][COLS * 8];
+    __shared__ float gs[32];          // [0..8] taps g, [16..24] their sigma derivative c
+    __shared__ float red[NT / 64];
+
+    int b = blockIdx.x;
+    const int cchunk = b % a.cchunks; b /= a.cchunks;
+    const int strip = b % a.strips; b /= a.strips;
+    const int seg = b % a.segs;
+    const int n = b / a.segs;
+    const int tid = threadIdx.x, quad = tid & 7, col = tid >> 3;
+    const int ys = seg * a.RS, ye = min(a.H, ys + a.RS);
+    const int x0 = strip * OUTC;
+    const int gj = x0 - P + col;
+    const bool in_strip = col >= P && col < COLS - P;
+    const bool out_col = in_strip && gj < a.W;
+    const int xr = reflect_idx(gj, a.W);
+    const bool d_col = gj >= 0 && gj < a.W;
+    const size_t img = (size_t)n * a.H * a.W;
+    const int coff = cchunk * 32 + quad * 4;
+
+    make_kernel1d(a.sigma, K, gs);
+    if (tid == 0) {                   // c_a = g_a (t_a^2 - sum_j g_j t_j^2) / sigma^3, in double from the double taps
+        const double sg = a.sigma[0];
+        double p[K], S = 0.0, m2 = 0.0;
+        for (int j = 0; j < K; ++j) { const double t = j - 4.0; p[j] = exp(-0.5 * (t / sg) * (t / sg)); S += p[j]; }
+        for (int j = 0; j < K; ++j) { const double t = j - 4.0; m2 += p[j] / S * t * t; }
+        for (int j = 0; j < K; ++j) { const double t = j - 4.0; gs[16 + j] = (float)(p[j] / S * (t * t - m2) / (sg * sg * sg)); }
+    }
+    __syncthreads();
+    float g[K], c[K], wcol[K];        // g, c: wave-uniform -> scalar registers
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        g[t] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gs[t])));
+        c[t] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gs[16 + t])));
+        wcol[t] = fold_weight(gs, gj, a.W, t);
+    }
+
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 Dw[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) Dw[t] = zero4;
+    float acc = 0.f;
+
+    auto load_x = [&](int yp) -> float4 {
+        const int r = reflect_idx(yp, a.H);
+        return *reinterpret_cast<const float4*>(a.x + ((img + (size_t)r * a.W + xr) * a.C + coff));
+    };
+    auto load_d = [&](int q) -> float4 {
+        if (q < 0 || q >= a.H || !d_col) return zero4;
+        return *reinterpret_cast<const float4*>(a.dy + ((img + (size_t)q * a.W + gj) * a.C + coff));
+    };
+
+    const int y_first = ys - 2 * P, y_last = ye - 1 + P;
+    float4 nx = zero4, nd = load_d(y_first + P);
+    for (int yp = y_first; yp <= y_last; ++yp) {
+        const float4 cx = nx, cd = nd;
+        if (yp + 1 <= y_last) {
+            if (yp + 1 >= ys - P) nx = load_x(yp + 1);
+            nd = load_d(yp + 1 + P);
+        }
+#pragma unroll
+        for (int t = 0; t < K - 1; ++t) Dw[t] = Dw[t + 1];
+        Dw[K - 1] = cd;                                            // Dw[t] = dy[yp - 4 + t]
+        if (yp < ys - P) continue;                                 // (uniform) dy-window warm-up steps
+        const int buf = yp & 1;
+        Xs[buf][tid] = cx;
+        __syncthreads();
+        const bool v_row = yp >= ys && yp < ye;                    // (uniform) image row i = yp of this segment
+        float4 h = zero4, bq = zero4;
+        if (in_strip) {
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const float4 xv = Xs[buf][tid + (t - P) * 8];
+                h = f4_fma(g[t], xv, h);
+                bq = f4_fma(c[t], xv, bq);
+            }
+        }
+        if (a.part && out_col) {
+            // first term: dy rows yp - 4 + t of this segment only (the window also holds the neighbours' rows for V')
+            float4 w1 = zero4;
+            if (yp - P >= ys && yp + P < ye) {                     // (uniform) interior step: the whole window belongs to the segment
+#pragma unroll
+                for (int t = 0; t < K; ++t) w1 = f4_fma(c[K - 1 - t], Dw[t], w1);
+            } else {
+#pragma unroll
+                for (int t = 0; t < K; ++t) {
+                    const int q = yp - P + t;
+                    w1 = f4_fma((q >= ys && q < ye) ? c[K - 1 - t] : 0.f, Dw[t], w1);
+                }
+            }
+            acc = f4_dot(w1, h, acc);
+        }
+        if (!v_row) continue;
+        float4 v = zero4;
+        if (yp >= P + 1 && yp <= a.H - 2 - P) {                    // interior row: no fold
+#pragma unroll
+            for (int t = 0; t < K; ++t) v = f4_fma(g[K - 1 - t], Dw[t], v);
+        } else {
+#pragma unroll
+            for (int t = 0; t < K; ++t) v = f4_fma(fold_weight(gs, yp, a.H, t), Dw[t], v);
+        }
+        if (a.part && out_col) acc = f4_dot(v, bq, acc);           // second term
+        if (a.dx) {
+            Vs[buf][tid] = v;
+            __syncthreads();
+            if (out_col) {
+                float4 o = zero4;
+#pragma unroll
+                for (int t = 0; t < K; ++t) o = f4_fma(wcol[t], Vs[buf][tid + (t - P) * 8], o);
+                const size_t oo = (img + (size_t)yp * a.W + gj) * a.C + coff;
+                if (a.dx_add) {
+                    const float4 q = *reinterpret_cast<const float4*>(a.dx_add + oo);
+                    o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+                }
+                *reinterpret_cast<float4*>(a.dx + oo) = o;
+            }
+        }
+    }
+    if (a.part) {
+        const int lane = tid & 63, wid = tid >> 6;
+        const float sw = wave_sum(acc);
+        __syncthreads();
+        if (lane == 0) red[wid] = sw;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.f;
+            for (int w = 0; w < NT / 64; ++w) tot += red[w];
+            a.part[blockIdx.x] = tot;
+        }
+    }
+}
+
 constexpr int STREAM_COLS = 64;
 
 bool stream_ok(int ksize, int N, int H, int W, int C) {
