@@ -40,10 +40,12 @@ struct FftArgs {
 enum { IN_COMPLEX = 0, IN_DIFF = 1, IN_HALF = 2 };   // IN_HALF: bins l > L/2 are the conjugates of bins L - l
 enum { OUT_COMPLEX = 0, OUT_COMPLEX_MAX = 1, OUT_REAL = 2 };
 
+// 256 or 512 threads per block (round 3: the 64 KB tiles of the 256-point lines allow two blocks per CU -- with 512 threads those
+// are 16 waves per CU instead of 8 for the same tile: twice the loads in flight in the latency-bound load / store phases)
 template <int IN, int OUT>
-__global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs a) {
+__global__ __launch_bounds__(512) void fft_lines_kernel(FftArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int L = a.L, IC = a.IC, tid = threadIdx.x;
+    const int L = a.L, IC = a.IC, tid = threadIdx.x, NT = blockDim.x;
     const int NTW = a.generic ? L : (L / 2 > 0 ? L / 2 : 1);    // twiddles: e^(-+2 pi i j / L), j < L/2 (all j for the direct DFT)
     float2* tw = reinterpret_cast<float2*>(sm);                 // [NTW]
     float2* data = reinterpret_cast<float2*>(sm) + NTW;         // [L][IC]
@@ -51,13 +53,13 @@ __global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs a) {
     const long o = blockIdx.x / chunks;
     const long i0 = (blockIdx.x % chunks) * IC;
 
-    for (int j = tid; j < (a.generic ? L : L / 2); j += 256) {
+    for (int j = tid; j < (a.generic ? L : L / 2); j += NT) {
         float s, c;
         sincospif(2.0f * (float)j / (float)L, &s, &c);
         tw[j] = make_float2(c, a.inverse ? s : -s);
     }
     // ---- load (bit-reversed along L) ------------------------------------------------------------------------
-    const int ic = tid % IC, bl = tid / IC, BL = 256 / IC;
+    const int ic = tid % IC, bl = tid / IC, BL = NT / IC;
     const bool ic_ok = i0 + ic < a.inner;
     const size_t base = (size_t)o * L * a.inner + i0 + ic;            // full-length lines (real input, real output)
     const size_t base_in = (size_t)o * a.Lin * a.inner + i0 + ic;
@@ -258,7 +260,10 @@ int launch_fft(FftArgs& a, hipStream_t s) {
         const double in_b = IN == IN_DIFF ? 8.0 * a.Lin : 8.0 * a.Lin, out_b = (OUT == OUT_REAL ? (a.out2 ? 8.0 : 4.0) : 8.0) * a.Lout;
         FAVAE_PROF_NOTE(0, lines * (in_b + out_b));
     }
-    FAVAE_KLAUNCH((fft_lines_kernel<IN, OUT>), dim3((unsigned)blocks), dim3(256), shm, s, a);
+    static int nt512 = -1;                    // FAVAE_FFT_512=0: 256 threads per block everywhere (A/B switch)
+    if (nt512 < 0) { const char* e = getenv("FAVAE_FFT_512"); nt512 = (e && e[0] == '0') ? 0 : 1; }
+    const int nt = (nt512 && a.L >= 128 && a.IC >= 32 && !a.generic) ? 512 : 256;
+    FAVAE_KLAUNCH((fft_lines_kernel<IN, OUT>), dim3((unsigned)blocks), dim3(nt), shm, s, a);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
 }
