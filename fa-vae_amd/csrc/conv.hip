@@ -133,6 +133,7 @@ struct ConvArgs {
     // conv3x3_halo_sp_kernel<., 2, 3, false, false, true>: per-tile sums (sum y, sum y^2) per output channel of the FINAL output
     // (bias and residual included) -- pass 1 of the GroupNorm that consumes this conv's output (gn_partial<0>: one tensor read)
     double* gs_part;          // [N][tiles per image][Cout][2]
+    unsigned* gs_amax;        // optional (same variant): max |y| of the output, bit pattern, one atomicMax per workgroup (pre-zeroed)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -907,7 +908,8 @@ struct GnBwdEpi {              // GroupNorm-backward partial sums in the data-gr
 };
 static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                          const float* scale, const float* shift, float* y, int wplanes, const float* x_amax,
-                         favae_stream_t stream, void* planes_out, const GnBwdEpi* gb = nullptr, double* stats_part = nullptr);
+                         favae_stream_t stream, void* planes_out, const GnBwdEpi* gb = nullptr, double* stats_part = nullptr,
+                         float* stats_amax = nullptr);
 
 extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const float* w, const float* bias,
                               const float* resid, const float* scale, const float* shift, float* y,
@@ -971,13 +973,15 @@ extern "C" int favae_conv_stats_tiles(const favae_conv_desc* d, int has_affine) 
 
 extern "C" int favae_conv_fwd_split_stats(const favae_conv_desc* d, const float* x, const void* wsplit, int planes,
                                           const float* x_absmax, const float* bias, const float* resid, const float* scale,
-                                          const float* shift, float* y, void* part, size_t part_bytes, favae_stream_t stream) {
+                                          const float* shift, float* y, void* part, size_t part_bytes, float* y_absmax,
+                                          favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && wsplit && (x_absmax || planes == 4) && part);
     const int tiles = favae_conv_stats_tiles(d, scale != nullptr);
     if (!tiles || (planes != 2 && planes != 1 && planes != 4)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
+    if (y_absmax && hipMemsetAsync(y_absmax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr, nullptr,
-                         (double*)part);
+                         (double*)part, y_absmax);
 }
 
 extern "C" int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy, const void* wsplit, int planes,
@@ -994,7 +998,7 @@ extern "C" int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy,
 
 static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                          const float* scale, const float* shift, float* y, int wplanes, const float* x_amax,
-                         favae_stream_t stream, void* planes_out, const GnBwdEpi* gb, double* stats_part) {
+                         favae_stream_t stream, void* planes_out, const GnBwdEpi* gb, double* stats_part, float* stats_amax) {
     FAVAE_REQUIRE(desc_ok(d) && x && w && y);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     // roofline numerators of this conv: 2*M*Cout*KH*KW*Cin FLOP; one read of x (+ resid), one write of y, the weights
@@ -1038,6 +1042,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     a.planes_out = planes_out;
     a.gb_x = nullptr; a.gb_mean = a.gb_rstd = a.gb_gamma = a.gb_beta = nullptr; a.gb_part = nullptr; a.gb_groups = 1; a.gb_act = 0;
     a.gs_part = stats_part;
+    a.gs_amax = (unsigned*)stats_amax;
     if (gb) {
         a.gb_x = gb->x; a.gb_mean = gb->mean; a.gb_rstd = gb->rstd; a.gb_gamma = gb->gamma; a.gb_beta = gb->beta;
         a.gb_part = gb->part; a.gb_groups = gb->groups; a.gb_act = gb->act;

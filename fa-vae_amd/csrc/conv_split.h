@@ -560,6 +560,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 
     float un_a = 1.f, un_w = 1.f;
     if constexpr (S::SCALED) { un_a = sp::pow2_inv(Sa); un_w = sp::pow2_inv(sp::pow2_scale(a.w_amax)); }
     double gs1[2] = {0.0, 0.0}, gs2[2] = {0.0, 0.0};
+    float se_amax = 0.f;                 // SE: max |y| of this thread's outputs (operand range of a plain conv that consumes y)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + (lane & 31);
@@ -604,6 +605,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 
             if constexpr (SE) {          // statistics feed E[y^2] - mean^2: fp64 from the first product on (norm.hip)
                 gs1[j] += (double)v;
                 gs2[j] += (double)v * (double)v;
+                se_amax = fmaxf(se_amax, fabsf(v));
             }
         }
         if constexpr (GB) { gs1[j] = (double)f1; gs2[j] = (double)f2; }
@@ -623,6 +625,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 
             }
         }
         __syncthreads();
+        if constexpr (SE) {
+            if (a.gs_amax) {             // one atomic per workgroup; non-negative floats order like their bit patterns
+                float* wmx = reinterpret_cast<float*>(lds + 4 * 128 * 2 * sizeof(double));
+                se_amax = wave_max(se_amax);
+                if (lane == 0) wmx[wid] = se_amax;
+                __syncthreads();
+                if (tid == 0) {
+                    float m = wmx[0];
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) m = fmaxf(m, wmx[w]);
+                    atomicMax(a.gs_amax, __float_as_uint(m));
+                }
+            }
+        }
         if (tid < 128 && n0 + tid < a.Cout) {
             double u = 0.0, w2 = 0.0;
 #pragma unroll

@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FAVAE_HIP_LIB") or os.path.join(_HERE, "libfavae_hip.so")     # FAVAE_HIP_LIB: same-box A/B of two builds
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02, ACT_RELU = 0, 1, 2, 3
@@ -106,7 +106,7 @@ SIGNATURES = {
     "favae_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     "favae_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _S]),
     "favae_conv_stats_tiles": (c_int, [POINTER(ConvDesc), c_int]),
-    "favae_conv_fwd_split_stats": (c_int, [POINTER(ConvDesc), _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _S]),
+    "favae_conv_fwd_split_stats": (c_int, [POINTER(ConvDesc), _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, _S]),
     "favae_gn_stats_tiles": (c_int, [_P, c_int, _P, _P, c_int, c_int64, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _S]),
     "favae_conv_gnbwd_tiles": (c_int, [POINTER(ConvDesc)]),
     "favae_gn_bwd_tiles_workspace": (c_size_t, [c_int, c_int, c_int]),

@@ -244,7 +244,11 @@ def get_conv_mode():
 
 
 def absmax(t):
-    """device scalar max|t| (operand range of the fp16 split-precision conv kernels)"""
+    """device scalar max|t| (operand range of the fp16 split-precision conv kernels); taken from the producing conv's epilogue when
+    it left one on the tensor (`_favae_amax`, valid while the version counter is unchanged)"""
+    pre = getattr(t, "_favae_amax", None)
+    if pre is not None and pre[1] == t._version:
+        return pre[0]
     out = torch.empty((1,), dtype=torch.float32, device=t.device)
     call("favae_absmax", ptr(t), t.numel(), ptr(out))
     return out
@@ -478,7 +482,8 @@ def _bias_grad_and_range(dy, p_b, need_b, want_range, M, Cout, dev):
     return db, dyb
 
 
-def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=None, planes_out=None, gnbwd=None, stats_out=None):
+def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=None, planes_out=None, gnbwd=None, stats_out=None,
+                 y_amax=None):
     """conv forward / data gradient.  When the library runs this shape on the split-precision matrix path the weights are
     pre-split once per call (instead of once per tile in the K loop); the fp16 scheme (2 planes) also needs the operand
     range: `x_bound` = device scalar >= max|T(x)| (computed here for an un-transformed operand when not supplied).
@@ -516,9 +521,9 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
         elif planes_out is not None:
             call("favae_conv_fwd_split_planes", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
                  ptr(shift), ptr(y), ptr(planes_out))
-        elif stats_out is not None:          # forward + per-tile statistics of the output (pass 1 of the next GroupNorm)
+        elif stats_out is not None:          # forward + per-tile statistics of the output (pass 1 of the next GroupNorm) + max|y|
             call("favae_conv_fwd_split_stats", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
-                 ptr(shift), ptr(y), ptr(stats_out), stats_out.numel() * 8)
+                 ptr(shift), ptr(y), ptr(stats_out), stats_out.numel() * 8, ptr(y_amax))
         else:
             call("favae_conv_fwd_split", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
                  ptr(shift), ptr(y))
@@ -591,9 +596,11 @@ class FusedConvFn(torch.autograd.Function):
             st_tiles = query("favae_conv_stats_tiles", byref(d), 0 if scale is None else 1)
             if st_tiles:
                 st_part = torch.empty((N * st_tiles * Cout * 2,), dtype=torch.float64, device=dev)
-        w_amax = _conv_launch(d, x, wk, b, resid, scale, shift, y, xb, planes_out=xs, stats_out=st_part)
+        y_amax = torch.empty((1,), dtype=torch.float32, device=dev) if st_part is not None else None
+        w_amax = _conv_launch(d, x, wk, b, resid, scale, shift, y, xb, planes_out=xs, stats_out=st_part, y_amax=y_amax)
         if st_part is not None:
             y._favae_gnstats = (st_part, st_tiles, y._version)
+            y._favae_amax = (y_amax, y._version)
         ctx.cfg = cfg
         ctx.has_b = b is not None
         ctx.has_gn = gn_w is not None

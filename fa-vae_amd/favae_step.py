@@ -227,9 +227,10 @@ class TrainStep:
 
         def marked(x, i):
             y = _GradMark.apply(x, mark(i))
-            st = getattr(x, "_favae_gnstats", None)
-            if st is not None:                  # the view shares x's version counter: the tile statistics the producing conv left on
-                y._favae_gnstats = st           # x stay valid for the GroupNorm behind the mark (ops.gn_stats), as without marks
+            for attr in ("_favae_gnstats", "_favae_amax"):
+                st = getattr(x, attr, None)
+                if st is not None:              # the view shares x's version counter: the by-products the producing conv left on x
+                    setattr(y, attr, st)        # (tile statistics, max|x|) stay valid behind the mark, as without marks
             return y
 
         def pre_hook(i):

@@ -175,10 +175,12 @@ class _BlurMixin:
         (ops.gn_stats) stay valid for the alias: same memory, same version counter."""
         if not (K._BLUR_TAP and torch.is_grad_enabled() and h.requires_grad):
             return h, self._gaussian_blur(h, i)
-        st = getattr(h, "_favae_gnstats", None)
+        st, am = getattr(h, "_favae_gnstats", None), getattr(h, "_favae_amax", None)
         h2, f = K.blur_tap(h, self.sigmas, i, self.kernel_size)
         if st is not None:
             h2._favae_gnstats = st
+        if am is not None:
+            h2._favae_amax = am
         return h2, f
 
 

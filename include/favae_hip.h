@@ -398,9 +398,12 @@ int favae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
  *   favae_conv_stats_tiles(d, has_affine)   tiles per image when favae_conv_fwd_split(d, ...) runs that kernel, else 0
  * ---------------------------------------------------------------------------------------------------------- */
 int favae_conv_stats_tiles(const favae_conv_desc* d, int has_affine);
+/* y_absmax (optional device float): max |y| of the output as a further by-product -- the fp16 operand range of a conv that consumes y
+ * WITHOUT a normalisation in front (Downsample, Upsample, nin_shortcut: models/codec.py:17,26-29,50), which otherwise costs one
+ * favae_absmax pass over y. */
 int favae_conv_fwd_split_stats(const favae_conv_desc* d, const float* x, const void* wsplit, int planes, const float* x_absmax,
                                const float* bias, const float* resid, const float* scale, const float* shift, float* y,
-                               void* part, size_t part_bytes, favae_stream_t stream);
+                               void* part, size_t part_bytes, float* y_absmax, favae_stream_t stream);
 int favae_gn_stats_tiles(const void* part, int tiles, const float* gamma, const float* beta, int N, int64_t HW, int C, int G,
                          float eps, float* mean, float* rstd, float* scale, float* shift, float* absmax_out, void* ws,
                          size_t ws_bytes, favae_stream_t stream);

@@ -1,5 +1,5 @@
 import sys, os, collections, traceback
-sys.path.insert(0, "/root/repo/fa-vae_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "fa-vae_amd"))
 import torch, favae_hip
 from favae_step import TrainStep
 from utils import synthetic_batch
