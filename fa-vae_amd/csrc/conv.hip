@@ -81,6 +81,20 @@ int b6_waves() {
     if (v < 0) { const char* e = getenv("FAVAE_B6_WAVES"); v = (e && e[0] == '4') ? 4 : 8; }
     return v;
 }
+// FAVAE_WINO=0 keeps the dense 3x3 convs of the h3 scheme on the direct LDS-halo kernel instead of the Winograd F(2x2, 3x3) kernel
+int g_wino = -1;
+bool use_wino() {
+    if (g_wino < 0) { const char* e = getenv("FAVAE_WINO"); g_wino = (e && e[0] == '0') ? 0 : 1; }
+    return g_wino == 1;
+}
+
+// FAVAE_WINO_DBG=1..4: timing ablations of the Winograd data-gradient kernel (wrong results): no MFMA / no transform / no barriers / no epilogue
+int wino_dbg() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FAVAE_WINO_DBG"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 // FAVAE_CONV_NOBUF=1 disables the buffer-addressed kernels (A/B against the flat-addressed fast kernels)
 bool force_nobuf() {
     static int v = -1;
@@ -523,6 +537,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #include "conv_fast.h"
 #include "conv_buf.h"
 #include "conv_split.h"
+#include "conv_wino.h"
 #include "conv_thin.h"
 
 // out[i] (+)= sum_z part[z][i] in a fixed order (4 interleaved partial sums -> 4 loads in flight per thread)
@@ -917,11 +932,17 @@ extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const fl
     return conv_fwd_impl(d, x, w, bias, resid, scale, shift, y, 0, nullptr, stream, nullptr);
 }
 
+static bool wino_ok(const favae_conv_desc* d, bool has_affine);
 extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, const void* wsplit, int planes,
                                     const float* x_absmax, const float* bias, const float* resid, const float* scale,
                                     const float* shift, float* y, favae_stream_t stream) {
     if (!sp_fwd_eligible(d, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-    FAVAE_REQUIRE(wsplit && (planes == 3 || planes == 4 || ((planes == 2 || planes == 1) && x_absmax)));
+    if (planes & FAVAE_PLANES_WINO) {
+        if (planes != (2 | FAVAE_PLANES_WINO) || !wino_ok(d, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+        FAVAE_REQUIRE(wsplit && x_absmax);
+    } else {
+        FAVAE_REQUIRE(wsplit && (planes == 3 || planes == 4 || ((planes == 2 || planes == 1) && x_absmax)));
+    }
     return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr);
 }
 
@@ -930,6 +951,7 @@ extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, co
 // 1 when favae_conv_fwd_split(d, ...) runs the dense 3x3 halo kernel with fp16 planes (two: h3, or one: h1) -- the kernel whose
 // epilogue can emit GroupNorm sums (SE / GB variants)
 static bool halo3_fp16_ok(const favae_conv_desc* d, bool has_affine);
+static bool wino_ok(const favae_conv_desc* d, bool has_affine);
 
 static bool planes_producer_ok(const favae_conv_desc* d, bool has_affine) { return conv_mode() == 2 && halo3_fp16_ok(d, has_affine); }
 
@@ -940,6 +962,51 @@ static bool halo3_fp16_ok(const favae_conv_desc* d, bool has_affine) {
     return d->Cout > 64 && d->Cin % 16 == 0 && d->stride == 1 && d->gather == FAVAE_GATHER_PLAIN && d->KH == 3 && d->KW == 3 &&
            d->pad == 1 && d->Hout == d->Hin && d->Wout == d->Win && d->Hin % 8 == 0 && d->Win % 16 == 0 && xb < (1u << 31) &&
            wb < (1u << 31) && (size_t)d->N * d->Hout * d->Wout * d->Cout * 4 < ((size_t)1 << 32);
+}
+
+// Dense 3x3 convs of the h3 scheme whose shape tiles into 16 x 16 pixels x 64 output channels run conv3x3_wino_sp_kernel
+// (conv_wino.h): the caller then passes Winograd weight records (favae_wino_weights) and planes = 2 | FAVAE_PLANES_WINO.
+static bool wino_ok(const favae_conv_desc* d, bool has_affine) {
+    return use_wino() && conv_mode() == 2 && halo3_fp16_ok(d, has_affine) && d->Hin % 16 == 0 && d->Win % 16 == 0 && d->Cout % 64 == 0 &&
+           (size_t)d->Cout * d->Cin * 64 < (1u << 31) && (!has_affine || d->Cin <= wino::AFF_C);
+}
+
+// switch the Winograd path on / off at run time (overrides FAVAE_WINO); returns the previous setting
+extern "C" int favae_set_wino(int on) {
+    const int prev = use_wino() ? 1 : 0;
+    g_wino = on ? 1 : 0;
+    return prev;
+}
+
+extern "C" int favae_conv_wino_ok(const favae_conv_desc* d, int has_affine) { return desc_ok(d) && wino_ok(d, has_affine != 0) ? 1 : 0; }
+
+extern "C" size_t favae_wino_weights_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0 || Cout % 16 || Cin % 16) return 0;
+    return (size_t)sp::WHDR + (size_t)Cout * Cin * 64;
+}
+
+// Winograd weight records of w (OHWI fp32 [Cout][3][3][Cin]) for conv3x3_wino_sp_kernel: U = G g G^T, scaled, split into two fp16
+// planes, in MFMA fragment order.  flip = 0: the forward conv (Cout outputs); flip = 1: its data gradient (Cin outputs, taps
+// flipped).  amax: device float max|w| (nullptr: computed here).  The header (float[0]) holds max|w|.
+extern "C" int favae_wino_weights(const float* w, void* out, int Cout, int Cin, int flip, const float* amax, favae_stream_t stream) {
+    FAVAE_REQUIRE(w && out && favae_wino_weights_bytes(Cout, Cin) && (((uintptr_t)out) & 15) == 0);
+    const int vec = (((uintptr_t)w) & 15) == 0 ? 1 : 0;
+    FAVAE_REQUIRE(flip ? (Cin % 64 == 0 && Cout % 16 == 0) : (Cout % 64 == 0 && Cin % 16 == 0));
+    hipStream_t s = (hipStream_t)stream;
+    float* hdr = nullptr;
+    if (!amax) {
+        const int rc = launch_absmax(w, (int64_t)Cout * 9 * Cin, (float*)out, s);
+        if (rc != FAVAE_OK) return rc;
+        amax = (const float*)out;
+    } else {
+        hdr = (float*)out;
+    }
+    const unsigned blocks = (unsigned)(((size_t)Cout * Cin / 8 + 255) / 256);
+    FAVAE_PROF_NOTE(0, 4.0 * Cout * 9 * Cin + 64.0 * Cout * Cin);
+    if (flip) FAVAE_KLAUNCH((wino_weights_kernel<true>), dim3(blocks), dim3(256), 0, s, w, (unsigned char*)out + sp::WHDR, Cout, Cin, amax, hdr, vec);
+    else FAVAE_KLAUNCH((wino_weights_kernel<false>), dim3(blocks), dim3(256), 0, s, w, (unsigned char*)out + sp::WHDR, Cout, Cin, amax, hdr, vec);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
 }
 
 extern "C" int favae_conv_planes_ok(const favae_conv_desc* d, int has_affine) {
@@ -960,6 +1027,7 @@ extern "C" int favae_conv_fwd_split_planes(const favae_conv_desc* d, const float
 // into part[N][tiles][C][2] (double; tiles = (H/8) (W/16) per image) -- favae_gn_act_bwd_tiles consumes them.
 extern "C" int favae_conv_gnbwd_tiles(const favae_conv_desc* d) {
     if (!desc_ok(d) || !halo3_fp16_ok(d, false)) return 0;
+    if (wino_ok(d, false)) return (d->Hout / 16) * (d->Wout / 16);
     return (d->Hout / 8) * (d->Wout / 16);
 }
 
@@ -968,6 +1036,7 @@ extern "C" int favae_conv_gnbwd_tiles(const favae_conv_desc* d) {
 extern "C" int favae_conv_stats_tiles(const favae_conv_desc* d, int has_affine) {
     if (!desc_ok(d) || !halo3_fp16_ok(d, has_affine != 0)) return 0;
     if (has_affine && d->act != FAVAE_ACT_SILU) return 0;
+    if (wino_ok(d, has_affine != 0)) return (d->Hout / 16) * (d->Wout / 16);
     return (d->Hout / 8) * (d->Wout / 16);
 }
 
@@ -977,7 +1046,10 @@ extern "C" int favae_conv_fwd_split_stats(const favae_conv_desc* d, const float*
                                           favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && wsplit && (x_absmax || planes == 4) && part);
     const int tiles = favae_conv_stats_tiles(d, scale != nullptr);
-    if (!tiles || (planes != 2 && planes != 1 && planes != 4)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    // the tile grid of the partial sums is the kernel's: Winograd records go with the Winograd kernel's 16 x 16 tiles and nothing else
+    if (((planes & FAVAE_PLANES_WINO) != 0) != wino_ok(d, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (planes & FAVAE_PLANES_WINO) planes = planes == (2 | FAVAE_PLANES_WINO) ? planes : 0;
+    if (!tiles || ((planes & 0xff) != 2 && planes != 1 && planes != 4)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     if (y_absmax && hipMemsetAsync(y_absmax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr, nullptr,
@@ -990,7 +1062,9 @@ extern "C" int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy,
                                       favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && dy && wsplit && (dy_absmax || planes == 4) && da && x && mean && rstd && gamma && beta && part && groups > 0);
     const int tiles = favae_conv_gnbwd_tiles(d);
-    if (!tiles || (planes != 2 && planes != 1 && planes != 4) || d->Cout % groups != 0) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (((planes & FAVAE_PLANES_WINO) != 0) != wino_ok(d, false)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (planes & FAVAE_PLANES_WINO) planes = planes == (2 | FAVAE_PLANES_WINO) ? planes : 0;
+    if (!tiles || ((planes & 0xff) != 2 && planes != 1 && planes != 4) || d->Cout % groups != 0) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     GnBwdEpi gb{x, mean, rstd, gamma, beta, (double*)part, groups, act};
     return conv_fwd_impl(d, dy, (const float*)wsplit, nullptr, nullptr, nullptr, nullptr, da, planes, dy_absmax, stream, nullptr, &gb);
@@ -1005,6 +1079,8 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     FAVAE_PROF_NOTE(2.0 * d->N * d->Hout * d->Wout * d->Cout * d->KH * d->KW * d->Cin,
                     4.0 * ((double)d->N * d->Hin * d->Win * d->Cin + (double)d->N * d->Hout * d->Wout * d->Cout * (resid ? 2 : 1) +
                            (double)d->Cout * d->KH * d->KW * d->Cin));
+    const bool wino = (wplanes & FAVAE_PLANES_WINO) != 0;     // Winograd records (favae_wino_weights): conv3x3_wino_sp_kernel
+    wplanes &= 0xff;
     const bool w6 = wplanes != 0;                            // pre-split weights: records start behind the header
     if (!w6) {
         const int tk = thin_kind(d, scale != nullptr);
@@ -1097,7 +1173,41 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     // 2x2 phase convs (Upsample forward / data gradient, first phase of the Downsample data gradient): one side on a sub-grid
     const bool halo2_ok = special && halo_common && use_halo2() && d->KH == 2 && d->KW == 2 && d->lat_step == 2 && xf == 0 &&
                           (d->pad == 0 || d->pad == 1) && (a.pad_w == 0 || a.pad_w == 1);
-    if (halo_ok || halo2_ok) {
+    if (wino) {
+        if (!(halo_ok && wplanes == 2 && !planes_out && d->Hin % 16 == 0 && d->Win % 16 == 0 && d->Cout % 64 == 0 && d->w_rec_offset == 0))
+            return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+        if (gb && (xf != 0 || bias || resid)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+        if (stats_part && !(xf == 0 || xf == 2)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+        a.tiles_n = d->Cout / 64;
+        a.w_bytes = (unsigned)((size_t)d->Cout * d->Cin * 64);
+        const dim3 wgrid((unsigned)(d->N * (d->Hin / 16) * (d->Win / 16) * a.tiles_n));
+#define FAVAE_LAUNCH_WINO4(X, GBV, SEV, DBG)                                                                                \
+    do {                                                                                                                    \
+        static bool attr_set = false;                                                                                       \
+        if (!attr_set) {                                                                                                    \
+            (void)hipFuncSetAttribute((const void*)conv3x3_wino_sp_kernel<X, GBV, SEV, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      wino::LDS_B);                                                                         \
+            attr_set = true;                                                                                                \
+        }                                                                                                                   \
+        FAVAE_KLAUNCH((conv3x3_wino_sp_kernel<X, GBV, SEV, DBG>), wgrid, dim3(512), wino::LDS_B, s, a);                     \
+    } while (0)
+#define FAVAE_LAUNCH_WINO(X, GBV, SEV) FAVAE_LAUNCH_WINO4(X, GBV, SEV, 0)
+        if (gb) FAVAE_LAUNCH_WINO(0, true, false);
+        else if (stats_part && xf == 0) FAVAE_LAUNCH_WINO(0, false, true);
+        else if (stats_part) FAVAE_LAUNCH_WINO(2, false, true);
+        else if (xf == 0 && wino_dbg() == 1) FAVAE_LAUNCH_WINO4(0, false, false, 1);
+        else if (xf == 0 && wino_dbg() == 2) FAVAE_LAUNCH_WINO4(0, false, false, 2);
+        else if (xf == 0 && wino_dbg() == 3) FAVAE_LAUNCH_WINO4(0, false, false, 3);
+        else if (xf == 0 && wino_dbg() == 4) FAVAE_LAUNCH_WINO4(0, false, false, 4);
+        else if (xf == 0 && wino_dbg() == 5) FAVAE_LAUNCH_WINO4(0, false, false, 5);
+        else if (xf == 0 && wino_dbg() == 6) FAVAE_LAUNCH_WINO4(0, false, false, 6);
+        else if (xf == 0) FAVAE_LAUNCH_WINO(0, false, false);
+        else if (xf == 1) FAVAE_LAUNCH_WINO(1, false, false);
+        else if (xf == 2) FAVAE_LAUNCH_WINO(2, false, false);
+        else FAVAE_LAUNCH_WINO(3, false, false);
+#undef FAVAE_LAUNCH_WINO
+#undef FAVAE_LAUNCH_WINO4
+    } else if (halo_ok || halo2_ok) {
         a.tiles_n = cdiv(d->Cout, 128);
         const dim3 hgrid((unsigned)(d->N * (d->Hin / 8) * (d->Win / 16) * a.tiles_n));
 #define FAVAE_LAUNCH_HALO_K(X, KS)                                                                            \

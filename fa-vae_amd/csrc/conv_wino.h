@@ -1,0 +1,452 @@
+// Dense 3x3 stride-1 pad-1 convolution (forward and data gradient) as Winograd F(2x2, 3x3) on the split-precision matrix pipe
+// (included by conv.hip; scheme h3 = two scaled fp16 planes, 3 x v_mfma_f32_32x32x16_f16 per fp32 product block).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 2x2 output tile and (ci, co) pair: 16 multiplies instead of 36
+//
+// so the matrix pipe -- the power-bound resource of the direct kernels (profiles/r03_pmc_conv.md) -- does 4/9 of the multiplies
+// of conv3x3_halo_sp_kernel.  The transforms run in fp32 BEFORE the operand split (B^T d B and G g G^T are sums of <= 4 / 9 fp32
+// terms), the 16 element-wise products are 16 independent GEMMs over ci with fp32 accumulation, and A^T M A is an fp32 sum of 9
+// accumulators: measured against fp64 the result is within 2x of the direct h3 kernel's operand-rounding error and below the
+// fp32 accumulation rounding both share (tests/test_gpu_ops.py precision table).
+//
+// Workgroup = 16 x 16 output pixels (8 x 8 Winograd tiles = the 64 rows of two MFMA row blocks) x 64 output channels, 8 waves, two per
+// SIMD with 256 registers each: wave (b, c) owns the four Winograd positions (a, b), a = 0..3, for the 32 output channels of half c,
+// i.e. the accumulators M[a][b] of 64 tiles x 32 channels (8 x f32x16 = 128 registers).  On this part a SIMD's MFMAs and its other
+// vector instructions do not overlap (tools/experiments/mfma_valu_overlap.hip: time(interleaved) = time(MFMA) + time(FMA), also with
+// two waves per SIMD), so the design minimises matrix + vector instructions per output and uses the second wave only to hide LDS /
+// L2 / barrier latency.  Per 16-channel K chunk:
+//   * the 18 x 18 input halo is loaded ONCE, transformed (fused GroupNorm / SiLU), scaled and staged as fp32 in LDS;
+//   * thread (tile, channel quad, half h) reads three rows of its 4 x 4 patch, forms two rows of B^T d B in registers (packed adds),
+//     splits the 8 positions into (hi, lo) fp16 planes and stores them position-major: V[position][plane][tile][16 k] -- a wave's
+//     fragment reads are contiguous 1 KB runs (conflict-free ds_read_b128);
+//   * the pre-transformed, pre-split weights of a wave's positions and channels are needed by that wave only: they never touch LDS but
+//     stream from L2 straight into MFMA B fragments (fragment-ordered records written by wino_weights_kernel), reloaded in place one
+//     K chunk ahead.
+// Epilogue: the sum over a is taken in registers (t[i][b] = sum_a A^T[i][a] M[a][b]), the waves exchange t through LDS, and
+// thread (co, tile group) finishes y[i][j] = sum_b A^T[j][b] t[i][b] with the bias / residual / statistics epilogues of the
+// direct kernel (64 consecutive channels per pixel: coalesced 256-byte stores).
+// Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, dense tensors, H % 16 == 0, W % 16 == 0, Cin % 16 == 0, Cout % 64 == 0.
+#pragma once
+
+#include "split_planes.h"
+
+namespace wino {
+constexpr int HP = 18;                        // halo pixels per side
+constexpr int RAWP = 80;                      // bytes per staged halo pixel: 16 channels fp32 + 16 B (patch reads of every other tile
+                                              // of a tile row cover the 16 slots of a 256-byte bank row exactly once)
+constexpr int RAW_B = HP * HP * RAWP;         // 25920
+constexpr int VPL = 64 * 32;                  // bytes per (position, plane): 64 tiles x 16 k fp16
+constexpr int V_B = 16 * 2 * VPL;             // 65536 per K chunk
+constexpr int AFF_C = 512;                    // fused GroupNorm: (scale, shift) of up to 512 input channels staged in LDS
+constexpr int LDS_B = 2 * V_B + RAW_B + 2 * AFF_C * 4;   // 161088 of the 160 KB (163840)
+constexpr int UCH = 16 * 1024;                // weight bytes per (co tile of 64, K chunk, column b): [a][co block][plane][lane][16 B]
+constexpr float HEAD = 0.25f;                 // |B^T d B| <= 4 max|d|, |G g G^T| <= 2.25 max|g|: two more bits of fp16 head room
+
+// (hi, lo) fp16 planes of four values (already scaled), stored VPL apart.  hi = rne(t) as a packed pair; the residual t - hi comes from
+// one mixed-precision FMA per value (v_fma_mix_f32: the f16 half of the pair x -1 + the fp32 value, exact) -- 8 vector instructions
+// per four values (the compiler's own lowering of the same expression converts every hi twice: 16).
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float minus_lo_half(unsigned h, float v) {      // v - (float)h.lo
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    return r;
+}
+__device__ __forceinline__ float minus_hi_half(unsigned h, float v) {      // v - (float)h.hi
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    return r;
+}
+__device__ __forceinline__ void split_store(unsigned char* dst, const float4 t) {
+    const unsigned h01 = cvt_pk_f16(t.x, t.y), h23 = cvt_pk_f16(t.z, t.w);
+    const unsigned l01 = cvt_pk_f16(minus_lo_half(h01, t.x), minus_hi_half(h01, t.y));
+    const unsigned l23 = cvt_pk_f16(minus_lo_half(h23, t.z), minus_hi_half(h23, t.w));
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+    *reinterpret_cast<uint2*>(dst + VPL) = make_uint2(l01, l23);
+}
+__device__ __forceinline__ float4 sub4(const float4 p, const float4 q) { return make_float4(p.x - q.x, p.y - q.y, p.z - q.z, p.w - q.w); }
+__device__ __forceinline__ float4 add4(const float4 p, const float4 q) { return make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w); }
+}  // namespace wino
+
+// w: OHWI fp32 [Cout][3][3][Cin].  Logical conv of this record buffer: O output channels, I input channels,
+//   FLIP = false: O = Cout, I = Cin,  g[o][kh][kw][i] = w[o][kh][kw][i]            (forward)
+//   FLIP = true : O = Cin,  I = Cout, g[o][kh][kw][i] = w[i][2 - kh][2 - kw][o]    (data gradient)
+// out (behind the header): U = G g G^T scaled by S_U = HEAD * 2^(14 - floor(log2 max|w|)), split into (hi, lo) fp16 planes, in MFMA
+// B-fragment order: [o / 64][i / 16][b][a][(o / 32) & 1][plane][lane = (o & 31) + 32 ((i / 8) & 1)][8 k].  One thread per (o, 8 i).
+template <bool FLIP>
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, int Cout, int Cin,
+                                                           const float* __restrict__ amax, float* __restrict__ hdr_out, int vec) {
+    const int O = FLIP ? Cin : Cout, I = FLIP ? Cout : Cin;
+    const int I8 = I / 8;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (hdr_out && idx == 0) *hdr_out = *amax;
+    if (idx >= O * I8) return;
+    // FLIP: consecutive threads -> consecutive o (= ci, contiguous in w); else consecutive 8-channel groups of i
+    const int o = FLIP ? idx % O : idx / I8, i8 = FLIP ? idx / O : idx % I8;
+    const float S = sp::pow2_scale(amax) * wino::HEAD;
+    float g[3][3][8];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            if constexpr (FLIP) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[kh][kw][e] = w[(((size_t)(i8 * 8 + e) * 3 + (2 - kh)) * 3 + (2 - kw)) * Cin + o] * S;
+            } else if (!vec) {                     // w not 16-byte aligned (a view into a flat parameter buffer)
+                const float* p = w + (((size_t)o * 3 + kh) * 3 + kw) * Cin + i8 * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[kh][kw][e] = p[e] * S;
+            } else {
+                const float4* p = reinterpret_cast<const float4*>(w + (((size_t)o * 3 + kh) * 3 + kw) * Cin + i8 * 8);
+                const float4 u = p[0], v = p[1];
+                g[kh][kw][0] = u.x * S; g[kh][kw][1] = u.y * S; g[kh][kw][2] = u.z * S; g[kh][kw][3] = u.w * S;
+                g[kh][kw][4] = v.x * S; g[kh][kw][5] = v.y * S; g[kh][kw][6] = v.z * S; g[kh][kw][7] = v.w * S;
+            }
+        }
+    const int KC = I / 16;
+    const int ct = o >> 6, cb = (o >> 5) & 1, ln = (o & 31) + 32 * (i8 & 1), kc = i8 >> 1;
+    unsigned char* base = out + (size_t)(ct * KC + kc) * (4 * wino::UCH) + cb * 2048 + ln * 16;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float t[3][8];                          // row a of G g: G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                t[kw][e] = a == 0 ? g[0][kw][e] : a == 3 ? g[2][kw][e]
+                         : a == 1 ? 0.5f * (g[0][kw][e] + g[1][kw][e] + g[2][kw][e]) : 0.5f * (g[0][kw][e] - g[1][kw][e] + g[2][kw][e]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            _Float16 hi[8], lo[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float u = b == 0 ? t[0][e] : b == 3 ? t[2][e]
+                              : b == 1 ? 0.5f * (t[0][e] + t[1][e] + t[2][e]) : 0.5f * (t[0][e] - t[1][e] + t[2][e]);
+                hi[e] = (_Float16)u;
+                lo[e] = (_Float16)(u - (float)hi[e]);
+            }
+            unsigned char* d = base + (size_t)b * wino::UCH + a * 4096;
+            *reinterpret_cast<half8_t*>(d) = half8_t{hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+            *reinterpret_cast<half8_t*>(d + 1024) = half8_t{lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]};
+        }
+    }
+}
+
+// GB: GroupNorm-backward partial sums in the epilogue; SE: per-tile (sum y, sum y^2) + max|y| of the output (as conv3x3_halo_sp_kernel)
+template <int XFORM, bool GB, bool SE, int DBG = 0>
+__global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
+    static_assert(!GB || XFORM == 0, "GroupNorm-backward sums: plain data gradient");
+    static_assert(!(GB && SE), "one statistics epilogue at a time");
+    using namespace wino;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
+    unsigned char* Vs = wlds;                      // [2][16 positions][2 planes][64 tiles][32 B]
+    unsigned char* Rs = wlds + 2 * V_B;            // [324 halo pixels][RAWP]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);             // scalar: enters buffer soffsets and uniform branches
+    const int wb = wid & 3, wc = wid >> 2;                                // matrix role: Winograd column b, output-channel half c
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % a.tiles_n;
+    int spt = tile / a.tiles_n;
+    const int tiles_w = a.Wout / 16, tiles_h = a.Hout / 16;
+    const int tx0 = (spt % tiles_w) * 16; spt /= tiles_w;
+    const int ty0 = (spt % tiles_h) * 16;
+    const int n = spt / tiles_h;
+    const int n0 = tn * 64;
+    const int q4 = tid & 3;
+    const float Sa = sp::pow2_scale(a.x_amax) * HEAD;
+
+    const auto rx = make_rsrc(a.x, a.x_bytes);
+    const auto rw = make_rsrc(a.w, a.w_bytes);
+    float* Aff = reinterpret_cast<float*>(wlds + 2 * V_B + RAW_B);      // [2][AFF_C]: scale, shift of this image's input channels
+    if (XFORM) {                                   // read back per chunk at staging time: no registers held across the K loop
+        if (tid < a.Cin) {
+            Aff[tid] = a.scale[n * a.aff_stride + tid];
+            Aff[AFF_C + tid] = a.shift[n * a.aff_stride + tid];
+        }
+    }
+
+    // halo staging slots of this thread (324 pixels x 4 channel quads = 1296 float4 over 512 threads: two full rounds + 272 threads)
+    unsigned vh[3];
+    int ro[3];
+    bool hok[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int i = tid + 512 * j;
+        const int hrow = i >> 2;
+        const int hy = hrow / HP, hx = hrow - hy * HP;
+        const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+        hok[j] = hrow < HP * HP && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
+        vh[j] = hok[j] ? (unsigned)(((n * a.in_img + y * a.in_row + x) * a.Cin + q4 * 4) * 4) : FAVAE_OOB;
+        ro[j] = hrow * RAWP + q4 * 16;
+    }
+    float4 rg[3];
+    auto load_raw = [&](int kc) {
+        const unsigned sk = (unsigned)(kc * 64);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rg[j] = bload(rx, vh[j], sk);
+    };
+    auto store_raw = [&](int kc) {                  // kc = the chunk rg holds
+        float4 rsc = make_float4(0.f, 0.f, 0.f, 0.f), rsh = rsc;
+        if (XFORM) {
+            rsc = *reinterpret_cast<const float4*>(Aff + kc * 16 + q4 * 4);
+            rsh = *reinterpret_cast<const float4*>(Aff + AFF_C + kc * 16 + q4 * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float4 t = xform4_t<XFORM>(rg[j], rsc, rsh, a.act);
+            if (XFORM && !hok[j]) t = make_float4(0.f, 0.f, 0.f, 0.f);       // padding stays exactly zero behind the transform
+            t = make_float4(t.x * Sa, t.y * Sa, t.z * Sa, t.w * Sa);
+            if (j < 2 || tid < 272) *reinterpret_cast<float4*>(Rs + ro[j]) = t;
+        }
+    };
+
+    // transform item of this thread: Winograd tile (tty, ttx) of the 8 x 8, channel quad q4, half th = rows (2 th, 2 th + 1) of
+    // B^T d B.  The lanes of one ds_read_b128 service group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32: MI355X_MICROARCH.md) take
+    // every other tile of one tile row: with the 80-byte pixel pitch their 16 reads fall on the 16 slots of the bank row.
+    const int th = wc;
+    const int lk = lane >> 2;
+    const int tig = (lk & 7) >> 1, lg = ((lk >> 3) << 1) | (__builtin_popcount(lk & 7) & 1);
+    const int ttx = 2 * tig + (lg & 1), tty = 2 * wb + (lg >> 1), tt = tty * 8 + ttx;
+    const unsigned char* rbase = Rs + ((tty * 2 + th) * HP + ttx * 2) * RAWP + q4 * 16;      // patch rows th, th + 1, th + 2
+    unsigned char* vbase = Vs + tt * 32 + q4 * 8;
+    float4 pr[3][4];
+    auto read_patch = [&]() {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pr[r][c] = *reinterpret_cast<const float4*>(rbase + (r * HP + c) * RAWP);
+    };
+    // B^T d (along y): th = 0: rows (d0 - d2, d1 + d2); th = 1: rows (d1 - d3, d2 - d1) = with (p, q, s) the three rows read:
+    // X = p - s is position row (th ? 3 : 0), O = th ? q - p : q + s is position row (th ? 2 : 1); then . B (along x), split, store
+    auto transform = [&](int buf) {
+        float4 X[4], O[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) X[c] = sub4(pr[0][c], pr[2][c]);
+        if (th) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) O[c] = sub4(pr[1][c], pr[0][c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) O[c] = add4(pr[1][c], pr[2][c]);
+        }
+        unsigned char* vx = vbase + buf * V_B + (th ? 3 : 0) * 4 * 2 * VPL;
+        unsigned char* vo = vbase + buf * V_B + (th ? 2 : 1) * 4 * 2 * VPL;
+        split_store(vx + 0 * 2 * VPL, sub4(X[0], X[2]));
+        split_store(vx + 1 * 2 * VPL, add4(X[1], X[2]));
+        split_store(vx + 2 * 2 * VPL, sub4(X[2], X[1]));
+        split_store(vx + 3 * 2 * VPL, sub4(X[1], X[3]));
+        split_store(vo + 0 * 2 * VPL, sub4(O[0], O[2]));
+        split_store(vo + 1 * 2 * VPL, add4(O[1], O[2]));
+        split_store(vo + 2 * 2 * VPL, sub4(O[2], O[1]));
+        split_store(vo + 3 * 2 * VPL, sub4(O[1], O[3]));
+    };
+
+    // fragments: A = V[position (ar, wb)][plane][row block][32 tiles][16 k], B = this wave's weight records (co block wc)
+    const unsigned char* Afr = Vs + wb * 2 * VPL + (lane & 31) * 32 + (lane >> 5) * 16;
+    const unsigned vw = (unsigned)(lane * 16);
+    const int KC = a.Cin / 16, KL = KC - 1;
+    half8_t bfr[4][2];
+    auto load_b = [&](int kc, int ar) {
+        const unsigned so = (unsigned)(((tn * KC + kc) * 4 + wb) * UCH + ar * 4096 + wc * 2048);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) bfr[ar][pl] = __builtin_bit_cast(half8_t, bload(rw, vw, so + (unsigned)(pl * 1024)));
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ar][rb][r] = 0.f;
+    auto mma = [&](int buf, int ar) {               // smallest terms first; the two row blocks alternate between dependent MFMAs
+        half8_t af[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                af[rb][pl] = *reinterpret_cast<const half8_t*>(Afr + buf * V_B + (ar * 4 * 2 + pl) * VPL + rb * 1024);
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) {
+            const int pa = p3 == 0 ? 1 : 0, pb = p3 == 1 ? 1 : 0;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+                acc[ar][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rb][pa], bfr[ar][pb], acc[ar][rb], 0, 0, 0);
+        }
+    };
+
+    // prologue: V[0] <- chunk 0, raw LDS <- chunk 1, registers <- loads of chunk 2, weights of chunk 0 (chunk indices clamped to KL)
+    load_raw(0);
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar) load_b(0, ar);
+    if (XFORM) __syncthreads();                     // (scale, shift) staged
+    store_raw(0);
+    load_raw(KL < 1 ? KL : 1);
+    __syncthreads();
+    read_patch();
+    transform(0);
+    __syncthreads();
+    store_raw(KL < 1 ? KL : 1);
+    load_raw(KL < 2 ? KL : 2);
+    __syncthreads();
+
+    // Every iteration is the same straight-line code (the last one transforms a clamped chunk nobody reads).  At the top: V[buf] =
+    // chunk kc, raw LDS = chunk kc + 1, rg = loads of chunk kc + 2, bfr = weights of chunk kc.
+    for (int kc = 0; kc < KC; ++kc) {
+        const int buf = kc & 1, kn = kc < KL ? kc + 1 : KL;
+        if (DBG != 2) read_patch();
+        if (DBG != 1) mma(buf, 0);
+        if (DBG != 5) load_b(kn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (DBG != 3) __syncthreads();              // every wave has its patch of chunk kc + 1: the raw tile may be overwritten
+        __builtin_amdgcn_sched_barrier(0);
+        if (DBG != 6) store_raw(kc + 2 < KL ? kc + 2 : KL);
+        if (DBG != 6) load_raw(kc + 3 < KL ? kc + 3 : KL);
+        if (DBG != 2) transform(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ar = 1; ar < 4; ++ar) {
+            if (DBG != 1) mma(buf, ar);
+            if (DBG != 5) load_b(kn, ar);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (DBG != 3) __syncthreads();
+        if (DBG == 1) {                              // keep the operands alive
+#pragma unroll
+            for (int ar = 0; ar < 4; ++ar) asm volatile("" ::"v"(bfr[ar][0]), "v"(bfr[ar][1]));
+        }
+    }
+    if (DBG == 4) {                                  // no epilogue: one store keeps the accumulators alive
+        float sacc = 0.f;
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) sacc += acc[ar][rb][0];
+        if (sacc == 12345.678f) a.y[tid] = sacc;
+        return;
+    }
+
+    // ---- epilogue: t[i][wb] = sum_a A^T[i][a] M[a][wb] in registers (A^T = [[1,1,1,0],[0,1,-1,-1]]), exchanged through LDS.
+    // Thread (co = lane, tile group wid) then finishes 8 tiles x 2 x 2 outputs; a wave stores 64 consecutive channels of one pixel
+    // (256 bytes).  Offsets are scalar per pixel (buffer soffset) + one constant voffset: no 64-bit address arithmetic.
+    const float un = sp::pow2_inv(Sa) * sp::pow2_inv(sp::pow2_scale(a.w_amax) * HEAD);
+    const int col = n0 + lane;
+    const unsigned ybytes = (unsigned)((size_t)a.N * a.out_img * a.Cout * 4);
+    const auto ry = make_rsrc(a.y, ybytes);
+    const unsigned vcol = (unsigned)(col * 4);
+    const unsigned pix0 = (unsigned)(n * a.out_img + (ty0 + wid * 2) * a.out_row + tx0);     // first pixel of this wave's tile row
+    const unsigned rowb = (unsigned)(a.out_row * a.Cout * 4), pxb = (unsigned)(a.Cout * 4);
+    auto pix_off = [&](int q, int i, int j) { return pix0 * pxb + (unsigned)i * rowb + (unsigned)(q * 2 + j) * pxb; };
+    // The residual (forward) or the GroupNorm input x (GB data gradient) of all 32 outputs is loaded HERE, before the exchange and
+    // before any store: vmcnt counts stores too, so a load issued behind a store waits for that store's acknowledgement.
+    const bool has_res = a.resid != nullptr;
+    const auto rpre = make_rsrc(GB ? (const void*)a.gb_x : (has_res ? (const void*)a.resid : (const void*)a.y), (GB || has_res) ? ybytes : 0u);
+    float pre[8][2][2];
+    if (GB || has_res) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    pre[q][i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rpre, vcol, pix_off(q, i, j), 0));
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pre[q][0][0] = pre[q][0][1] = pre[q][1][0] = pre[q][1][1] = 0.f;
+    }
+    float* Ts = reinterpret_cast<float*>(wlds);     // [2 i][4 b][64 tiles][64 co]
+    {
+        float* tw = Ts + (wb * 64 + 4 * (lane >> 5)) * 64 + wc * 32 + (lane & 31);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m0 = acc[0][rb][r], m1 = acc[1][rb][r], m2 = acc[2][rb][r], m3 = acc[3][rb][r];
+                const int off = (rb * 32 + (r & 3) + 8 * (r >> 2)) * 64;
+                tw[off] = (m0 + m1) + m2;
+                tw[4 * 64 * 64 + off] = (m1 - m2) - m3;
+            }
+    }
+    __syncthreads();
+
+    const float bv = a.bias ? a.bias[col] : 0.f;
+    float g_mu = 0.f, g_rs = 0.f, g_ga = 0.f, g_be = 0.f;
+    if constexpr (GB) {
+        const int grp = col / (a.Cout / a.gb_groups);
+        g_mu = a.gb_mean[n * a.gb_groups + grp];
+        g_rs = a.gb_rstd[n * a.gb_groups + grp];
+        g_ga = a.gb_gamma[col];
+        g_be = a.gb_beta[col];
+    }
+    double gs1 = 0.0, gs2 = 0.0;
+    float se_amax = 0.f;
+    const float* tr = Ts + (wid * 8) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                   // tile (wid, q) of the workgroup
+        float v[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* tp = tr + (i * 4 * 64 + q) * 64;
+            const float t0 = tp[0], t1 = tp[64 * 64], t2v = tp[2 * 64 * 64], t3 = tp[3 * 64 * 64];
+            v[i][0] = (t0 + t1) + t2v;
+            v[i][1] = (t1 - t2v) - t3;
+        }
+        float f1 = 0.f, f2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float y = fmaf(v[i][j], un, bv);
+                if constexpr (!GB) y += pre[q][i][j];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), ry, vcol, pix_off(q, i, j), 0);
+                if constexpr (GB) {
+                    const float xh = (pre[q][i][j] - g_mu) * g_rs;
+                    const float dyv = y * favae_act_grad(fmaf(xh, g_ga, g_be), a.gb_act);
+                    f1 += dyv;
+                    f2 = fmaf(dyv, xh, f2);
+                }
+                if constexpr (SE) {
+                    gs1 += (double)y;
+                    gs2 += (double)y * (double)y;
+                    se_amax = fmaxf(se_amax, fabsf(y));
+                }
+            }
+        if constexpr (GB) { gs1 += (double)f1; gs2 += (double)f2; }
+    }
+    if constexpr (GB || SE) {
+        // fixed summation order: 32 outputs per thread, then the eight tile-row waves -> one (S1, S2) pair per channel of this tile
+        double* red = reinterpret_cast<double*>(wlds + 2 * V_B);          // [8 waves][64 channels][2], behind the t arrays
+        red[(wid * 64 + lane) * 2] = gs1;
+        red[(wid * 64 + lane) * 2 + 1] = gs2;
+        if constexpr (SE) {
+            if (a.gs_amax) {
+                float* wmx = reinterpret_cast<float*>(wlds + 2 * V_B + 8 * 64 * 2 * sizeof(double));
+                se_amax = wave_max(se_amax);
+                if (lane == 0) wmx[wid] = se_amax;
+            }
+        }
+        __syncthreads();
+        if constexpr (SE) {
+            if (a.gs_amax && tid == 0) {
+                const float* wmx = reinterpret_cast<const float*>(wlds + 2 * V_B + 8 * 64 * 2 * sizeof(double));
+                float m = wmx[0];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) m = fmaxf(m, wmx[w]);
+                atomicMax(a.gs_amax, __float_as_uint(m));
+            }
+        }
+        if (tid < 64) {
+            double u = 0.0, w2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { u += red[(q * 64 + tid) * 2]; w2 += red[(q * 64 + tid) * 2 + 1]; }
+            const int tpi = tiles_w * tiles_h;
+            const int ti = (ty0 / 16) * tiles_w + tx0 / 16;
+            double* out = (GB ? a.gb_part : a.gs_part) + (((size_t)n * tpi + ti) * a.Cout + n0 + tid) * 2;
+            out[0] = u;
+            out[1] = w2;
+        }
+    }
+}

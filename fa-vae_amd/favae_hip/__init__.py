@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FAVAE_HIP_LIB") or os.path.join(_HERE, "libfavae_hip.so")     # FAVAE_HIP_LIB: same-box A/B of two builds
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02, ACT_RELU = 0, 1, 2, 3
@@ -124,6 +124,10 @@ SIGNATURES = {
     "favae_conv_wgrad_slabs": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, POINTER(c_int), _S]),
     "favae_reduce_slabs_grouped": (c_int, [POINTER(ReduceJob), c_int, _S]),
     "favae_split_weights_amax": (c_int, [_P, _P, c_int64, c_int, _P, _S]),
+    "favae_conv_wino_ok": (c_int, [_P, c_int]),
+    "favae_set_wino": (c_int, [c_int]),
+    "favae_wino_weights_bytes": (c_size_t, [c_int, c_int]),
+    "favae_wino_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P, _S]),
     "favae_segment_absmax": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _S]),
     "favae_prof_enable": (c_int, [c_int]),
     "favae_prof_reset": (c_int, []),

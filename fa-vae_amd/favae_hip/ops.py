@@ -221,6 +221,8 @@ def _fp16_planes():
 
 
 _WREC = {1: 8, 2: 16, 3: 24, 4: 8}    # bytes of one pre-split record (4 weights) per scheme id
+_WINO_FLIP_FWD = os.environ.get("FAVAE_WINO_FLIP_FWD", "1") != "0"
+PLANES_WINO = 0x100                   # include/favae_hip.h FAVAE_PLANES_WINO: the records are Winograd records (favae_wino_weights)
 CONV_MODES = {"fp32": 0, "h1": 1, "h3": 2, "b6": 3, "b1": 4}
 
 
@@ -482,8 +484,15 @@ def _bias_grad_and_range(dy, p_b, need_b, want_range, M, Cout, dev):
     return db, dyb
 
 
+def _wino_records(w, co, ci, flip, w_amax):
+    """Winograd weight records of the OHWI tensor w (csrc/conv_wino.h): flip = 0 forward conv, 1 its data gradient."""
+    wsp = torch.empty(query("favae_wino_weights_bytes", co, ci), dtype=torch.uint8, device=w.device)
+    call("favae_wino_weights", ptr(w), ptr(wsp), co, ci, flip, ptr(w_amax))
+    return wsp
+
+
 def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=None, planes_out=None, gnbwd=None, stats_out=None,
-                 y_amax=None):
+                 y_amax=None, wino_rec=None):
     """conv forward / data gradient.  When the library runs this shape on the split-precision matrix path the weights are
     pre-split once per call (instead of once per tile in the K loop); the fp16 scheme (2 planes) also needs the operand
     range: `x_bound` = device scalar >= max|T(x)| (computed here for an un-transformed operand when not supplied).
@@ -492,7 +501,24 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
     Returns the device float holding max|w| when pre-split records were made (fp16 scheme), else None."""
     planes = query("favae_conv_wants_split_weights", byref(d), 0 if scale is None else 1)
     w_amax = None
-    if planes:
+    if planes == 2 and planes_out is None and query("favae_conv_wino_ok", byref(d), 0 if scale is None else 1):
+        # dense 3x3 conv of the h3 scheme: Winograd F(2x2, 3x3) kernel, records = G g G^T in fragment order (csrc/conv_wino.h)
+        if wino_rec is not None:                 # made by the forward pass (FusedConvFn.forward)
+            wsp = wino_rec
+        else:
+            if flip_of is not None:
+                w, co, kh, kw, ci, w_amax = flip_of
+                flip = 1
+            else:
+                w, co, ci, flip = w_ohwi, d.Cout, d.Cin, 0        # OHWI memory, whatever the logical shape
+            if w_amax is None:
+                w_amax = _weight_amax(w)
+            wsp = _wino_records(w, co, ci, flip, w_amax)
+        w_amax = wsp[:4].view(torch.float32)
+        planes |= PLANES_WINO
+    if planes & PLANES_WINO:
+        pass
+    elif planes:
         if flip_of is not None and (planes in (3, 4) or flip_of[5] is not None) and os.environ.get("FAVAE_FLIP_SPLIT", "1") != "0":
             w, co, kh, kw, ci, w_amax = flip_of
             n = w.numel()
@@ -510,7 +536,8 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
                 call("favae_split_weights", ptr(w_ohwi), ptr(wsp), n, planes)
             if planes in (1, 2):
                 w_amax = wsp[:4].view(torch.float32)          # header of the record buffer (keeps the buffer alive while saved)
-        if planes in (1, 2) and x_bound is None:
+    if planes:
+        if (planes & 0xFF) in (1, 2) and x_bound is None:
             if scale is not None:
                 raise RuntimeError("a transformed conv operand needs its range bound (gn_stats(with_bound=True))")
             x_bound = absmax(x)
@@ -601,6 +628,14 @@ class FusedConvFn(torch.autograd.Function):
         if st_part is not None:
             y._favae_gnstats = (st_part, st_tiles, y._version)
             y._favae_amax = (y_amax, y._version)
+        # Winograd records of the data gradient, made HERE: in the backward pass this small kernel would sit on the critical chain
+        # next to the weight-gradient stream (measured 72 us per layer there against 9 us alone)
+        ctx.wflip = None
+        if (_WINO_FLIP_FWD and w_amax is not None and cfg.stride == 1 and not cfg.upsample and cfg.kh == 3
+                and (ctx.needs_input_grad[0] or gn_w is not None)):
+            d2 = make_conv_desc(N, Ho, Wo, Cout, Hin, Win, Cin, cfg.kh, cfg.kw, 1, cfg.kh - 1 - cfg.pad, GATHER_PLAIN, ACT_NONE, 1)
+            if query("favae_conv_wants_split_weights", byref(d2), 0) == 2 and query("favae_conv_wino_ok", byref(d2), 0):
+                ctx.wflip = _wino_records(wk, Cout, Cin, 1, w_amax)
         ctx.cfg = cfg
         ctx.has_b = b is not None
         ctx.has_gn = gn_w is not None
@@ -729,7 +764,7 @@ class FusedConvFn(torch.autograd.Function):
                     # experiment: the dense data gradient starts only after the weight gradient of the layer behind it has retired
                     torch.cuda.current_stream().wait_stream(_SIDE["stream"])
                 _conv_launch(d2, dy, None, None, None, None, None, da, dyb, flip_of=(wk, Cout, cfg.kh, cfg.kw, Cin, w_amax),
-                             planes_out=dys, gnbwd=gnb)
+                             planes_out=dys, gnbwd=gnb, wino_rec=ctx.wflip if dys is None else None)
             if run_wgrad is not None:
                 run_wgrad(dys)
                 run_wgrad = None

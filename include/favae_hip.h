@@ -110,6 +110,18 @@ int favae_split_weights(const float* in, void* out, int64_t n, int planes, favae
 int favae_split_weights_amax(const float* in, void* out, int64_t n, int planes, const float* amax, favae_stream_t stream);
 int favae_segment_absmax(const float* x, const int64_t* seg_off, int nseg, const int* chunk_seg, const int64_t* chunk_first, int nchunks,
                          float* out, favae_stream_t stream);
+/* Winograd F(2x2, 3x3) for the dense 3x3 stride-1 convs of the h3 scheme (csrc/conv_wino.h): the matrix pipe does 4/9 of the multiplies
+ * of the direct kernel; transforms in fp32, products on two scaled fp16 planes, fp32 accumulation and output transform.
+ * favae_conv_wino_ok(d, has_affine) = 1 when favae_conv_fwd_split / _stats / favae_conv_dgrad_gnbwd run d on that kernel: the caller
+ * then passes records made by favae_wino_weights (favae_wino_weights_bytes(Cout, Cin) bytes) and planes = 2 | FAVAE_PLANES_WINO; the
+ * tile counts of favae_conv_stats_tiles / favae_conv_gnbwd_tiles are that kernel's (16 x 16 pixels).  favae_wino_weights: w = OHWI fp32
+ * [Cout][3][3][Cin]; flip = 0 -> records of the forward conv, flip = 1 -> of its data gradient (Cin outputs, taps flipped);
+ * amax = device float max|w| or NULL (computed).  FAVAE_WINO=0 in the environment keeps every conv on the direct kernels. */
+#define FAVAE_PLANES_WINO 0x100
+int favae_conv_wino_ok(const favae_conv_desc* d, int has_affine);
+int favae_set_wino(int on);            /* run-time override of FAVAE_WINO; returns the previous setting */
+size_t favae_wino_weights_bytes(int Cout, int Cin);
+int favae_wino_weights(const float* w, void* out, int Cout, int Cin, int flip, const float* amax, favae_stream_t stream);
 int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, const void* wsplit, int planes, const float* x_absmax,
                          const float* bias, const float* resid, const float* scale, const float* shift, float* y,
                          favae_stream_t stream);

@@ -272,6 +272,58 @@ def test_split_precision_is_fp32_grade_against_fp64(K):
         open(os.path.join(out, "r03_precision.txt"), "w").write(text + "\n")
 
 
+@pytest.mark.parametrize("cin,cout,hw", [(128, 128, 32), (256, 128, 16), (128, 256, 48)])
+def test_winograd_conv_path_matches_direct_kernels(K, cin, cout, hw):
+    """The Winograd F(2x2, 3x3) kernel (csrc/conv_wino.h) behind the dense 3x3 convs of the h3 scheme against the direct LDS-halo kernel
+    it replaces (favae_set_wino(0)) and against fp64: two stacked ResnetBlocks -- GroupNorm+SiLU fused forward with the statistics /
+    max|y| epilogue feeding the next GroupNorm and the next plain conv, residual add, data gradient with the GroupNorm-backward sums
+    epilogue -- outputs and every gradient.  Both paths are fp32-grade, so they agree to a few 1e-6 of the tensor's rms; the Winograd
+    path must not be further from fp64 than 1.5x the direct path (+1e-7)."""
+    from models import codec as C
+    import favae_hip as H
+    torch.manual_seed(5)
+    blocks = torch.nn.Sequential(C.ResnetBlock(cin, cout, 0.0), C.ResnetBlock(cout, cout, 0.0))
+    x = torch.randn(2, cin, hw, hw)
+    gy = torch.randn(2, cout, hw, hw)
+    def ref_block(m, t):
+        b = m.block
+        h = F.conv2d(F.silu(F.group_norm(t, 32, b[0].weight.double(), b[0].bias.double(), eps=b[0].eps)), b[2].weight.double(),
+                     b[2].bias.double(), padding=1)
+        h = F.conv2d(F.silu(F.group_norm(h, 32, b[3].weight.double(), b[3].bias.double(), eps=b[3].eps)), b[6].weight.double(),
+                     b[6].bias.double(), padding=1)
+        if m.has_shortcut:
+            t = F.conv2d(t, m.shortcut.weight.double(), m.shortcut.bias.double())
+        return t + h
+    names = [k for k, _ in blocks.named_parameters()]
+    xr = x.double().requires_grad_(True)
+    yr = ref_block(blocks[1], ref_block(blocks[0], xr))
+    gr = torch.autograd.grad(yr, [xr] + list(blocks.parameters()), gy.double(), allow_unused=True)
+    blocks.to(dev())
+
+    def run(wino):
+        prev = H.query("favae_set_wino", 1 if wino else 0)
+        try:
+            xd = x.to(dev()).requires_grad_(True)
+            y = blocks(xd)
+            g = torch.autograd.grad(y, [xd] + list(blocks.parameters()), gy.to(dev()))
+            K.sync_side_stream()
+            torch.cuda.synchronize()
+        finally:
+            H.query("favae_set_wino", prev)
+        return [y.detach().double().cpu()] + [t.double().cpu() for t in g]
+    if not H.query("favae_set_wino", 1):
+        H.query("favae_set_wino", 0)
+        pytest.skip("Winograd path switched off (FAVAE_WINO=0)")
+    a, b = run(True), run(False)
+    refs = [yr.detach()] + [t for t in gr]
+    for nm, u, v, r in zip(["y", "dx"] + ["d" + n for n in names], a, b, refs):
+        rms = float(r.pow(2).mean().sqrt())
+        eu, ev = float((u - r).pow(2).mean().sqrt()) / rms, float((v - r).pow(2).mean().sqrt()) / rms
+        assert eu <= 1.5 * ev + 1e-7, "%s: Winograd path %.2e from fp64, direct path %.2e" % (nm, eu, ev)
+        assert float((u - v).abs().max()) <= 2e-5 * float(r.abs().max()), "%s: paths differ by %.2e of the maximum" % (
+            nm, float((u - v).abs().max()) / float(r.abs().max()))
+
+
 BLOCK_DIMS = {"res_same": ("res", (64, 64)), "res_short": ("res", (32, 96)), "nonres": ("nonres", (64, 64)),
               "nonres_g4": ("nonres4", (8, 8)), "attn": ("attn", (64,)), "down": ("down", (32,)), "down_odd": ("down", (32,)),
               "up": ("up", (32,))}
