@@ -265,22 +265,23 @@ def test_side_stream_weight_gradients_are_race_free(mtag, hw):
     # equal to the default path to rounding -- the default weight gradient is the nine-tap kernel since round 3, which sums the
     # pixels in another order (column strips instead of image rows).  (The GroupNorm-backward sums of the data-gradient epilogue
     # are a different summation order than the streaming pass, and a conv uses one or the other: compared with both off.)
-    # (ref2 on the direct kernels as well: the pre-split planes are a by-product of the direct LDS-halo kernel, while the default forward /
+    # (all three on the direct kernels: the pre-split planes are a by-product of the direct LDS-halo kernel, while the default forward /
     # data gradient is the Winograd kernel since round 3 -- another fp32-grade rounding of the forward, which in a model with a
     # quantizer may flip a code index; the Winograd path has its own equivalence test in tests/test_gpu_ops.py)
     import favae_hip as H
     prev_w = H.query("favae_set_wino", 0)
     try:
+        ref1 = grads(False, 0)
         ref2 = grads(False, 0, planes=False, fuse=False)
+        ref3 = grads(False, 0, planes=True, fuse=False)
+        got = grads(True, 400000, planes=True, fuse=False)
     finally:
         H.query("favae_set_wino", prev_w)
-    ref3 = grads(False, 0, planes=True, fuse=False)
-    got = grads(True, 400000, planes=True, fuse=False)
     assert torch.equal(got, ref3), "gradients with pre-split planes differ between one and two streams: %g" % float((got - ref3).abs().max())
     scale = float(ref2.abs().max())
     assert float((ref3 - ref2).abs().max()) < 2e-5 * scale, float((ref3 - ref2).abs().max()) / scale
     # and the two GroupNorm-backward formulations agree to rounding
-    assert float((ref - ref2).abs().max()) < 2e-5 * scale, float((ref - ref2).abs().max()) / scale
+    assert float((ref1 - ref2).abs().max()) < 2e-5 * scale, float((ref1 - ref2).abs().max()) / scale
 
 
 def test_gan_stage1_discriminator_alone_against_reference_golden(golden_dir):
