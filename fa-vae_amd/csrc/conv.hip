@@ -88,13 +88,6 @@ bool use_wino() {
     return g_wino == 1;
 }
 
-// FAVAE_WINO_DBG=1..4: timing ablations of the Winograd data-gradient kernel (wrong results): no MFMA / no transform / no barriers / no epilogue
-int wino_dbg() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FAVAE_WINO_DBG"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
 // FAVAE_CONV_NOBUF=1 disables the buffer-addressed kernels (A/B against the flat-addressed fast kernels)
 bool force_nobuf() {
     static int v = -1;
@@ -1181,32 +1174,24 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         a.tiles_n = d->Cout / 64;
         a.w_bytes = (unsigned)((size_t)d->Cout * d->Cin * 64);
         const dim3 wgrid((unsigned)(d->N * (d->Hin / 16) * (d->Win / 16) * a.tiles_n));
-#define FAVAE_LAUNCH_WINO4(X, GBV, SEV, DBG)                                                                                \
+#define FAVAE_LAUNCH_WINO(X, GBV, SEV)                                                                                      \
     do {                                                                                                                    \
         static bool attr_set = false;                                                                                       \
         if (!attr_set) {                                                                                                    \
-            (void)hipFuncSetAttribute((const void*)conv3x3_wino_sp_kernel<X, GBV, SEV, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)conv3x3_wino_sp_kernel<X, GBV, SEV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       wino::LDS_B);                                                                         \
             attr_set = true;                                                                                                \
         }                                                                                                                   \
-        FAVAE_KLAUNCH((conv3x3_wino_sp_kernel<X, GBV, SEV, DBG>), wgrid, dim3(512), wino::LDS_B, s, a);                     \
+        FAVAE_KLAUNCH((conv3x3_wino_sp_kernel<X, GBV, SEV>), wgrid, dim3(512), wino::LDS_B, s, a);                          \
     } while (0)
-#define FAVAE_LAUNCH_WINO(X, GBV, SEV) FAVAE_LAUNCH_WINO4(X, GBV, SEV, 0)
         if (gb) FAVAE_LAUNCH_WINO(0, true, false);
         else if (stats_part && xf == 0) FAVAE_LAUNCH_WINO(0, false, true);
         else if (stats_part) FAVAE_LAUNCH_WINO(2, false, true);
-        else if (xf == 0 && wino_dbg() == 1) FAVAE_LAUNCH_WINO4(0, false, false, 1);
-        else if (xf == 0 && wino_dbg() == 2) FAVAE_LAUNCH_WINO4(0, false, false, 2);
-        else if (xf == 0 && wino_dbg() == 3) FAVAE_LAUNCH_WINO4(0, false, false, 3);
-        else if (xf == 0 && wino_dbg() == 4) FAVAE_LAUNCH_WINO4(0, false, false, 4);
-        else if (xf == 0 && wino_dbg() == 5) FAVAE_LAUNCH_WINO4(0, false, false, 5);
-        else if (xf == 0 && wino_dbg() == 6) FAVAE_LAUNCH_WINO4(0, false, false, 6);
         else if (xf == 0) FAVAE_LAUNCH_WINO(0, false, false);
         else if (xf == 1) FAVAE_LAUNCH_WINO(1, false, false);
         else if (xf == 2) FAVAE_LAUNCH_WINO(2, false, false);
         else FAVAE_LAUNCH_WINO(3, false, false);
 #undef FAVAE_LAUNCH_WINO
-#undef FAVAE_LAUNCH_WINO4
     } else if (halo_ok || halo2_ok) {
         a.tiles_n = cdiv(d->Cout, 128);
         const dim3 hgrid((unsigned)(d->N * (d->Hin / 8) * (d->Win / 16) * a.tiles_n));

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 }
 
 // GB: GroupNorm-backward partial sums in the epilogue; SE: per-tile (sum y, sum y^2) + max|y| of the output (as conv3x3_halo_sp_kernel)
-template <int XFORM, bool GB, bool SE, int DBG = 0>
+template <int XFORM, bool GB, bool SE>
 __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     static_assert(!GB || XFORM == 0, "GroupNorm-backward sums: plain data gradient");
     static_assert(!(GB && SE), "one statistics epilogue at a time");
@@ -197,9 +197,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            float4 t = xform4_t<XFORM>(rg[j], rsc, rsh, a.act);
-            if (XFORM && !hok[j]) t = make_float4(0.f, 0.f, 0.f, 0.f);       // padding stays exactly zero behind the transform
-            t = make_float4(t.x * Sa, t.y * Sa, t.z * Sa, t.w * Sa);
+            const float4 t0 = xform4_t<XFORM>(rg[j], rsc, rsh, a.act);
+            const float sj = (XFORM && !hok[j]) ? 0.f : Sa;                  // padding stays exactly zero behind the transform (finite values)
+            const float4 t = make_float4(t0.x * sj, t0.y * sj, t0.z * sj, t0.w * sj);
             if (j < 2 || tid < 272) *reinterpret_cast<float4*>(Rs + ro[j]) = t;
         }
     };
@@ -293,40 +293,28 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     load_raw(KL < 2 ? KL : 2);
     __syncthreads();
 
-    // Every iteration is the same straight-line code (the last one transforms a clamped chunk nobody reads).  At the top: V[buf] =
+    // Every iteration is the same straight-line code (the last one transforms a clamped chunk nobody reads: making that conditional
+    // costs 35+ spilled registers).  At the top: V[buf] =
     // chunk kc, raw LDS = chunk kc + 1, rg = loads of chunk kc + 2, bfr = weights of chunk kc.
     for (int kc = 0; kc < KC; ++kc) {
         const int buf = kc & 1, kn = kc < KL ? kc + 1 : KL;
-        if (DBG != 2) read_patch();
-        if (DBG != 1) mma(buf, 0);
-        if (DBG != 5) load_b(kn, 0);
+        read_patch();
+        mma(buf, 0);
+        load_b(kn, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (DBG != 3) __syncthreads();              // every wave has its patch of chunk kc + 1: the raw tile may be overwritten
+        __syncthreads();                            // every wave has its patch of chunk kc + 1: the raw tile may be overwritten
         __builtin_amdgcn_sched_barrier(0);
-        if (DBG != 6) store_raw(kc + 2 < KL ? kc + 2 : KL);
-        if (DBG != 6) load_raw(kc + 3 < KL ? kc + 3 : KL);
-        if (DBG != 2) transform(buf ^ 1);
+        store_raw(kc + 2 < KL ? kc + 2 : KL);
+        load_raw(kc + 3 < KL ? kc + 3 : KL);
+        transform(buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ar = 1; ar < 4; ++ar) {
-            if (DBG != 1) mma(buf, ar);
-            if (DBG != 5) load_b(kn, ar);
+            mma(buf, ar);
+            load_b(kn, ar);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (DBG != 3) __syncthreads();
-        if (DBG == 1) {                              // keep the operands alive
-#pragma unroll
-            for (int ar = 0; ar < 4; ++ar) asm volatile("" ::"v"(bfr[ar][0]), "v"(bfr[ar][1]));
-        }
-    }
-    if (DBG == 4) {                                  // no epilogue: one store keeps the accumulators alive
-        float sacc = 0.f;
-#pragma unroll
-        for (int ar = 0; ar < 4; ++ar)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) sacc += acc[ar][rb][0];
-        if (sacc == 12345.678f) a.y[tid] = sacc;
-        return;
+        __syncthreads();
     }
 
     // ---- epilogue: t[i][wb] = sum_a A^T[i][a] M[a][wb] in registers (A^T = [[1,1,1,0],[0,1,-1,-1]]), exchanged through LDS.

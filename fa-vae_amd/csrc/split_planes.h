@@ -66,17 +66,24 @@ template <> struct Scheme<2> {
     static constexpr bool SCALED = true;
     static constexpr int ROWB = 80;        // 2 planes x 32 B + 16 B pad (20-bank row stride: conflict-free ds_read_b128)
     static constexpr int WREC = 16;        // {plane0[4 fp16], plane1[4]}
+    // hi = rne(a) as a packed pair (v_cvt_pk_f16_f32); the residual a - hi from one mixed-precision FMA per value (v_fma_mix_f32: the
+    // f16 half of the pair x -1 + the fp32 value: exact, the same bits as a - (float)hi) -- 8 vector instructions per four values
+    // behind the scaling; the compiler's own lowering of the C expression converts every hi twice (16).  MFMAs and the other vector
+    // instructions of a SIMD do not overlap on this part (tools/experiments/mfma_valu_overlap.hip): every one saved is matrix time.
     static __device__ __forceinline__ void split4(const float4 v, float S, uint2 (&p)[2]) {
-        const float a[4] = {v.x * S, v.y * S, v.z * S, v.w * S};
-        _Float16 h[4], l[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            h[e] = (_Float16)a[e];                                  // round to nearest
-            l[e] = (_Float16)(a[e] - (float)h[e]);                  // the residual is exact in fp32
-        }
-        const half2_t h01 = {h[0], h[1]}, h23 = {h[2], h[3]}, l01 = {l[0], l[1]}, l23 = {l[2], l[3]};
-        p[0] = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
-        p[1] = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+        const float a0 = v.x * S, a1 = v.y * S, a2 = v.z * S, a3 = v.w * S;
+        unsigned h01, h23, l01, l23;
+        float r0, r1, r2, r3;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h01) : "v"(a0), "v"(a1));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h23) : "v"(a2), "v"(a3));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h01), "v"(a0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h01), "v"(a1));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h23), "v"(a2));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h23), "v"(a3));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l01) : "v"(r0), "v"(r1));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l23) : "v"(r2), "v"(r3));
+        p[0] = make_uint2(h01, h23);
+        p[1] = make_uint2(l01, l23);
     }
     static __device__ __forceinline__ void mma(const bf16x8_t (&a)[2], const bf16x8_t (&b)[2], f32x16& c) {
         const half8_t a0 = __builtin_bit_cast(half8_t, a[0]), a1 = __builtin_bit_cast(half8_t, a[1]);
