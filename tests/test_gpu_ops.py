@@ -324,6 +324,48 @@ def test_winograd_conv_path_matches_direct_kernels(K, cin, cout, hw):
             nm, float((u - v).abs().max()) / float(r.abs().max()))
 
 
+@pytest.mark.parametrize("N,cin,cout,H,W", [(1, 16, 128, 16, 16), (3, 32, 192, 16, 48), (2, 48, 128, 32, 16), (1, 512, 128, 16, 16),
+                                            (2, 64, 320, 48, 32)])
+def test_winograd_conv_shapes_against_direct_kernel(K, N, cin, cout, H, W):
+    """Edge shapes of the Winograd kernel: one / two / three K chunks (Cin = 16, 32, 48), a 32-chunk K loop, non-square images, batch 1
+    and 3, a channel count that is not a power of two (five 64-channel tiles), with bias + residual and with the fused GroupNorm+SiLU
+    (16 groups): forward, data gradient and the gradients that flow through the epilogue by-products, against the direct kernel."""
+    import favae_hip as H_
+    if not H_.query("favae_set_wino", 1):
+        H_.query("favae_set_wino", 0)
+        pytest.skip("Winograd path switched off (FAVAE_WINO=0)")
+    torch.manual_seed(N * 1000 + cin)
+    d = dev()
+    x = torch.randn(N, cin, H, W, device=d)
+    w = (torch.randn(cout, cin, 3, 3, device=d) * math.sqrt(1.0 / (9 * cin)))
+    b = torch.randn(cout, device=d) * 0.1
+    res = torch.randn(N, cout, H, W, device=d)
+    gw, gb = 1 + 0.2 * torch.randn(cin, device=d), 0.2 * torch.randn(cin, device=d)
+    gy = torch.randn(N, cout, H, W, device=d)
+    cfg_gn = K.ConvCfg(3, 3, 1, 1, groups=16)
+    cfg = K.ConvCfg(3, 3, 1, 1)
+
+    def run(wino):
+        prev = H_.query("favae_set_wino", 1 if wino else 0)
+        try:
+            outs = []
+            for gn in (False, True):
+                xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+                y = K.fused_conv(xg, wg, b, gw if gn else None, gb if gn else None, res, cfg_gn if gn else cfg)
+                dx, dw = torch.autograd.grad(y, (xg, wg), gy)
+                K.sync_side_stream()
+                torch.cuda.synchronize()
+                outs += [y.detach(), dx, dw]
+        finally:
+            H_.query("favae_set_wino", prev)
+        return outs
+    a, bb = run(True), run(False)
+    for nm, u, v in zip(["y", "dx", "dw", "y_gn", "dx_gn", "dw_gn"], a, bb):
+        scale = float(v.abs().max())
+        assert float((u - v).abs().max()) <= 2e-5 * scale, "%s: Winograd and direct kernels differ by %.2e of the maximum" % (
+            nm, float((u - v).abs().max()) / scale)
+
+
 BLOCK_DIMS = {"res_same": ("res", (64, 64)), "res_short": ("res", (32, 96)), "nonres": ("nonres", (64, 64)),
               "nonres_g4": ("nonres4", (8, 8)), "attn": ("attn", (64,)), "down": ("down", (32,)), "down_odd": ("down", (32,)),
               "up": ("up", (32,))}
