@@ -141,6 +141,8 @@ struct ConvArgs {
     // (bias and residual included) -- pass 1 of the GroupNorm that consumes this conv's output (gn_partial<0>: one tensor read)
     double* gs_part;          // [N][tiles per image][Cout][2]
     unsigned* gs_amax;        // optional (same variant): max |y| of the output, bit pattern, one atomicMax per workgroup (pre-zeroed)
+    // conv3x3_wino_sp_kernel: floor(2^32 / d) + 1 for d = channel tiles, tile columns, tile rows (division by multiply-high)
+    unsigned wino_rcp_n, wino_rcp_w, wino_rcp_h;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -1173,6 +1175,8 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         if (stats_part && !(xf == 0 || xf == 2)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         a.tiles_n = d->Cout / 64;
         a.w_bytes = (unsigned)((size_t)d->Cout * d->Cin * 64);
+        auto rcp32 = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };   // 0: divisor 1
+        a.wino_rcp_n = rcp32(a.tiles_n); a.wino_rcp_w = rcp32(d->Win / 16); a.wino_rcp_h = rcp32(d->Hin / 16);
         const dim3 wgrid((unsigned)(d->N * (d->Hin / 16) * (d->Win / 16) * a.tiles_n));
 #define FAVAE_LAUNCH_WINO(X, GBV, SEV)                                                                                      \
     do {                                                                                                                    \

@@ -148,13 +148,18 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);             // scalar: enters buffer soffsets and uniform branches
     const int wb = wid & 3, wc = wid >> 2;                                // matrix role: Winograd column b, output-channel half c
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = tile % a.tiles_n;
-    int spt = tile / a.tiles_n;
+    // tile decode with host-made reciprocals (q = mulhi(v, floor(2^32 / d) + 1), exact while v d < 2^32): scalar multiplies instead of
+    // the ~25 vector instructions of every integer division by a run-time value -- the prologue is not amortised over a long K loop
+    const unsigned tile = (unsigned)xcd_remap(blockIdx.x, gridDim.x);
     const int tiles_w = a.Wout / 16, tiles_h = a.Hout / 16;
-    const int tx0 = (spt % tiles_w) * 16; spt /= tiles_w;
-    const int ty0 = (spt % tiles_h) * 16;
-    const int n = spt / tiles_h;
+    auto udiv = [](unsigned v, unsigned rcp) { return rcp ? __umulhi(v, rcp) : v; };      // rcp = 0: divisor 1
+    unsigned spt = udiv(tile, a.wino_rcp_n);
+    const int tn = (int)(tile - spt * (unsigned)a.tiles_n);
+    unsigned sp2 = udiv(spt, a.wino_rcp_w);
+    const int tx0 = (int)(spt - sp2 * (unsigned)tiles_w) * 16;
+    const unsigned sp3 = udiv(sp2, a.wino_rcp_h);
+    const int ty0 = (int)(sp2 - sp3 * (unsigned)tiles_h) * 16;
+    const int n = (int)sp3;
     const int n0 = tn * 64;
     const int q4 = tid & 3;
     const float Sa = sp::pow2_scale(a.x_amax) * HEAD;
@@ -296,7 +301,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     // Every iteration is the same straight-line code (the last one transforms a clamped chunk nobody reads: making that conditional
     // costs 35+ spilled registers).  At the top: V[buf] =
     // chunk kc, raw LDS = chunk kc + 1, rg = loads of chunk kc + 2, bfr = weights of chunk kc.
-    for (int kc = 0; kc < KC; ++kc) {
+    int kc = 0;
+    if (KL > 0) do {                                // all chunks but the last: the last one has nothing to stage or transform behind it
         const int buf = kc & 1, kn = kc < KL ? kc + 1 : KL;
         read_patch();
         mma(buf, 0);
@@ -315,7 +321,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-    }
+    } while (++kc < KL);
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar) mma(KL & 1, ar);
+    __syncthreads();
 
     // ---- epilogue: t[i][wb] = sum_a A^T[i][a] M[a][wb] in registers (A^T = [[1,1,1,0],[0,1,-1,-1]]), exchanged through LDS.
     // Thread (co = lane, tile group wid) then finishes 8 tiles x 2 x 2 outputs; a wave stores 64 consecutive channels of one pixel
