@@ -261,13 +261,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
         for (int pl = 0; pl < 2; ++pl) bfr[ar][pl] = __builtin_bit_cast(half8_t, bload(rw, vw, so + (unsigned)(pl * 1024)));
     };
     f32x16 acc[4][2];
-#pragma unroll
-    for (int ar = 0; ar < 4; ++ar)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ar][rb][r] = 0.f;
-    auto mma = [&](int buf, int ar) {               // smallest terms first; the two row blocks alternate between dependent MFMAs
+    // FIRST: the chunk that starts the accumulators -- its first product takes a zero C operand (an inline constant of the MFMA) instead
+    // of 128 registers zeroed by 128 vector moves per wave
+    auto mma = [&](int buf, int ar, auto first_c) { // smallest terms first; the two row blocks alternate between dependent MFMAs
+        constexpr bool FIRST = decltype(first_c)::value != 0;
         half8_t af[2][2];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
@@ -278,8 +275,16 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
         for (int p3 = 0; p3 < 3; ++p3) {
             const int pa = p3 == 0 ? 1 : 0, pb = p3 == 1 ? 1 : 0;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-                acc[ar][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rb][pa], bfr[ar][pb], acc[ar][rb], 0, 0, 0);
+            for (int rb = 0; rb < 2; ++rb) {
+                f32x16 c;
+                if constexpr (FIRST) {
+                    if (p3 == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+                    } else c = acc[ar][rb];
+                } else c = acc[ar][rb];
+                acc[ar][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rb][pa], bfr[ar][pb], c, 0, 0, 0);
+            }
         }
     };
 
@@ -298,14 +303,13 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     load_raw(KL < 2 ? KL : 2);
     __syncthreads();
 
-    // Every iteration is the same straight-line code (the last one transforms a clamped chunk nobody reads: making that conditional
-    // costs 35+ spilled registers).  At the top: V[buf] =
-    // chunk kc, raw LDS = chunk kc + 1, rg = loads of chunk kc + 2, bfr = weights of chunk kc.
-    int kc = 0;
-    if (KL > 0) do {                                // all chunks but the last: the last one has nothing to stage or transform behind it
+    // One K chunk: at the top V[buf] = chunk kc, raw LDS = chunk kc + 1, rg = loads of chunk kc + 2, bfr = weights of chunk kc.  Straight-
+    // line code (conditionals inside cost 35+ spilled registers); the chunk that starts the accumulators and the last chunk (nothing to
+    // stage or transform behind it) are their own copies.
+    auto chunk = [&](int kc, auto first_c) {
         const int buf = kc & 1, kn = kc < KL ? kc + 1 : KL;
         read_patch();
-        mma(buf, 0);
+        mma(buf, 0, first_c);
         load_b(kn, 0);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                            // every wave has its patch of chunk kc + 1: the raw tile may be overwritten
@@ -316,14 +320,21 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ar = 1; ar < 4; ++ar) {
-            mma(buf, ar);
+            mma(buf, ar, first_c);
             load_b(kn, ar);
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-    } while (++kc < KL);
+    };
+    if (KL > 0) {
+        chunk(0, sp::IC<1>{});
+        for (int kc = 1; kc < KL; ++kc) chunk(kc, sp::IC<0>{});
 #pragma unroll
-    for (int ar = 0; ar < 4; ++ar) mma(KL & 1, ar);
+        for (int ar = 0; ar < 4; ++ar) mma(KL & 1, ar, sp::IC<0>{});
+    } else {
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar) mma(0, ar, sp::IC<1>{});
+    }
     __syncthreads();
 
     // ---- epilogue: t[i][wb] = sum_a A^T[i][a] M[a][wb] in registers (A^T = [[1,1,1,0],[0,1,-1,-1]]), exchanged through LDS.
