@@ -1004,6 +1004,18 @@ extern "C" int favae_wino_weights(const float* w, void* out, int Cout, int Cin, 
     return FAVAE_OK;
 }
 
+// The records of many weight tensors in one launch (a model's flat parameter buffer after an optimizer step): jobs = DEVICE array of
+// favae_wino_job {w, out (header + records, 16-byte aligned), amax (device float, required), Cout, Cin, flip, block0}, block_job = DEVICE
+// int[nblocks]: job index of every block; job j owns blocks block0 .. block0 + ceil(Cout Cin / 8 / 256) - 1.
+extern "C" int favae_wino_weights_grouped(const void* jobs, const int* block_job, int nblocks, favae_stream_t stream) {
+    FAVAE_REQUIRE(jobs && block_job && nblocks > 0);
+    static_assert(sizeof(WinoJob) == sizeof(favae_wino_job), "favae_wino_job layout");
+    FAVAE_PROF_NOTE(0, 0);
+    FAVAE_KLAUNCH(wino_weights_grouped_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const WinoJob*)jobs, block_job);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+
 extern "C" int favae_conv_planes_ok(const favae_conv_desc* d, int has_affine) {
     return desc_ok(d) && planes_producer_ok(d, has_affine != 0) ? 1 : 0;
 }

@@ -77,11 +77,10 @@ __device__ __forceinline__ float4 add4(const float4 p, const float4 q) { return 
 // out (behind the header): U = G g G^T scaled by S_U = HEAD * 2^(14 - floor(log2 max|w|)), split into (hi, lo) fp16 planes, in MFMA
 // B-fragment order: [o / 64][i / 16][b][a][(o / 32) & 1][plane][lane = (o & 31) + 32 ((i / 8) & 1)][8 k].  One thread per (o, 8 i).
 template <bool FLIP>
-__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, int Cout, int Cin,
-                                                           const float* __restrict__ amax, float* __restrict__ hdr_out, int vec) {
+__device__ __forceinline__ void wino_weights_body(const float* __restrict__ w, unsigned char* __restrict__ out, int Cout, int Cin,
+                                                  const float* __restrict__ amax, float* __restrict__ hdr_out, int vec, int idx) {
     const int O = FLIP ? Cin : Cout, I = FLIP ? Cout : Cin;
     const int I8 = I / 8;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
     if (hdr_out && idx == 0) *hdr_out = *amax;
     if (idx >= O * I8) return;
     // FLIP: consecutive threads -> consecutive o (= ci, contiguous in w); else consecutive 8-channel groups of i
@@ -133,6 +132,28 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
             *reinterpret_cast<half8_t*>(d + 1024) = half8_t{lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]};
         }
     }
+}
+
+template <bool FLIP>
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, int Cout, int Cin,
+                                                           const float* __restrict__ amax, float* __restrict__ hdr_out, int vec) {
+    wino_weights_body<FLIP>(w, out, Cout, Cin, amax, hdr_out, vec, blockIdx.x * 256 + threadIdx.x);
+}
+
+// All Winograd records of a model in ONE launch (favae_wino_weights_grouped): jobs[] = one (weight tensor, direction) each, block_job[b] =
+// the job of block b (blocks of a job are consecutive from job.block0).  `out` points at the job's record buffer INCLUDING its header.
+struct WinoJob {
+    const float* w;
+    unsigned char* out;
+    const float* amax;
+    int Cout, Cin, flip, block0;
+};
+__global__ __launch_bounds__(256) void wino_weights_grouped_kernel(const WinoJob* __restrict__ jobs, const int* __restrict__ block_job) {
+    const WinoJob j = jobs[block_job[blockIdx.x]];
+    const int idx = (blockIdx.x - j.block0) * 256 + threadIdx.x;
+    const int vec = ((reinterpret_cast<uintptr_t>(j.w) & 15) == 0) ? 1 : 0;
+    if (j.flip) wino_weights_body<true>(j.w, j.out + sp::WHDR, j.Cout, j.Cin, j.amax, reinterpret_cast<float*>(j.out), vec, idx);
+    else wino_weights_body<false>(j.w, j.out + sp::WHDR, j.Cout, j.Cin, j.amax, reinterpret_cast<float*>(j.out), vec, idx);
 }
 
 // GB: GroupNorm-backward partial sums in the epilogue; SE: per-tile (sum y, sum y^2) + max|y| of the output (as conv3x3_halo_sp_kernel)

@@ -197,7 +197,7 @@ class WeightMaxima:
     def refresh(self):
         call("favae_segment_absmax", ptr(self.flat), ptr(self.seg_off), self.nseg, ptr(self.chunk_seg), ptr(self.chunk_first),
              self.chunk_seg.numel(), ptr(self.out))
-        self.versions = [p._version for p in self.params]
+        self.versions = [(p._version, _weights_epoch(p)) for p in self.params]
 
 
 def _weight_amax(w):
@@ -205,9 +205,94 @@ def _weight_amax(w):
     if ent is None:
         return None
     wm, i = ent
-    if wm.versions[i] != w._version:
+    if wm.versions[i] != (w._version, _weights_epoch(w)):
         return None
     return wm.out[i:i + 1]
+
+
+# The optimizer kernel writes parameters through a raw pointer: no tensor version counter moves.  Caches derived from the weights (their
+# maxima, their Winograd records) therefore also carry the update count of the storage the weights live in: adam_step() bumps it, the
+# cache's refresh() records it, and an entry is used only while both the parameter's version and that count are the ones seen at refresh.
+_WEIGHT_EPOCH = {}
+
+
+def _storage_key(t):
+    return t.untyped_storage().data_ptr()
+
+
+def _touch_weights(t):
+    k = _storage_key(t)
+    _WEIGHT_EPOCH[k] = _WEIGHT_EPOCH.get(k, 0) + 1
+
+
+def _weights_epoch(t):
+    return _WEIGHT_EPOCH.get(_storage_key(t), 0)
+
+
+class WinoRecords:
+    """Winograd weight records (csrc/conv_wino.h) of every dense 3x3 conv weight in `params`, both directions, made by ONE launch
+    (favae_wino_weights_grouped) -- 136 small launches per training step otherwise.  Needs the maxima of a WeightMaxima over the same
+    parameters (the records' scale); refresh() is called by the owner of the parameters after every update, behind the maxima's refresh.
+    A parameter's records are used only while its version counter is the one seen at refresh time."""
+
+    def __init__(self, params):
+        import ctypes as C
+        from . import WinoJob
+        self.params, jobs, self.bufs = [], [], {}
+        dev = None
+        nbytes = 0
+        for p in params:
+            ent = getattr(p, "_favae_wmax", None)
+            if ent is None or p.dim() != 4 or tuple(p.shape[2:]) != (3, 3) or not _is_cl(p):
+                continue
+            co, ci = int(p.shape[0]), int(p.shape[1])
+            for flip in (0, 1):
+                o, i = (ci, co) if flip else (co, ci)
+                if o % 64 or i % 16:
+                    continue
+                size = int(query("favae_wino_weights_bytes", co, ci))
+                jobs.append((p, flip, co, ci, nbytes, size))
+                nbytes += (size + 255) // 256 * 256
+            dev = p.device
+            self.params.append(p)
+        self.n = len(jobs)
+        if not self.n:
+            return
+        self.store = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        arr = (WinoJob * self.n)()
+        block_job, b0 = [], 0
+        for k, (p, flip, co, ci, off, size) in enumerate(jobs):
+            wm, i = p._favae_wmax
+            nb = (co * ci // 8 + 255) // 256
+            arr[k].w, arr[k].out, arr[k].amax = p.data_ptr(), self.store.data_ptr() + off, wm.out[i:i + 1].data_ptr()
+            arr[k].Cout, arr[k].Cin, arr[k].flip, arr[k].block0 = co, ci, flip, b0
+            block_job += [k] * nb
+            b0 += nb
+            self.bufs.setdefault(id(p), {})[flip] = self.store[off:off + size]
+        raw = bytes(memoryview(arr))
+        self.jobs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.block_job = torch.tensor(block_job, dtype=torch.int32, device=dev)
+        self.nblocks = b0
+        self.versions = {}
+        for p in self.params:
+            p._favae_wino = self
+
+    def refresh(self):
+        if not self.n or get_conv_mode() != "h3":
+            self.versions = {}
+            return
+        call("favae_wino_weights_grouped", ptr(self.jobs), ptr(self.block_job), self.nblocks)
+        self.versions = {id(p): (p._version, _weights_epoch(p)) for p in self.params}
+
+    def get(self, p, flip):
+        if self.versions.get(id(p)) != (p._version, _weights_epoch(p)):
+            return None
+        return self.bufs.get(id(p), {}).get(flip)
+
+
+def _wino_cached(w, flip):
+    wr = getattr(w, "_favae_wino", None)
+    return wr.get(w, flip) if wr is not None else None
 
 
 def _fp16_planes():
@@ -511,9 +596,11 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
                 flip = 1
             else:
                 w, co, ci, flip = w_ohwi, d.Cout, d.Cin, 0        # OHWI memory, whatever the logical shape
-            if w_amax is None:
-                w_amax = _weight_amax(w)
-            wsp = _wino_records(w, co, ci, flip, w_amax)
+            wsp = _wino_cached(w, flip)              # made for the whole model after the optimizer step (WinoRecords)
+            if wsp is None:
+                if w_amax is None:
+                    w_amax = _weight_amax(w)
+                wsp = _wino_records(w, co, ci, flip, w_amax)
         w_amax = wsp[:4].view(torch.float32)
         planes |= PLANES_WINO
     if planes & PLANES_WINO:
@@ -635,7 +722,9 @@ class FusedConvFn(torch.autograd.Function):
                 and (ctx.needs_input_grad[0] or gn_w is not None)):
             d2 = make_conv_desc(N, Ho, Wo, Cout, Hin, Win, Cin, cfg.kh, cfg.kw, 1, cfg.kh - 1 - cfg.pad, GATHER_PLAIN, ACT_NONE, 1)
             if query("favae_conv_wants_split_weights", byref(d2), 0) == 2 and query("favae_conv_wino_ok", byref(d2), 0):
-                ctx.wflip = _wino_records(wk, Cout, Cin, 1, w_amax)
+                ctx.wflip = _wino_cached(wk, 1)
+                if ctx.wflip is None:
+                    ctx.wflip = _wino_records(wk, Cout, Cin, 1, w_amax)
         ctx.cfg = cfg
         ctx.has_b = b is not None
         ctx.has_gn = gn_w is not None
@@ -1560,5 +1649,6 @@ def l1_loss(a, b):
 
 def adam_step(p, g, m, v, step, lr, betas=(0.5, 0.9), eps=1e-8, grad_scale=1.0):
     """In-place Adam over flat fp32 buffers (favae_scripts/train_favae.py:297-305)."""
+    _touch_weights(p)                                # per-weight caches (maxima, Winograd records) of this buffer are stale from here on
     call("favae_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
          int(step), float(grad_scale))

@@ -17,6 +17,8 @@ Epoch-dependent switches of the reference (disc_start_epochs, ffl_start_epochs, 
 carry the optimizer state over with opt_g_state_dict() / opt_d_state_dict() -> load_opt_state_dicts(); opt_g and opt_d keep separate
 step counts (`t`, `t_d`), as the reference's two Adam instances do.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -156,6 +158,10 @@ class TrainStep:
             self.wmax.append(K.WeightMaxima(self.dpflat, self.dparams))
         for wm in self.wmax:
             wm.refresh()
+        # Winograd weight records of every dense 3x3 conv of the model, refreshed behind the maxima after each optimizer step
+        self.wino = K.WinoRecords(self.params) if dev.type == "cuda" and os.environ.get("FAVAE_WINO_GROUPED", "1") != "0" else None
+        if self.wino is not None:
+            self.wino.refresh()
 
     # ------------------------------------------------------------------------------------------------------------
     # data parallelism: one process per GPU, each on its own slice of the global batch
@@ -431,6 +437,8 @@ class TrainStep:
                         self.eps, gs)
         if self.wmax:
             self.wmax[0].refresh()
+        if self.wino is not None:
+            self.wino.refresh()
         if self.train_disc:
             out.update(self.disc_step(x))
         return out

@@ -120,6 +120,16 @@ int favae_segment_absmax(const float* x, const int64_t* seg_off, int nseg, const
 #define FAVAE_PLANES_WINO 0x100
 int favae_conv_wino_ok(const favae_conv_desc* d, int has_affine);
 int favae_set_wino(int on);            /* run-time override of FAVAE_WINO; returns the previous setting */
+/* Records of many weight tensors in ONE launch (favae_step.TrainStep: every dense 3x3 conv weight of the model, both directions, after each
+ * optimizer step).  jobs / block_job are DEVICE arrays: job j = {w, out = header + records (16-byte aligned), amax = device float max|w|,
+ * Cout, Cin, flip, block0}; block_job[b] = the job of block b; job j owns the blocks block0 .. block0 + ceil(Cout Cin / 2048) - 1. */
+typedef struct favae_wino_job {
+    const float* w;
+    void* out;
+    const float* amax;
+    int32_t Cout, Cin, flip, block0;
+} favae_wino_job;
+int favae_wino_weights_grouped(const void* jobs, const int* block_job, int nblocks, favae_stream_t stream);
 size_t favae_wino_weights_bytes(int Cout, int Cin);
 int favae_wino_weights(const float* w, void* out, int Cout, int Cin, int flip, const float* amax, favae_stream_t stream);
 int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, const void* wsplit, int planes, const float* x_absmax,
