@@ -327,7 +327,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     // One K chunk: at the top V[buf] = chunk kc, raw LDS = chunk kc + 1, rg = loads of chunk kc + 2, bfr = weights of chunk kc.  Straight-
     // line code (conditionals inside cost 35+ spilled registers); the chunk that starts the accumulators and the last chunk (nothing to
     // stage or transform behind it) are their own copies.
-    auto chunk = [&](int kc, auto first_c) {
+    auto chunk = [&](int kc, auto first_c, auto stage_c) {
         const int buf = kc & 1, kn = kc < KL ? kc + 1 : KL;
         read_patch();
         mma(buf, 0, first_c);
@@ -335,8 +335,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                            // every wave has its patch of chunk kc + 1: the raw tile may be overwritten
         __builtin_amdgcn_sched_barrier(0);
-        store_raw(kc + 2 < KL ? kc + 2 : KL);
-        load_raw(kc + 3 < KL ? kc + 3 : KL);
+        if constexpr (decltype(stage_c)::value != 0) {      // chunk kc + 2 exists: stage it, request chunk kc + 3
+            store_raw(kc + 2);
+            load_raw(kc + 3 < KL ? kc + 3 : KL);
+        }
         transform(buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -347,11 +349,16 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     };
-    if (KL > 0) {
-        chunk(0, sp::IC<1>{});
-        for (int kc = 1; kc < KL; ++kc) chunk(kc, sp::IC<0>{});
+    if (KL > 1) {
+        chunk(0, sp::IC<1>{}, sp::IC<1>{});
+        for (int kc = 1; kc < KL - 1; ++kc) chunk(kc, sp::IC<0>{}, sp::IC<1>{});
+        chunk(KL - 1, sp::IC<0>{}, sp::IC<0>{});
 #pragma unroll
         for (int ar = 0; ar < 4; ++ar) mma(KL & 1, ar, sp::IC<0>{});
+    } else if (KL == 1) {
+        chunk(0, sp::IC<1>{}, sp::IC<0>{});
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar) mma(1, ar, sp::IC<0>{});
     } else {
 #pragma unroll
         for (int ar = 0; ar < 4; ++ar) mma(0, ar, sp::IC<1>{});
