@@ -393,17 +393,30 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) pre[q][0][0] = pre[q][0][1] = pre[q][1][0] = pre[q][1][1] = 0.f;
     }
-    float* Ts = reinterpret_cast<float*>(wlds);     // [2 i][4 b][64 tiles][64 co]
+    // t arrays in LDS: [2 i][4 b][64 co][TPITCH = 68 tiles-padded]: the tile index is the fast one -- a lane's four consecutive accumulator
+    // rows (r & 3) are four consecutive tiles = one 16-byte store, and the finishing thread's eight tiles of a tile row two 16-byte loads
+    // (16 + 16 LDS instructions per thread instead of 64 + 64); the 272-byte channel pitch keeps both conflict-free
+    constexpr int TPITCH = 68;
+    float* Ts = reinterpret_cast<float*>(wlds);
     {
-        float* tw = Ts + (wb * 64 + 4 * (lane >> 5)) * 64 + wc * 32 + (lane & 31);
+        float* tw = Ts + (wb * 64 + wc * 32 + (lane & 31)) * TPITCH + 4 * (lane >> 5);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float m0 = acc[0][rb][r], m1 = acc[1][rb][r], m2 = acc[2][rb][r], m3 = acc[3][rb][r];
-                const int off = (rb * 32 + (r & 3) + 8 * (r >> 2)) * 64;
-                tw[off] = (m0 + m1) + m2;
-                tw[4 * 64 * 64 + off] = (m1 - m2) - m3;
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float4 u0, u1;
+                float* p0 = &u0.x;
+                float* p1 = &u1.x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = r4 * 4 + e;
+                    const float m0 = acc[0][rb][r], m1 = acc[1][rb][r], m2 = acc[2][rb][r], m3 = acc[3][rb][r];
+                    p0[e] = (m0 + m1) + m2;
+                    p1[e] = (m1 - m2) - m3;
+                }
+                const int off = rb * 32 + 8 * r4;
+                *reinterpret_cast<float4*>(tw + off) = u0;
+                *reinterpret_cast<float4*>(tw + 4 * 64 * TPITCH + off) = u1;
             }
     }
     __syncthreads();
@@ -419,16 +432,24 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     }
     double gs1 = 0.0, gs2 = 0.0;
     float se_amax = 0.f;
-    const float* tr = Ts + (wid * 8) * 64 + lane;
+    const float* tr = Ts + lane * TPITCH + wid * 8;
+    float tv[2][4][8];                              // [i][b][tile of the row]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float4 lo = *reinterpret_cast<const float4*>(tr + (i * 4 + b) * 64 * TPITCH);
+            const float4 hi = *reinterpret_cast<const float4*>(tr + (i * 4 + b) * 64 * TPITCH + 4);
+            tv[i][b][0] = lo.x; tv[i][b][1] = lo.y; tv[i][b][2] = lo.z; tv[i][b][3] = lo.w;
+            tv[i][b][4] = hi.x; tv[i][b][5] = hi.y; tv[i][b][6] = hi.z; tv[i][b][7] = hi.w;
+        }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {                   // tile (wid, q) of the workgroup
         float v[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float* tp = tr + (i * 4 * 64 + q) * 64;
-            const float t0 = tp[0], t1 = tp[64 * 64], t2v = tp[2 * 64 * 64], t3 = tp[3 * 64 * 64];
-            v[i][0] = (t0 + t1) + t2v;
-            v[i][1] = (t1 - t2v) - t3;
+            v[i][0] = (tv[i][0][q] + tv[i][1][q]) + tv[i][2][q];
+            v[i][1] = (tv[i][1][q] - tv[i][2][q]) - tv[i][3][q];
         }
         float f1 = 0.f, f2 = 0.f;
 #pragma unroll
@@ -454,12 +475,13 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     }
     if constexpr (GB || SE) {
         // fixed summation order: 32 outputs per thread, then the eight tile-row waves -> one (S1, S2) pair per channel of this tile
-        double* red = reinterpret_cast<double*>(wlds + 2 * V_B);          // [8 waves][64 channels][2], behind the t arrays
+        constexpr int T_B = 8 * 64 * TPITCH * 4;                          // 139264 bytes of t arrays
+        double* red = reinterpret_cast<double*>(wlds + T_B);              // [8 waves][64 channels][2], behind the t arrays
         red[(wid * 64 + lane) * 2] = gs1;
         red[(wid * 64 + lane) * 2 + 1] = gs2;
         if constexpr (SE) {
             if (a.gs_amax) {
-                float* wmx = reinterpret_cast<float*>(wlds + 2 * V_B + 8 * 64 * 2 * sizeof(double));
+                float* wmx = reinterpret_cast<float*>(wlds + T_B + 8 * 64 * 2 * sizeof(double));
                 se_amax = wave_max(se_amax);
                 if (lane == 0) wmx[wid] = se_amax;
             }
@@ -467,7 +489,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
         __syncthreads();
         if constexpr (SE) {
             if (a.gs_amax && tid == 0) {
-                const float* wmx = reinterpret_cast<const float*>(wlds + 2 * V_B + 8 * 64 * 2 * sizeof(double));
+                const float* wmx = reinterpret_cast<const float*>(wlds + T_B + 8 * 64 * 2 * sizeof(double));
                 float m = wmx[0];
 #pragma unroll
                 for (int w = 1; w < 8; ++w) m = fmaxf(m, wmx[w]);
