@@ -53,7 +53,9 @@ NOTES = {
                 "weight-gradient kernels; the latter run on a second HIP stream). achieved = algorithmic fp32 FLOPs (2*M*Cout*KH*KW*Cin "
                 "per launch) / launch durations from two HIP events around every launch on its own stream (csrc/prof.hip), first "
                 "`profiled_steps` steps of the timed region. peak = 2500 TFLOP/s dense 16-bit MFMA / products per fp32 multiply-add "
-                "(planes=2: two scaled fp16 planes, 3 products -> 833; planes=3: 6 products; planes=1: one 16-bit plane, 2500).",
+                "(planes=2: two scaled fp16 planes, 3 products -> 833; planes=3: 6 products; planes=1: one 16-bit plane, 2500). "
+                "conv3x3_wino_sp_kernel (Winograd F(2x2,3x3), csrc/conv_wino.h) is priced on the same direct-conv FLOPs and the same "
+                "833 peak although it executes 4/9 of the multiplies.",
     "single_stream": "*_single_stream: the same launches in 2 untimed steps with the weight-gradient stream off (exclusive durations)",
     "traffic": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch averaged over the launches of one step, separate rocprofv3 "
                "--pmc passes (gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md; fabric-side counter, includes Infinity-Cache "
