@@ -248,7 +248,7 @@ def kernel_planes(name):
             return int(args[1])
         if name.startswith("conv_fwd_sp_kernel") or name.startswith("conv_wgrad_sp_kernel"):
             return int(args[-1])
-        if name.startswith("conv3x3_wino_sp_kernel"):        # h3 only; priced on the direct conv's FLOPs (it executes 4/9 of the products)
+        if name.startswith(("conv3x3_wino_sp_kernel", "conv3x3_winow_sp_kernel")):   # h3 only; priced on the direct conv's FLOPs (it executes 4/9 of the products)
             return 2
     except ValueError:
         pass
