@@ -236,11 +236,8 @@ class WinoRecords:
     A parameter's records are used only while its version counter is the one seen at refresh time."""
 
     def __init__(self, params):
-        import ctypes as C
-        from . import WinoJob
-        self.params, jobs, self.bufs = [], [], {}
-        dev = None
-        nbytes = 0
+        self.params, self._jobs, self.bufs, self.versions = [], [], {}, {}
+        self.dev, self.nbytes, self.store = None, 0, None
         for p in params:
             ent = getattr(p, "_favae_wmax", None)
             if ent is None or p.dim() != 4 or tuple(p.shape[2:]) != (3, 3) or not _is_cl(p):
@@ -251,17 +248,22 @@ class WinoRecords:
                 if o % 64 or i % 16:
                     continue
                 size = int(query("favae_wino_weights_bytes", co, ci))
-                jobs.append((p, flip, co, ci, nbytes, size))
-                nbytes += (size + 255) // 256 * 256
-            dev = p.device
+                self._jobs.append((p, flip, co, ci, self.nbytes, size))
+                self.nbytes += (size + 255) // 256 * 256
+            self.dev = p.device
             self.params.append(p)
-        self.n = len(jobs)
-        if not self.n:
-            return
-        self.store = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        self.n = len(self._jobs)
+        for p in self.params:
+            p._favae_wino = self
+
+    def _materialize(self):
+        """record store + device job table, on the first refresh that needs them (64 bytes per (Cout, Cin) pair and direction: ~1 GB for the
+        f=16 model -- not spent when the conv mode is not h3 or the Winograd path is off)"""
+        from . import WinoJob
+        self.store = torch.empty((self.nbytes,), dtype=torch.uint8, device=self.dev)
         arr = (WinoJob * self.n)()
         block_job, b0 = [], 0
-        for k, (p, flip, co, ci, off, size) in enumerate(jobs):
+        for k, (p, flip, co, ci, off, size) in enumerate(self._jobs):
             wm, i = p._favae_wmax
             nb = (co * ci // 8 + 255) // 256
             arr[k].w, arr[k].out, arr[k].amax = p.data_ptr(), self.store.data_ptr() + off, wm.out[i:i + 1].data_ptr()
@@ -269,18 +271,19 @@ class WinoRecords:
             block_job += [k] * nb
             b0 += nb
             self.bufs.setdefault(id(p), {})[flip] = self.store[off:off + size]
-        raw = bytes(memoryview(arr))
-        self.jobs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
-        self.block_job = torch.tensor(block_job, dtype=torch.int32, device=dev)
+        self.jobs = torch.frombuffer(bytearray(bytes(memoryview(arr))), dtype=torch.uint8).to(self.dev)
+        self.block_job = torch.tensor(block_job, dtype=torch.int32, device=self.dev)
         self.nblocks = b0
-        self.versions = {}
-        for p in self.params:
-            p._favae_wino = self
 
     def refresh(self):
-        if not self.n or get_conv_mode() != "h3":
+        on = bool(query("favae_set_wino", 1))        # read the switch (set_wino returns the previous setting) ...
+        if not on:
+            query("favae_set_wino", 0)               # ... and leave it as it was
+        if not self.n or not on or get_conv_mode() != "h3":
             self.versions = {}
             return
+        if self.store is None:
+            self._materialize()
         call("favae_wino_weights_grouped", ptr(self.jobs), ptr(self.block_job), self.nblocks)
         self.versions = {id(p): (p._version, _weights_epoch(p)) for p in self.params}
 
