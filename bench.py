@@ -52,10 +52,14 @@ NOTES = {
     "roofline": "dominant kernel of the timed region by total time among all matrix-bound launches (conv forward, data-gradient and "
                 "weight-gradient kernels; the latter run on a second HIP stream). achieved = algorithmic fp32 FLOPs (2*M*Cout*KH*KW*Cin "
                 "per launch) / launch durations from two HIP events around every launch on its own stream (csrc/prof.hip), first "
-                "`profiled_steps` steps of the timed region. peak = 2500 TFLOP/s dense 16-bit MFMA / products per fp32 multiply-add "
-                "(planes=2: two scaled fp16 planes, 3 products -> 833; planes=3: 6 products; planes=1: one 16-bit plane, 2500). "
-                "conv3x3_wino_sp_kernel (Winograd F(2x2,3x3), csrc/conv_wino.h) is priced on the same direct-conv FLOPs and the same "
-                "833 peak although it executes 4/9 of the multiplies.",
+                "`profiled_steps` steps of the timed region. peak = the hardware peak of the pipe the kernel's matrix instruction runs "
+                "on (MI355X_MICROARCH.md: 2500 TFLOP/s dense for v_mfma_f32_32x32x16_f16/bf16, 157.3 for the fp32 MFMA) and frac = "
+                "achieved / peak. The split-precision kernels spend `products_per_fma` 16-bit MFMA products per fp32 multiply-add "
+                "(planes=2: two scaled fp16 planes, 3 products; planes=3: 6; one plane: 1) and conv3x3_wino_sp_kernel (Winograd "
+                "F(2x2,3x3), csrc/conv_wino.h) executes 4/9 of the direct conv's multiplies: executed_gflop_per_launch = algorithmic x "
+                "products x (4/9 for Winograd) is the MFMA work really issued, frac_of_pipe_peak = executed / time / 2500. "
+                "peak_fp32_equivalent = 2500 / products (833 for h3) and frac_fp32_equivalent = achieved / that: the fraction of what "
+                "a direct 3-product kernel could reach at best (a Winograd kernel may exceed its own share of it).",
     "single_stream": "*_single_stream: the same launches in 2 untimed steps with the weight-gradient stream off (exclusive durations)",
     "traffic": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch averaged over the launches of one step, separate rocprofv3 "
                "--pmc passes (gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md; fabric-side counter, includes Infinity-Cache "
@@ -101,7 +105,8 @@ def load_traffic():
 
 def compact_roofline(e):
     keep = ("kernel", "launches", "avg_launch_us", "share_of_step_time", "bound", "achieved", "peak", "unit", "frac",
-            "frac_of_measured_mfma_wall", "algorithmic_bytes_per_launch", "avg_algorithmic_gflop_per_launch", "traffic",
+            "executed_gflop_per_launch", "frac_of_pipe_peak", "peak_fp32_equivalent", "frac_fp32_equivalent",
+            "algorithmic_bytes_per_launch", "avg_algorithmic_gflop_per_launch", "traffic",
             "traffic_over_algorithmic", "achieved_single_stream", "frac_single_stream", "avg_launch_us_single_stream", "profiled_steps")
     return {k: rnd(e[k]) for k in keep if k in e}
 
@@ -123,6 +128,21 @@ def write_detail(detail):
     except OSError as e:
         print("[bench] could not write %s: %s" % (path, e), file=sys.stderr)
         return None
+
+def fit_line(res):
+    """the stdout JSON line, kept below MAX_LINE_BYTES by dropping optional keys (they stay in the side file) -- never by failing"""
+    line = json.dumps(res)
+    for k in ("with_lpips", "per_rank_images_per_s", "roofline_step", "ms_per_step_profiler_off"):
+        if len(line) < MAX_LINE_BYTES:
+            break
+        res = {kk: v for kk, v in res.items() if kk != k}
+        print("[bench] line too long: dropped optional key %r (kept in the side file)" % k, file=sys.stderr)
+        line = json.dumps(res)
+    if len(line) >= MAX_LINE_BYTES and isinstance(res.get("config"), dict):
+        res = dict(res, config=dict(res["config"], workload=res["config"]["workload"][:400]))
+        line = json.dumps(res)
+    return line
+
 
 # name -> (description, codebook, n_embed, model kwargs, oracle config kwargs, default batch per GPU,
 #          algorithmic TFLOP and GB per image of the stage-0 step (SURVEY 8d; None where the survey gives none))
@@ -168,7 +188,7 @@ def parse():
                          "accumulation, everything else fp32; like the reference under accelerate mixed precision) -- not the "
                          "headline workload, reported as dtype f16 and under config.workload")
     ap.add_argument("--cpu-batch", type=int, default=8, help="images per step of the bounded CPU-baseline sample")
-    ap.add_argument("--cpu-steps", type=int, default=2, help="timed steps of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed steps of the bounded CPU-baseline sample (median reported)")
     args = ap.parse_args()
     desc, cb, n_embed, mk, ok, batch, _ = CONFIGS[args.config]
     args.codebook = args.codebook or cb
@@ -204,7 +224,8 @@ def launch_ranks(n):
     if rc != 0 or line is None:
         print("[bench] the %d-rank launch failed (exit code %s)" % (n, rc), file=sys.stderr)
         return rc or 1
-    assert len(line) < MAX_LINE_BYTES, "relayed bench line is %d bytes" % len(line)
+    if len(line) >= MAX_LINE_BYTES:
+        line = fit_line(json.loads(line))
     print(line, flush=True)
     return 0
 
@@ -255,17 +276,32 @@ def kernel_planes(name):
     return None
 
 
+def executed_factor(name, planes):
+    """MFMA FLOPs issued per algorithmic FLOP: 16-bit products per fp32 multiply-add x 4/9 for the Winograd F(2x2,3x3) kernels"""
+    f = float(SPLIT_PRODUCTS[planes]) if planes else 1.0
+    if name.startswith(("conv3x3_wino_sp_kernel", "conv3x3_winow_sp_kernel")):
+        f *= 4.0 / 9.0
+    return f
+
+
 def roofline_entry(name, r, step_us, traffic, excl=None):
     planes = kernel_planes(name)
     avg_us = r["total_us"] / r["launches"]
     e = {"kernel": name, "launches": r["launches"], "avg_launch_us": avg_us, "share_of_step_time": r["total_us"] / step_us}
     if r["flops"] > 0 and not name.startswith("thin_"):          # thin_*: 3-channel ends, vector-ALU kernels priced against HBM
         ach = 1e-12 * r["flops"] / (1e-6 * r["total_us"])
-        peak = PEAK_16BIT_MFMA_TFLOPS / SPLIT_PRODUCTS[planes] if planes else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_16BIT_MFMA_TFLOPS if planes else PEAK_F32_MFMA_TFLOPS      # the pipe the kernel's matrix instruction runs on
+        ex = executed_factor(name, planes)
         e.update({"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                  "products_per_fma": SPLIT_PRODUCTS[planes] if planes else 1,
+                  "executed_gflop_per_launch": 1e-9 * ex * r["flops"] / r["launches"],
+                  "frac_of_pipe_peak": ex * ach / peak,
                   "vs_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
-                  "frac_of_measured_mfma_wall": (ach / (MFMA_WALL_RANDOM_TFLOPS / SPLIT_PRODUCTS[planes])) if planes else None,
+                  "frac_of_measured_mfma_wall": (ex * ach / MFMA_WALL_RANDOM_TFLOPS) if planes else None,
                   "avg_algorithmic_gflop_per_launch": 1e-9 * r["flops"] / r["launches"]})
+        if planes:
+            e["peak_fp32_equivalent"] = PEAK_16BIT_MFMA_TFLOPS / SPLIT_PRODUCTS[planes]
+            e["frac_fp32_equivalent"] = ach / e["peak_fp32_equivalent"]
     elif r["bytes"] > 0:
         ach = 1e-9 * r["bytes"] / (1e-6 * r["total_us"])
         e.update({"bound": "hbm", "achieved": ach, "peak": 1e3 * PEAK_HBM_TBS, "unit": "GB/s", "frac": ach / (1e3 * PEAK_HBM_TBS)})
@@ -280,6 +316,8 @@ def roofline_entry(name, r, step_us, traffic, excl=None):
         num = x["flops"] if e["bound"] == "mfma" else x["bytes"]
         e["achieved_single_stream"] = (1e-12 if e["bound"] == "mfma" else 1e-9) * num / (1e-6 * x["total_us"])
         e["frac_single_stream"] = e["achieved_single_stream"] / e["peak"]
+        if "peak_fp32_equivalent" in e:
+            e["frac_fp32_equivalent_single_stream"] = e["achieved_single_stream"] / e["peak_fp32_equivalent"]
         e["avg_launch_us_single_stream"] = x["total_us"] / x["launches"]
     return e
 
@@ -309,16 +347,20 @@ def cpu_baseline(args, torch):
     sc = O.StepConfig(lr=4.5e-6 * args.batch, with_disc_forward=True)
     tr = O.OracleTrainer(cfg, sc)
     B = args.cpu_batch
-    tr.step(O.det_input(min(B, 2), args.res, args.res, 1234))      # untimed warm-up step: thread pool, allocator, oneDNN primitives
+    t0 = time.perf_counter()
+    tr.step(O.det_input(B, args.res, args.res, 1234))      # untimed warm-up step AT THE TIMED BATCH SIZE: thread pool, allocator and the
+    t_warm = time.perf_counter() - t0                      # oneDNN primitives of exactly the shapes the timed steps run
     dts = []
     for i in range(max(1, args.cpu_steps)):
         t0 = time.perf_counter()
         tr.step(O.det_input(B, args.res, args.res, 1235 + i))
         dts.append(time.perf_counter() - t0)
-    dt = sum(dts)
-    return {"value": rnd(B * len(dts) / dt), "unit": "images/s", "cores": ncores, "kind": "port",
-            "sample": "%d timed steps (+1 warm-up) of the same %s step at batch %d, oracle/favae_oracle.py, torch %s CPU, %.1f s"
-                      % (len(dts), args.config, B, torch.__version__, dt)}
+    med = sorted(dts)[len(dts) // 2] if len(dts) % 2 else 0.5 * (sorted(dts)[len(dts) // 2 - 1] + sorted(dts)[len(dts) // 2])
+    return {"value": rnd(B / med), "unit": "images/s", "cores": ncores, "kind": "port",
+            "step_s": [rnd(v, 4) for v in dts],
+            "sample": "median of %d timed steps (after 1 warm-up step at the same batch, %.1f s) of the same %s step at batch %d, "
+                      "oracle/favae_oracle.py, torch %s CPU, %.1f s timed"
+                      % (len(dts), t_warm, args.config, B, torch.__version__, sum(dts))}
 
 
 def main():
@@ -477,9 +519,11 @@ def main():
             a_f = tf * args.batch * args.steps / dt                                  # per GPU
             a_b = gb * 1e-3 * args.batch * args.steps / dt
             planes = {"fp32": 2, "fp16": 1, "bf16": 4}[args.precision]
-            peak = PEAK_16BIT_MFMA_TFLOPS / SPLIT_PRODUCTS[planes]
+            peak_eq = PEAK_16BIT_MFMA_TFLOPS / SPLIT_PRODUCTS[planes]
             res["roofline_step"] = {"tflop_per_image": tf, "gb_per_image": gb,
-                                    "mfma": {"achieved": rnd(a_f), "peak": rnd(peak), "unit": "TFLOP/s", "frac": rnd(a_f / peak)},
+                                    "mfma": {"achieved": rnd(a_f), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                             "frac": rnd(a_f / PEAK_16BIT_MFMA_TFLOPS), "peak_fp32_equivalent": rnd(peak_eq),
+                                             "frac_fp32_equivalent": rnd(a_f / peak_eq)},
                                     "hbm": {"achieved": rnd(1e3 * a_b), "peak": 1e3 * PEAK_HBM_TBS, "unit": "GB/s",
                                             "frac": rnd(a_b / PEAK_HBM_TBS)}}
         if "all" in extras:
@@ -495,13 +539,11 @@ def main():
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             print("[bench] GPU part done: %.2f images/s; timing the CPU baseline sample..." % res["value"], file=sys.stderr, flush=True)
             res["cpu_baseline"] = cpu_baseline(args, torch)
-        line = json.dumps(res)
-        assert len(line) < MAX_LINE_BYTES, "bench line grew to %d bytes: tables and notes belong in the side file" % len(line)
-        detail["line"] = res
-        path = write_detail(detail)
+        detail["line"] = dict(res)
+        path = write_detail(detail)                  # the side file first: nothing of a finished run is lost to a formatting problem
         if path:
             print("[bench] kernel table / notes: %s" % path, file=sys.stderr, flush=True)
-        print(line, flush=True)
+        print(fit_line(res), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

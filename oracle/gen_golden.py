@@ -84,6 +84,10 @@ report = []
 def check(name, a, b, tol=2e-5):
     r = maxrel(a, b)
     report.append((name, r))
+    if os.environ.get("FAVAE_GOLDEN_NOASSERT") == "1":          # survey mode: print every difference instead of stopping at the first
+        if not r < tol:
+            print(f"  [over tolerance {tol:g}] {name}: {r:.3e}", flush=True)
+        return
     assert r < tol, f"oracle != reference for {name}: maxrel {r}"
 
 
@@ -92,6 +96,10 @@ def check_adam(name, a, b, lr):
     level may legitimately differ by 2*lr between two fp32 implementations; nothing may differ by more."""
     d = float((a.detach().double() - b.detach().double()).abs().max())
     report.append((name + " [abs, bound 2*lr]", d))
+    if os.environ.get("FAVAE_GOLDEN_NOASSERT") == "1":
+        if not d <= 2.02 * lr:
+            print(f"  [over 2*lr] {name}: {d:.3e}", flush=True)
+        return
     assert d <= 2.02 * lr, f"oracle != reference for {name}: max abs {d} > 2*lr"
 
 
@@ -531,16 +539,26 @@ DISC_KEYS = ["discriminator.features.0.weight", "discriminator.features.0.bias",
              "discriminator.features.9.weight", "discriminator.head.weight", "discriminator.head.bias"]
 
 
-def gen_gan():
+# discriminator-training fixtures: tag -> (codebook size, resolution, default seed)
+GAN_CASES = {
+    "gan_128": (512, 128, 4324),
+    # BASELINE configs[4] at its own size: FFHQ f=16, codebook 2048, use_same_conv_gauss, num_groups 32, gaussian_kernel 9, 256x256,
+    # discriminator from the first iteration (favae_scripts/train_favae_other_datasets_public.sh:8-13); batch 2 of the 32, perceptual
+    # term off (vgg16_lpips.pt is not available: LPIPS stays oracle-only)
+    "cfg5_256": (2048, 256, 5151),
+}
+
+
+def gen_gan(tag="gan_128"):
     """Discriminator training (BASELINE config 5 wiring, perceptual term off): one full train() iteration of the reference
     modules -- stage 0 with the hinge generator term and the adaptive weight (favae_scripts/train_favae.py:32-39,75-106,
     the five lines of compute_adaptive_weight are restated here because the script itself needs tensorboard/torchvision),
     opt_g step, stage 1 (models/vqgan_fcm.py:138-147) with hinge_d, opt_d step."""
-    tag = "gan_128"
-    mk = dict(codebook_size=512, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
+    csize, HW, seed0 = GAN_CASES[tag]
+    mk = dict(codebook_size=csize, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
               use_l2_quantizer=True, kernel_size=9, dsl_init_sigma=3.0, use_same_conv_gauss=True, num_groups=32, device="cpu")
-    ok = dict(codebook_size=512, variant="same_conv_gauss", kernel_size=9, num_groups=32)
-    B, H, W, seed = 2, 128, 128, int(os.environ.get("FAVAE_GAN_SEED", "4324"))
+    ok = dict(codebook_size=csize, variant="same_conv_gauss", kernel_size=9, num_groups=32)
+    B, H, W, seed = 2, HW, HW, int(os.environ.get("FAVAE_GAN_SEED", str(seed0)))
     lr, disc_w = 4.5e-6 * 2, 0.75
     out = {}
     model = VQGANFCM(**mk)
@@ -661,7 +679,7 @@ def gen_gan():
             out[p + "dgfull." + k] = npy(g)
     out[p + "shape"] = np.array([B, H, W, seed], np.int64)
     out[p + "hyper"] = np.array([lr, disc_w], np.float64)
-    np.savez_compressed(os.path.join(OUT, "gan_128.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **out)
 
 
 def gen_hinge():
@@ -840,7 +858,7 @@ def gen_attn_fcm():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["blocks", "blur", "vq", "vq_large", "hinge", "models", "cfg1", "cfg2", "f4_256", "gan", "lpips", "attn_fcm",
+    which = sys.argv[1:] or ["blocks", "blur", "vq", "vq_large", "hinge", "models", "cfg1", "cfg2", "f4_256", "gan", "cfg5", "lpips", "attn_fcm",
                              "variants"]
     if "blocks" in which:
         gen_blocks()
@@ -862,6 +880,8 @@ if __name__ == "__main__":
         gen_vq_large()
     if "gan" in which:
         gen_gan()
+    if "cfg5" in which:
+        gen_gan("cfg5_256")
     if "lpips" in which:
         gen_lpips_head()
     if "attn_fcm" in which:

@@ -21,11 +21,32 @@ def test_compact_roofline_is_small_and_numeric():
     for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "algorithmic_bytes_per_launch",
               "traffic_over_algorithmic", "frac_single_stream"):
         assert k in c, k
-    assert c["bound"] == "mfma" and c["unit"] == "TFLOP/s" and abs(c["peak"] - 2500.0 / 3) < 0.01
+    # peak = the hardware peak of the 16-bit matrix pipe (MI355X_MICROARCH.md); the h3 kernels issue 3 MFMA products per fp32 multiply-add
+    assert c["bound"] == "mfma" and c["unit"] == "TFLOP/s" and c["peak"] == 2500.0 and abs(c["peak_fp32_equivalent"] - 2500.0 / 3) < 0.01
     assert abs(c["frac"] - c["achieved"] / c["peak"]) < 1e-4
+    assert abs(c["frac_fp32_equivalent"] - 3 * c["frac"]) < 1e-4
+    assert abs(c["executed_gflop_per_launch"] - 3 * 177.41) < 0.01 and abs(c["frac_of_pipe_peak"] - 3 * c["frac"]) < 1e-4
     assert abs(c["traffic_over_algorithmic"] - 1.873 / 0.534) < 1e-3
     assert not any(isinstance(v, str) and len(v) > 80 for v in c.values())
     assert len(json.dumps(c)) < 700
+
+
+def test_winograd_kernel_is_priced_on_executed_flops():
+    """the Winograd kernel's line shows the fraction of the real 2.5 PFLOP/s pipe next to the fp32-equivalent one --
+    executed = algorithmic x 3 products x 4/9 (the numbers of the round-3 driver run: 177.41 GFLOP in 631 us -> 0.150 and 0.337)."""
+    name = "conv3x3_wino_sp_kernel<0, true, false>"
+    e = bench.compact_roofline(bench.roofline_entry(name, _rec(268, 631.0, 177.41, 0.534), 4 * 135000.0, {}, None))
+    assert abs(e["achieved"] - 281.2) < 0.5 and e["peak"] == 2500.0 and abs(e["frac"] - 0.1125) < 1e-3
+    assert abs(e["executed_gflop_per_launch"] - 177.41 * 3 * 4 / 9) < 0.01
+    assert abs(e["frac_of_pipe_peak"] - 0.150) < 1e-3 and abs(e["frac_fp32_equivalent"] - 0.337) < 1e-3
+
+
+def test_line_is_trimmed_not_asserted():
+    res = {"metric": "m", "value": 1.0, "config": {"workload": "w" * 300}, "roofline": {"kernel": "k"}, "with_lpips": {"x": "y" * 5000},
+           "cpu_baseline": {"value": 1}}
+    line = bench.fit_line(res)
+    out = json.loads(line)
+    assert len(line) < bench.MAX_LINE_BYTES and "with_lpips" not in out and "roofline" in out and "cpu_baseline" in out
 
 
 def test_hbm_bound_entry_uses_gb_per_s():

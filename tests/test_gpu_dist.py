@@ -118,6 +118,14 @@ def test_bench_line_schema():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "algorithmic_bytes_per_launch"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 * r["frac"]
+    # checkable against the guide: peak is the hardware peak of the pipe, the executed MFMA work is priced next to the algorithmic one
+    assert r["peak"] in (2500.0, 157.3)
+    for k in ("executed_gflop_per_launch", "frac_of_pipe_peak", "peak_fp32_equivalent", "frac_fp32_equivalent"):
+        assert k in r, k
+    ex = r["executed_gflop_per_launch"] / r["avg_algorithmic_gflop_per_launch"]
+    assert abs(r["frac_of_pipe_peak"] - ex * r["frac"]) < 2e-3 * r["frac_of_pipe_peak"]
+    assert abs(r["frac_fp32_equivalent"] - r["achieved"] / r["peak_fp32_equivalent"]) < 2e-3 * r["frac_fp32_equivalent"]
+    assert "median" in res["cpu_baseline"]["sample"] and len(res["cpu_baseline"]["step_s"]) == 1
     assert "<" in r["kernel"], "the kernel is named by its full instantiation (the name a rocprofv3 trace shows)"
     assert not any(isinstance(v, str) and len(v) > 80 for v in r.values()), "no prose inside the machine-readable roofline object"
     for k in ("kernel_table", "roofline_others"):
