@@ -973,6 +973,9 @@ extern "C" int favae_set_wino(int on) {
     return prev;
 }
 
+// side-effect-free read of the switch
+extern "C" int favae_get_wino(void) { return use_wino() ? 1 : 0; }
+
 extern "C" int favae_conv_wino_ok(const favae_conv_desc* d, int has_affine) { return desc_ok(d) && wino_ok(d, has_affine != 0) ? 1 : 0; }
 
 extern "C" size_t favae_wino_weights_bytes(int Cout, int Cin) {

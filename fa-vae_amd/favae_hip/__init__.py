@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FAVAE_HIP_LIB") or os.path.join(_HERE, "libfavae_hip.so")     # FAVAE_HIP_LIB: same-box A/B of two builds
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02, ACT_RELU = 0, 1, 2, 3
@@ -131,6 +131,7 @@ SIGNATURES = {
     "favae_split_weights_amax": (c_int, [_P, _P, c_int64, c_int, _P, _S]),
     "favae_conv_wino_ok": (c_int, [_P, c_int]),
     "favae_set_wino": (c_int, [c_int]),
+    "favae_get_wino": (c_int, []),
     "favae_wino_weights_grouped": (c_int, [_P, _P, c_int, _S]),
     "favae_wino_weights_bytes": (c_size_t, [c_int, c_int]),
     "favae_wino_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P, _S]),

@@ -169,7 +169,10 @@ class WeightMaxima:
     """max |w| of every parameter that is a view of one flat buffer, refreshed by ONE launch (favae_segment_absmax) -- the fp16
     split-precision convs need the maximum of their weight tensor on every call; without this each conv call runs its own reduction
     (98 launches + 98 memsets per training step).  refresh() is called by the owner of the flat buffer after every update of it; a
-    parameter's entry is used only while the parameter's version counter is the one seen at refresh time (load_state_dict, .copy_())."""
+    parameter's entry is used only while the parameter's version counter, the flat buffer's version counter (a write THROUGH the flat
+    buffer -- pflat.copy_(ckpt), dist.broadcast(pflat) -- moves that one only: `p.data = view` gives every parameter a counter of its
+    own) and the storage's update count (raw-pointer writes: the optimizer kernel, invalidate_weight_caches) are the ones seen at refresh
+    time."""
 
     def __init__(self, flat, params):
         self.flat, self.params = flat, [p for p in params if p.dim() >= 2]
@@ -197,7 +200,14 @@ class WeightMaxima:
     def refresh(self):
         call("favae_segment_absmax", ptr(self.flat), ptr(self.seg_off), self.nseg, ptr(self.chunk_seg), ptr(self.chunk_first),
              self.chunk_seg.numel(), ptr(self.out))
-        self.versions = [(p._version, _weights_epoch(p)) for p in self.params]
+        self.versions = [_weights_key(p) for p in self.params]
+
+
+def _weights_key(p):
+    """what a cache entry derived from parameter p (its max|w|, its Winograd records) is valid for: p's version counter, the version
+    counter of the flat buffer p is a view of (if any) and the update count of the storage"""
+    ent = getattr(p, "_favae_wmax", None)
+    return (p._version, ent[0].flat._version if ent is not None else -1, _weights_epoch(p))
 
 
 def _weight_amax(w):
@@ -205,7 +215,7 @@ def _weight_amax(w):
     if ent is None:
         return None
     wm, i = ent
-    if wm.versions[i] != (w._version, _weights_epoch(w)):
+    if wm.versions[i] != _weights_key(w):
         return None
     return wm.out[i:i + 1]
 
@@ -227,6 +237,12 @@ def _touch_weights(t):
 
 def _weights_epoch(t):
     return _WEIGHT_EPOCH.get(_storage_key(t), 0)
+
+
+def invalidate_weight_caches(t):
+    """Call after writing parameters that live in the storage of tensor `t` in a way no version counter sees (a raw-pointer kernel, a
+    foreign library): every cached max|w| and Winograd record of parameters in that storage is dropped until the owner's next refresh()."""
+    _touch_weights(t)
 
 
 class WinoRecords:
@@ -276,19 +292,17 @@ class WinoRecords:
         self.nblocks = b0
 
     def refresh(self):
-        on = bool(query("favae_set_wino", 1))        # read the switch (set_wino returns the previous setting) ...
-        if not on:
-            query("favae_set_wino", 0)               # ... and leave it as it was
+        on = bool(query("favae_get_wino"))
         if not self.n or not on or get_conv_mode() != "h3":
             self.versions = {}
             return
         if self.store is None:
             self._materialize()
         call("favae_wino_weights_grouped", ptr(self.jobs), ptr(self.block_job), self.nblocks)
-        self.versions = {id(p): (p._version, _weights_epoch(p)) for p in self.params}
+        self.versions = {id(p): _weights_key(p) for p in self.params}
 
     def get(self, p, flip):
-        if self.versions.get(id(p)) != (p._version, _weights_epoch(p)):
+        if self.versions.get(id(p)) != _weights_key(p):
             return None
         return self.bufs.get(id(p), {}).get(flip)
 
@@ -401,6 +415,17 @@ def flush_reductions():
     _SIDE["pending"].append((ev, [t for j in jobs for t in j[:2]]))
     _SIDE["jobs"] = []
     _SIDE["targets"] = set()
+
+
+def reset_side_state():
+    """Start of a training step: drop slab reductions a previous, ABORTED backward pass left queued (an exception in a later node, an
+    OOM retry) -- flushed into the freshly zeroed gradient buffer they would corrupt this step's gradients without any error.  The main
+    stream is first ordered behind whatever the side stream still runs, so the dropped workspaces can be reused safely."""
+    if _SIDE["jobs"] or _SIDE["targets"] or _SIDE["used"] or _SIDE["pending"]:
+        if _SIDE["stream"] is not None:
+            torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        _SIDE["jobs"], _SIDE["targets"], _SIDE["used"] = [], set(), False
+        _SIDE["pending"].clear()
 
 
 def side_stream_flushed():
@@ -557,6 +582,8 @@ def _bias_grad_and_range(dy, p_b, need_b, want_range, M, Cout, dev):
             else:
                 if tgt is None:
                     db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+                else:
+                    _order_behind_deferred(tgt)
                 call("favae_colsum_finish", ptr(pre[0]), pre[1], Cout, ptr(db if tgt is None else tgt), 0 if tgt is None else 1)
         return db, (pre[2] if want_range else None)
     if want_range:
@@ -566,10 +593,20 @@ def _bias_grad_and_range(dy, p_b, need_b, want_range, M, Cout, dev):
         tgt = _direct_grad(p_b)
         if tgt is None:
             db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        else:
+            _order_behind_deferred(tgt)
         call("favae_colsum", ptr(dy), ptr(db if tgt is None else tgt), M, Cout, 0 if tgt is None else 1, ptr(dyb), ptr(ws), ws.numel())
     elif want_range:
         call("favae_absmax", ptr(dy), dy.numel(), ptr(dyb))
     return db, dyb
+
+
+def _order_behind_deferred(tgt):
+    """a main-stream accumulation into `tgt` while a deferred (side-stream) reduction into the same range is still queued (a module
+    applied twice in one pass): run the queued reductions and wait for them first"""
+    if tgt.data_ptr() in _SIDE["targets"]:
+        flush_reductions()
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
 
 
 def _wino_records(w, co, ci, flip, w_amax):
@@ -722,7 +759,7 @@ class FusedConvFn(torch.autograd.Function):
         # next to the weight-gradient stream (measured 72 us per layer there against 9 us alone)
         ctx.wflip = None
         if (_WINO_FLIP_FWD and w_amax is not None and cfg.stride == 1 and not cfg.upsample and cfg.kh == 3
-                and (ctx.needs_input_grad[0] or gn_w is not None)):
+                and any(ctx.needs_input_grad) and (ctx.needs_input_grad[0] or gn_w is not None)):   # no backward (no_grad, eval): no records
             d2 = make_conv_desc(N, Ho, Wo, Cout, Hin, Win, Cin, cfg.kh, cfg.kw, 1, cfg.kh - 1 - cfg.pad, GATHER_PLAIN, ACT_NONE, 1)
             if query("favae_conv_wants_split_weights", byref(d2), 0) == 2 and query("favae_conv_wino_ok", byref(d2), 0):
                 ctx.wflip = _wino_cached(wk, 1)

@@ -404,6 +404,7 @@ class TrainStep:
     def disc_step(self, x):
         """Stage 1 (train_favae.py:108-116): discriminator update on (x, x_recon.detach()); model(x, stage=1) recomputes the
         reconstruction under no_grad in train mode (second EMA codebook update of the iteration, as in the reference)."""
+        K.reset_side_state()
         self.dgflat.zero_()                                  # opt_d.zero_grad(): also drops what stage 0 left here
         logits_real, logits_fake = self.model(K.to_cl(x), stage=1)
         loss_d = hinge_d_loss(logits_real, logits_fake)
@@ -419,6 +420,7 @@ class TrainStep:
 
     def step(self, x):
         self.model.train()
+        K.reset_side_state()                                 # nothing of an aborted earlier pass reaches this step's gradients
         self.gflat.zero_()
         K.set_dropout_seed(self.t + 1)                       # dropout sites (attention FCM only): fresh masks every step
         out = self.losses(x)

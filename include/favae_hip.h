@@ -120,6 +120,7 @@ int favae_segment_absmax(const float* x, const int64_t* seg_off, int nseg, const
 #define FAVAE_PLANES_WINO 0x100
 int favae_conv_wino_ok(const favae_conv_desc* d, int has_affine);
 int favae_set_wino(int on);            /* run-time override of FAVAE_WINO; returns the previous setting */
+int favae_get_wino(void);              /* the current setting, no side effect */
 /* Records of many weight tensors in ONE launch (favae_step.TrainStep: every dense 3x3 conv weight of the model, both directions, after each
  * optimizer step).  jobs / block_job are DEVICE arrays: job j = {w, out = header + records (16-byte aligned), amax = device float max|w|,
  * Cout, Cin, flip, block0}; block_job[b] = the job of block b; job j owns the blocks block0 .. block0 + ceil(Cout Cin / 2048) - 1. */

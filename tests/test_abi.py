@@ -78,3 +78,29 @@ def test_launch_profiler_reports_empty_without_launches():
     buf = ctypes.create_string_buffer(int(n) + 8)
     lib.favae_prof_report(buf, len(buf))
     assert buf.value == b""
+
+
+def test_weight_cache_keys_follow_every_visible_write():
+    """a cached max|w| / Winograd record of a parameter that is a view of a flat buffer is valid only while the
+    parameter's version counter, the FLAT BUFFER's version counter and the storage's update count are the ones seen at refresh --
+    pflat.copy_(checkpoint) / dist.broadcast(pflat) move only the flat buffer's counter.  Host logic only (no kernel runs here)."""
+    from favae_hip import ops as K
+    flat = torch.zeros(64 + 32)
+    p1 = torch.nn.Parameter(torch.zeros(4, 4, 2, 2))
+    p2 = torch.nn.Parameter(torch.zeros(8, 4))
+    off = 0
+    for p in (p1, p2):
+        p.data = flat[off:off + p.numel()].view(p.shape)
+        off += p.numel()
+    wm = K.WeightMaxima(flat, [p1, p2])
+    wm.versions = [K._weights_key(p) for p in wm.params]          # what refresh() records behind its kernel launch
+    assert K._weight_amax(p1) is not None and K._weight_amax(p2) is not None
+    flat.mul_(2.0)                                                # a write through the flat buffer
+    assert K._weight_amax(p1) is None and K._weight_amax(p2) is None
+    wm.versions = [K._weights_key(p) for p in wm.params]
+    with torch.no_grad():
+        p1.add_(1.0)                                              # a write through the parameter
+    assert K._weight_amax(p1) is None and K._weight_amax(p2) is not None
+    wm.versions = [K._weights_key(p) for p in wm.params]
+    K.invalidate_weight_caches(flat)                              # a raw-pointer write announced by its author
+    assert K._weight_amax(p1) is None and K._weight_amax(p2) is None

@@ -418,18 +418,26 @@ def test_discriminator_forward_backward_vs_oracle():
     close(d.features[9].running_var, P["discriminator.features.9.running_var"], 1e-5, "running_var")
 
 
-def test_gan_iteration_against_reference_golden(golden_dir):
-    """One full train() iteration with discriminator training against the reference's outputs (tests/golden/gan_128.npz):
+def _gan_case(tag):
+    """model / oracle configuration of a discriminator-training fixture (oracle/gen_golden.py GAN_CASES)"""
+    csize = {"gan_128": 512, "cfg5_256": 2048}[tag]
+    mk = dict(codebook_size=csize, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
+              use_l2_quantizer=True, kernel_size=9, dsl_init_sigma=3.0, use_same_conv_gauss=True, num_groups=32)
+    return mk, O.OracleConfig(codebook_size=csize, variant="same_conv_gauss", kernel_size=9, num_groups=32)
+
+
+@pytest.mark.parametrize("tag", ["gan_128", "cfg5_256"])
+def test_gan_iteration_against_reference_golden(golden_dir, tag):
+    """One full train() iteration with discriminator training against the reference's outputs (tests/golden/gan_128.npz, and
+    cfg5_256.npz = BASELINE configs[4] at its own size: 256x256, codebook 2048, use_same_conv_gauss, num_groups 32, k = 9):
     hinge generator term, adaptive weight, stage-1 discriminator update, two EMA codebook updates, three BN updates."""
     from test_oracle_golden import check_gan_golden
     from models.vqgan_fcm import VQGANFCM
     from favae_step import TrainStep
-    g = np.load(os.path.join(golden_dir, "gan_128.npz"))
-    B, H, W, seed = [int(v) for v in g["gan_128.shape"]]
-    lr, disc_w = [float(v) for v in g["gan_128.hyper"]]
-    mk = dict(codebook_size=512, n_embed=256, ch_mult=(1, 1, 2, 2, 4), attn_resolutions=[16], use_cosine_sim=True,
-              use_l2_quantizer=True, kernel_size=9, dsl_init_sigma=3.0, use_same_conv_gauss=True, num_groups=32)
-    cfg = O.OracleConfig(codebook_size=512, variant="same_conv_gauss", kernel_size=9, num_groups=32)
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    B, H, W, seed = [int(v) for v in g[tag + ".shape"]]
+    lr, disc_w = [float(v) for v in g[tag + ".hyper"]]
+    mk, cfg = _gan_case(tag)
     model = VQGANFCM(**mk, device=DEV)
     model.load_state_dict(O.det_state(cfg, with_disc=True), strict=True)
     model = model.to(DEV)
@@ -475,7 +483,105 @@ def test_gan_iteration_against_reference_golden(golden_dir):
     # decoder (decoder tensors: <= 1e-3 of the tensor max here; encoder tensors, after the cancellation: 3e-3 .. 6e-3 with either
     # 2x2-phase kernel family, tools/experiments/gan_grad_err.py) -- bar 1e-2; the un-cancelled training step keeps 5e-3 (_golden_step).
     tols = dict(stage0=1e-4, weight_d=2e-3, loss_g=5e-4, grads=1e-2, logits_fake_d=3e-3, dgrad_head=1e-1, dgrad_abs=1e-2, bn=1e-3)
-    check_gan_golden(g, res, P, lr, close_fn=close_fn, tols=tols)
+    if tag == "cfg5_256":      # 4x the LeakyReLU units: the slope-switching aggregates take the bars the oracle itself needed against the
+        tols.update(dgrad_abs=6e-2, dgrad_head=2e-1)    # reference at this size (oracle/gen_golden.py GAN_CASES); stage 0 unchanged
+    check_gan_golden(g, res, P, lr, close_fn=close_fn, tols=tols, tag=tag)
+
+
+def test_cfg5_256_b1_index_flips_and_loss_deltas(golden_dir):
+    """BASELINE configs[4] names bf16: the one-plane bf16 mode (b1) on the cfg5_256 state and input, REPORTED as what decides whether the
+    mode is usable -- the number of codebook indices that differ from the reference's (fp32) indices and the loss deltas against the
+    reference golden -- next to the fp32-grade mode on the same state (0 flips, 1e-4).  Two codebooks: the fixture's closed-form one
+    (similarities nearly degenerate: the worst case) and a trained-like one whose codes ARE encoder outputs of other images (every token
+    then has a well separated best code, as after EMA training).  bf16 operands carry 8 significand bits: the encoder output moves by
+    ~1e-2 relative, so flips are inherent to the mode in any framework; the bars only catch a broken kernel."""
+    from models.vqgan_fcm import VQGANFCM
+    from favae_hip import ops as K
+    tag = "cfg5_256"
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    B, H, W, seed = [int(v) for v in g[tag + ".shape"]]
+    mk, cfg = _gan_case(tag)
+    state = O.det_state(cfg, with_disc=True)
+    x = O.det_input(B, H, W, seed).to(DEV)
+
+    def encode(mode, codebook=None, xin=x):
+        prev = K.set_conv_mode(mode)
+        try:
+            model = VQGANFCM(**mk, device=DEV)
+            model.load_state_dict(state, strict=True)
+            model = model.to(DEV).train()
+            if codebook is not None:
+                model.quantizer._codebook.embed.data.copy_(codebook)
+            with torch.no_grad():                    # ONE codebook lookup (train mode: the EMA update runs behind it, as in the golden)
+                h = model.encoder(K.to_cl(xin), inference=model.inference)[0]
+                zq, ind, loss_q = model.quantizer(h)
+                x_recon = model.decode(zq)[0]
+            torch.cuda.synchronize()
+            return dict(x_recon=x_recon, loss_q=loss_q.reshape(-1), ind=ind.cpu().numpy(), h=h,
+                        loss_l1=(xin - x_recon).abs().mean().reshape(-1))
+        finally:
+            K.set_conv_mode(prev)
+
+    ref_ind = g[tag + ".indices"]
+    a, b = encode("h3"), encode("b1")
+    n = ref_ind.size
+    flips_h3, flips_b1 = int((a["ind"] != ref_ind).sum()), int((b["ind"] != ref_ind).sum())
+    d = {k: abs(float(b[k][0]) - float(g[tag + "." + ("loss_q" if k == "loss_q" else k)][0])) / abs(float(g[tag + "." + k][0]))
+         for k in ("loss_l1", "loss_q")}
+    print("\ncfg5_256 closed-form codebook: index flips vs reference h3 %d / %d, b1 %d / %d (%.1f %%); b1 loss deltas vs reference %s"
+          % (flips_h3, n, flips_b1, n, 100.0 * flips_b1 / n, {k: "%.2e" % v for k, v in d.items()}))
+    assert flips_h3 == 0
+    # trained-like codebook: l2-normalised encoder outputs (fp32-grade) of other images, one per code
+    codes = []
+    with torch.no_grad():
+        i = 0
+        while sum(c.shape[0] for c in codes) < mk["codebook_size"]:
+            hh = encode("h3", xin=O.det_input(2, H, W, 9000 + i).to(DEV))["h"]
+            codes.append(torch.nn.functional.normalize(hh.permute(0, 2, 3, 1).reshape(-1, hh.shape[1]), dim=-1))
+            i += 1
+    cb = torch.cat(codes)[:mk["codebook_size"]].reshape(1, mk["codebook_size"], -1)
+    a2, b2 = encode("h3", cb), encode("b1", cb)
+    f2 = int((a2["ind"] != b2["ind"]).sum())
+    l2 = {k: abs(float(b2[k][0]) - float(a2[k][0])) / abs(float(a2[k][0])) for k in ("loss_l1", "loss_q")}
+    rms = float(((b2["x_recon"] - a2["x_recon"]).pow(2).mean() / a2["x_recon"].pow(2).mean()).sqrt())
+    print("cfg5_256 trained-like codebook: b1 index flips vs h3 %d / %d (%.1f %%); loss deltas %s; x_recon rms-rel %.2e"
+          % (f2, n, 100.0 * f2 / n, {k: "%.2e" % v for k, v in l2.items()}, rms))
+    assert f2 <= 0.5 * n and l2["loss_l1"] < 5e-2 and d["loss_l1"] < 5e-2
+
+
+def test_flat_buffer_write_drops_weight_caches():
+    """after a write THROUGH the flat parameter buffer (checkpoint restore, broadcast) the forward and the
+    data-gradient convs must not run on the previous step's max|w| / Winograd records while the weight gradients read the new
+    weights.  ts.pflat.mul_() moves only the flat buffer's version counter; the forward behind it must equal, bit for bit, the
+    forward of a TrainStep that was built on the scaled weights."""
+    from favae_hip import ops as K
+    from favae_step import TrainStep
+    x = O.det_input(1, 64, 64, 11).to(DEV)
+    m1, _, _ = build("cfg1_k3")
+    ts1 = TrainStep(m1, lr=1e-4)
+    ts1.step(x)
+    torch.cuda.synchronize()
+    state = {k: v.detach().clone() for k, v in m1.state_dict().items()}
+    w = m1.decoder.final[2].weight
+    assert K._weight_amax(w) is not None
+    ts1.pflat.mul_(1.25)                                # every weight changes; no parameter version counter moves
+    assert K._weight_amax(w) is None and K._wino_cached(w, 0) is None, "stale cache entries survive a flat-buffer write"
+    m1.train()
+    with torch.no_grad():
+        o1 = ts1.losses(x)
+    m2, _, _ = build("cfg1_k3")
+    m2.load_state_dict(state)
+    with torch.no_grad():
+        for p in list(m2.encoder.parameters()) + list(m2.decoder.parameters()) + list(m2.quantizer.parameters()):
+            p.mul_(1.25)
+    ts2 = TrainStep(m2, lr=1e-4)
+    m2.train()
+    with torch.no_grad():
+        o2 = ts2.losses(x)
+    torch.cuda.synchronize()
+    assert torch.equal(o1["x_recon"], o2["x_recon"])
+    for k in ("loss_l1", "loss_quant", "loss_ffl", "loss_dsl"):
+        assert float(o1[k].reshape(-1)[0]) == float(o2[k].reshape(-1)[0]), k
 
 
 def test_gan_trainstep_runs_two_iterations():

@@ -311,8 +311,7 @@ def test_winograd_conv_path_matches_direct_kernels(K, cin, cout, hw):
         finally:
             H.query("favae_set_wino", prev)
         return [y.detach().double().cpu()] + [t.double().cpu() for t in g]
-    if not H.query("favae_set_wino", 1):
-        H.query("favae_set_wino", 0)
+    if not H.query("favae_get_wino"):
         pytest.skip("Winograd path switched off (FAVAE_WINO=0)")
     a, b = run(True), run(False)
     refs = [yr.detach()] + [t for t in gr]
@@ -331,8 +330,7 @@ def test_winograd_conv_shapes_against_direct_kernel(K, N, cin, cout, H, W):
     and 3, a channel count that is not a power of two (five 64-channel tiles), with bias + residual and with the fused GroupNorm+SiLU
     (16 groups): forward, data gradient and the gradients that flow through the epilogue by-products, against the direct kernel."""
     import favae_hip as H_
-    if not H_.query("favae_set_wino", 1):
-        H_.query("favae_set_wino", 0)
+    if not H_.query("favae_get_wino"):
         pytest.skip("Winograd path switched off (FAVAE_WINO=0)")
     torch.manual_seed(N * 1000 + cin)
     d = dev()
