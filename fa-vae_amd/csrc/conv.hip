@@ -973,6 +973,19 @@ extern "C" int favae_set_wino(int on) {
     return prev;
 }
 
+#ifdef FAVAE_WINO_TRACE
+// trace build only (tools/wino_trace.sh): copy the phase stamps of conv3x3_wino_sp_kernel to the host and clear them
+extern "C" int favae_debug_wino_trace(void* host_dst, size_t bytes) {
+    if (bytes > sizeof(g_wino_trace)) bytes = sizeof(g_wino_trace);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_wino_trace), bytes) != hipSuccess) return -2;
+    static unsigned long long zeros[1] = {0};
+    void* dptr = nullptr;
+    if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_wino_trace)) != hipSuccess) return -3;
+    return hipMemset(dptr, 0, sizeof(g_wino_trace)) == hipSuccess ? 0 : -4;
+}
+#endif
+
 // side-effect-free read of the switch
 extern "C" int favae_get_wino(void) { return use_wino() ? 1 : 0; }
 

@@ -156,6 +156,20 @@ __global__ __launch_bounds__(256) void wino_weights_grouped_kernel(const WinoJob
     else wino_weights_body<false>(j.w, j.out + sp::WHDR, j.Cout, j.Cin, j.amax, reinterpret_cast<float*>(j.out), vec, idx);
 }
 
+// FAVAE_WINO_TRACE (tools/wino_trace.sh builds a separate library with it; never the product build): lane 0 of every wave of a sample of
+// workgroups stamps s_memtime at phase boundaries of the kernel -- [64 sampled workgroups][8 waves][48 rows][8 stamps]; row 0 = prologue,
+// rows 1..KC = K chunks, row 47 = epilogue.  Each stamp costs an s_waitcnt lgkmcnt(0) (s_memtime returns through the scalar memory path).
+#ifdef FAVAE_WINO_TRACE
+__device__ unsigned long long g_wino_trace[64 * 8 * 48 * 8];
+#define WTRACE(row, slot)                                                                                                       \
+    do {                                                                                                                        \
+        if ((blockIdx.x & 63) == 5 && (blockIdx.x >> 6) < 64 && lane == 0)                                                      \
+            g_wino_trace[(((blockIdx.x >> 6) * 8 + wid) * 48 + (row)) * 8 + (slot)] = __builtin_readcyclecounter();            \
+    } while (0)
+#else
+#define WTRACE(row, slot) do { } while (0)
+#endif
+
 // GB: GroupNorm-backward partial sums in the epilogue; SE: per-tile (sum y, sum y^2) + max|y| of the output (as conv3x3_halo_sp_kernel)
 template <int XFORM, bool GB, bool SE>
 __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
@@ -314,6 +328,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     };
 
     // prologue: V[0] <- chunk 0, raw LDS <- chunk 1, registers <- loads of chunk 2, weights of chunk 0 (chunk indices clamped to KL)
+    WTRACE(0, 0);
     load_raw(0);
 #pragma unroll
     for (int ar = 0; ar < 4; ++ar) load_b(0, ar);
@@ -327,31 +342,42 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     store_raw(KL < 1 ? KL : 1);
     load_raw(KL < 2 ? KL : 2);
     __syncthreads();
+    WTRACE(0, 1);
 
     // One K chunk: at the top V[buf] = chunk kc, raw LDS = chunk kc + 1, rg = loads of chunk kc + 2, bfr = weights of chunk kc.  Straight-
     // line code (conditionals inside cost 35+ spilled registers); the chunk that starts the accumulators and the last chunk (nothing to
     // stage or transform behind it) are their own copies.
     auto chunk = [&](int kc, auto first_c, auto stage_c) {
         const int buf = kc & 1, kn = kc < KL ? kc + 1 : KL;
+        WTRACE(kc + 1, 0);
         read_patch();
         mma(buf, 0, first_c);
         load_b(kn, 0);
         __builtin_amdgcn_sched_barrier(0);
+        WTRACE(kc + 1, 1);
         __syncthreads();                            // every wave has its patch of chunk kc + 1: the raw tile may be overwritten
+        WTRACE(kc + 1, 2);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (decltype(stage_c)::value != 0) {      // chunk kc + 2 exists: stage it, request chunk kc + 3
             store_raw(kc + 2);
             load_raw(kc + 3 < KL ? kc + 3 : KL);
         }
+#ifdef FAVAE_WINO_TRACE
+        __builtin_amdgcn_sched_barrier(0);
+        WTRACE(kc + 1, 3);
+#endif
         transform(buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
+        WTRACE(kc + 1, 4);
 #pragma unroll
         for (int ar = 1; ar < 4; ++ar) {
             mma(buf, ar, first_c);
             load_b(kn, ar);
         }
         __builtin_amdgcn_sched_barrier(0);
+        WTRACE(kc + 1, 5);
         __syncthreads();
+        WTRACE(kc + 1, 6);
     };
     if (KL > 1) {
         chunk(0, sp::IC<1>{}, sp::IC<1>{});
@@ -368,6 +394,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
         for (int ar = 0; ar < 4; ++ar) mma(0, ar, sp::IC<1>{});
     }
     __syncthreads();
+    WTRACE(47, 0);
 
     // ---- epilogue: t[i][wb] = sum_a A^T[i][a] M[a][wb] in registers (A^T = [[1,1,1,0],[0,1,-1,-1]]), exchanged through LDS.
     // Thread (co = lane, tile group wid) then finishes 8 tiles x 2 x 2 outputs; a wave stores 64 consecutive channels of one pixel
@@ -423,7 +450,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
                 *reinterpret_cast<float4*>(tw + 4 * 64 * TPITCH + off) = u1;
             }
     }
+    WTRACE(47, 1);
     __syncthreads();
+    WTRACE(47, 2);
 
     const float bv = a.bias ? a.bias[col] : 0.f;
     float g_mu = 0.f, g_rs = 0.f, g_ga = 0.f, g_be = 0.f;
@@ -477,6 +506,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
             }
         if constexpr (GB) { gs1 += (double)f1; gs2 += (double)f2; }
     }
+    WTRACE(47, 3);
     if constexpr (GB || SE) {
         // fixed summation order: 32 outputs per thread, then the eight tile-row waves -> one (S1, S2) pair per channel of this tile
         constexpr int T_B = 8 * 64 * TPITCH * 4;                          // 139264 bytes of t arrays
@@ -511,4 +541,5 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
             out[1] = w2;
         }
     }
+    WTRACE(47, 4);
 }

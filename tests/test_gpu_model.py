@@ -546,7 +546,8 @@ def test_cfg5_256_b1_index_flips_and_loss_deltas(golden_dir):
     rms = float(((b2["x_recon"] - a2["x_recon"]).pow(2).mean() / a2["x_recon"].pow(2).mean()).sqrt())
     print("cfg5_256 trained-like codebook: b1 index flips vs h3 %d / %d (%.1f %%); loss deltas %s; x_recon rms-rel %.2e"
           % (f2, n, 100.0 * f2 / n, {k: "%.2e" % v for k, v in l2.items()}, rms))
-    assert f2 <= 0.5 * n and l2["loss_l1"] < 5e-2 and d["loss_l1"] < 5e-2
+    # measured on MI355X (round 4): closed-form codebook 6 / 512 flips (1.2 %), trained-like 7 / 512 (1.4 %), loss_l1 deltas 8e-4 / 4e-3
+    assert flips_b1 <= 0.05 * n and f2 <= 0.05 * n and l2["loss_l1"] < 2e-2 and d["loss_l1"] < 2e-2
 
 
 def test_flat_buffer_write_drops_weight_caches():

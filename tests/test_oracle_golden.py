@@ -325,7 +325,18 @@ def check_gan_golden(g, res, P, lr, close_fn=close, tols=GAN_TOLS_ORACLE, tag="g
     p = tag + "."
     close_fn(res["loss_disc"].reshape(-1), g[p + "loss_disc"], rtol=tols["stage0"], name="loss_disc")
     close_fn(torch.as_tensor(float(res["weight_d"])), g[p + "weight_d"], rtol=tols["weight_d"], name="weight_d")
-    close_fn(res["loss_g"].reshape(-1), g[p + "loss_g_total"], rtol=tols["loss_g"], name="loss_g")
+    # loss_g = (loss_l1 + loss_q + loss_ffl + loss_dsl) + weight_d * disc_weight * loss_disc: the last term carries weight_d's own tolerance
+    # (a RATIO OF GRADIENT NORMS, bar tols["weight_d"]) at |term| / |loss_g| times its size -- 1.8x at 128x128, 2.7x at 256x256 where the two
+    # parts nearly cancel.  Checked (i) with the reference's weight_d substituted for the own one at the stage-0 bar (what the rest of loss_g
+    # must hold) and (ii) as it is, at that bar plus the share weight_d's bar may move it by.
+    disc_w = float(g[p + "hyper"][1])
+    w_ref, w_own = float(g[p + "weight_d"]), float(res["weight_d"])
+    lg_own, ld_own = res["loss_g"].reshape(-1), res["loss_disc"].reshape(-1)
+    lg_ref = T(g[p + "loss_g_total"]).reshape(-1)
+    close_fn(lg_own - (w_own - w_ref) * disc_w * ld_own.to(lg_own.dtype), g[p + "loss_g_total"], rtol=max(tols["stage0"], 2e-4),
+             name="loss_g with the reference's weight_d")
+    amp = abs(w_ref * disc_w * float(g[p + "loss_disc"].reshape(-1)[0])) / abs(float(lg_ref[0]))
+    close_fn(lg_own, g[p + "loss_g_total"], rtol=tols["loss_g"] + tols["weight_d"] * amp, name="loss_g")
     close_fn(res["logits_fake"], g[p + "logits_fake"], rtol=tols["stage0"], name="logits_fake")
     close_fn(res["logits_real"], g[p + "logits_real"], rtol=tols["stage0"], name="logits_real")
     close_fn(res["loss_d"].reshape(-1), g[p + "loss_d"], rtol=tols["stage0"], name="loss_d")
