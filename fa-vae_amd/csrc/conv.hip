@@ -813,7 +813,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 }
 
 int launch_absmax(const float* x, int64_t n, float* out, hipStream_t s) {
-    if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
+    if (favae_zero_target(out, sizeof(float), s) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     long blocks = (n / 4 + 255) / 256;
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
     FAVAE_PROF_NOTE(0, 4.0 * n);
@@ -986,6 +986,13 @@ extern "C" int favae_debug_wino_trace(void* host_dst, size_t bytes) {
 }
 #endif
 
+// see common.h: pointers into [p, p + bytes) are reduction targets the caller keeps zeroed (bytes = 0 / p = NULL: no arena)
+extern "C" int favae_set_zero_arena(const void* p, size_t bytes) {
+    g_zero_lo = bytes ? (const char*)p : nullptr;
+    g_zero_hi = bytes ? (const char*)p + bytes : nullptr;
+    return FAVAE_OK;
+}
+
 // side-effect-free read of the switch
 extern "C" int favae_get_wino(void) { return use_wino() ? 1 : 0; }
 
@@ -1074,7 +1081,7 @@ extern "C" int favae_conv_fwd_split_stats(const favae_conv_desc* d, const float*
     if (planes & FAVAE_PLANES_WINO) planes = planes == (2 | FAVAE_PLANES_WINO) ? planes : 0;
     if (!tiles || ((planes & 0xff) != 2 && planes != 1 && planes != 4)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
-    if (y_absmax && hipMemsetAsync(y_absmax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
+    if (y_absmax && favae_zero_target(y_absmax, sizeof(float), (hipStream_t)stream) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr, nullptr,
                          (double*)part, y_absmax);
 }
@@ -1844,7 +1851,7 @@ extern "C" int favae_colsum(const float* a, float* out, int64_t M, int C, int ac
     const long rpb = (M + nb - 1) / nb;
     hipStream_t s = (hipStream_t)stream;
     unsigned* amax = (unsigned*)absmax_out;
-    if (amax && hipMemsetAsync(amax, 0, sizeof(float), s) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
+    if (amax && favae_zero_target(amax, sizeof(float), s) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     FAVAE_PROF_NOTE(0, 4.0 * M * C);
     if (C % 4 == 0 && ((((uintptr_t)a) & 15) == 0))
         FAVAE_KLAUNCH(colsum_partial_vec_kernel, dim3(1, nb), dim3(256), 0, s, a, (float*)ws, (long)M, C, rpb, amax);

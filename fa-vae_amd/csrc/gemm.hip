@@ -477,7 +477,7 @@ extern "C" int favae_attn_bwd_point(float* s, float* dp, const float* lse, const
     FAVAE_REQUIRE(s && dp && lse && delta && ds_absmax && rows > 0 && L > 0 && rows_per_batch > 0 && row0 >= 0 &&
                   row0 + rows_per_batch <= Ltot);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ds_absmax, 0, sizeof(float), st) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
+    if (favae_zero_target(ds_absmax, sizeof(float), st) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     FAVAE_PROF_NOTE(0, 16.0 * rows * L);
     long blocks = cdiv(rows, 4);
     if (blocks > 2048) blocks = 2048;

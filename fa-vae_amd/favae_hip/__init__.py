@@ -132,6 +132,7 @@ SIGNATURES = {
     "favae_conv_wino_ok": (c_int, [_P, c_int]),
     "favae_set_wino": (c_int, [c_int]),
     "favae_get_wino": (c_int, []),
+    "favae_set_zero_arena": (c_int, [c_void_p, c_size_t]),
     "favae_wino_weights_grouped": (c_int, [_P, _P, c_int, _S]),
     "favae_wino_weights_bytes": (c_size_t, [c_int, c_int]),
     "favae_wino_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P, _S]),

@@ -347,13 +347,53 @@ def get_conv_mode():
     return {v: k for k, v in CONV_MODES.items()}[query("favae_get_conv_mode")]
 
 
+# ---- zero arena: pre-zeroed atomicMax targets ------------------------------------------------------------------------------
+# The max|x| scalars of the fp16 split scheme are atomicMax targets that must start at zero; each library call zeroes its own with a
+# 4-byte memset launch (117-156 per training step, 5 us + a queue gap each) unless the pointer lies in a range the caller keeps zero
+# (include/favae_hip.h, favae_set_zero_arena).  TrainStep.step() zeroes ONE buffer per step (zero_arena_reset) and the allocation sites
+# below hand out its floats one after the other; outside a TrainStep (inference, tests) or when the buffer is used up they fall back to
+# torch.empty + the library's own memset.  A by-product scalar that rides on a tensor (`_favae_amax`, `_favae_dycs`) carries the arena
+# epoch it was taken in: after the next reset the slot is zero again and must not be trusted.
+_ARENA = {"buf": None, "pos": 0, "epoch": 0, "n": 4096, "stream": None}
+
+
+def zero_arena_reset(dev):
+    """start of a training step: every slot handed out before is invalid from here on; one memset for all of this step's targets"""
+    a = _ARENA
+    if a["buf"] is None or a["buf"].device != torch.device(dev):
+        a["buf"] = torch.zeros((a["n"],), dtype=torch.float32, device=dev)
+        query("favae_set_zero_arena", a["buf"].data_ptr(), a["n"] * 4)
+    else:
+        a["buf"].zero_()
+    a["pos"] = 0
+    a["epoch"] += 1
+    a["stream"] = torch.cuda.current_stream()       # slots are zero in THIS stream's order only
+
+
+def zero_arena_off():
+    """drop the arena (the library zeroes every target itself again)"""
+    _ARENA["buf"], _ARENA["pos"] = None, 0
+    _ARENA["epoch"] += 1
+    query("favae_set_zero_arena", None, 0)
+
+
+def _max_target(dev):
+    """a float32[1] that is zero in stream order when the kernel that atomicMax'es into it runs: the next arena slot, else a fresh tensor
+    (which the library memsets)"""
+    a = _ARENA
+    if a["buf"] is not None and a["pos"] < a["n"] and a["buf"].device == torch.device(dev) and torch.cuda.current_stream() == a["stream"]:
+        a["pos"] += 1
+        return a["buf"][a["pos"] - 1:a["pos"]]
+    return torch.empty((1,), dtype=torch.float32, device=dev)
+
+
 def absmax(t):
     """device scalar max|t| (operand range of the fp16 split-precision conv kernels); taken from the producing conv's epilogue when
-    it left one on the tensor (`_favae_amax`, valid while the version counter is unchanged)"""
+    it left one on the tensor (`_favae_amax`, valid while the version counter is unchanged and the arena slot has not been recycled)"""
     pre = getattr(t, "_favae_amax", None)
-    if pre is not None and pre[1] == t._version:
+    if pre is not None and pre[1] == t._version and pre[2] == _ARENA["epoch"]:
         return pre[0]
-    out = torch.empty((1,), dtype=torch.float32, device=t.device)
+    out = _max_target(t.device)
     call("favae_absmax", ptr(t), t.numel(), ptr(out))
     return out
 
@@ -558,7 +598,8 @@ _DYCS_FUSE = os.environ.get("FAVAE_DYCS_FUSE", "1") != "0"
 
 def _dy_byproducts(dy, C):
     pre = getattr(dy, "_favae_dycs", None) if _DYCS_FUSE else None
-    if pre is not None and pre[3] == dy._version and pre[0].numel() == pre[1] * C and dy.shape[1] == C:
+    if (pre is not None and pre[3] == dy._version and pre[0].numel() == pre[1] * C and dy.shape[1] == C
+            and pre[4] == _ARENA["epoch"]):
         return pre
     return None
 
@@ -587,7 +628,7 @@ def _bias_grad_and_range(dy, p_b, need_b, want_range, M, Cout, dev):
                 call("favae_colsum_finish", ptr(pre[0]), pre[1], Cout, ptr(db if tgt is None else tgt), 0 if tgt is None else 1)
         return db, (pre[2] if want_range else None)
     if want_range:
-        dyb = torch.empty((1,), dtype=torch.float32, device=dev)
+        dyb = _max_target(dev)
     if need_b:
         ws = workspace(query("favae_colsum_workspace", M, Cout), dev)
         tgt = _direct_grad(p_b)
@@ -750,11 +791,11 @@ class FusedConvFn(torch.autograd.Function):
             st_tiles = query("favae_conv_stats_tiles", byref(d), 0 if scale is None else 1)
             if st_tiles:
                 st_part = torch.empty((N * st_tiles * Cout * 2,), dtype=torch.float64, device=dev)
-        y_amax = torch.empty((1,), dtype=torch.float32, device=dev) if st_part is not None else None
+        y_amax = _max_target(dev) if st_part is not None else None
         w_amax = _conv_launch(d, x, wk, b, resid, scale, shift, y, xb, planes_out=xs, stats_out=st_part, y_amax=y_amax)
         if st_part is not None:
             y._favae_gnstats = (st_part, st_tiles, y._version)
-            y._favae_amax = (y_amax, y._version)
+            y._favae_amax = (y_amax, y._version, _ARENA["epoch"])
         # Winograd records of the data gradient, made HERE: in the backward pass this small kernel would sit on the critical chain
         # next to the weight-gradient stream (measured 72 us per layer there against 9 us alone)
         ctx.wflip = None
@@ -919,7 +960,7 @@ class FusedConvFn(torch.autograd.Function):
                     call("favae_gn_act_bwd_colsum", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin, gG, act,
                          ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0, gn_tiles,
                          ptr(gn_ws), gn_ws.numel(), ptr(cs_part), ptr(cs_amax))
-                    dx._favae_dycs = (cs_part, cs_blocks, cs_amax, dx._version)
+                    dx._favae_dycs = (cs_part, cs_blocks, cs_amax, dx._version, _ARENA["epoch"])
                 elif gn_tiles:                                # pass 1 came out of the data-gradient conv's epilogue
                     call("favae_gn_act_bwd_tiles", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin,
                          gG, act, ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,
@@ -1241,13 +1282,13 @@ class AttnCoreFn(torch.autograd.Function):
         dmax = absmax(do)
         delta = torch.empty((N, L), dtype=torch.float32, device=dev)
         call("favae_rowdot", ptr(do), ptr(o), ptr(delta), N * L, C)
-        dsmax = torch.empty((1,), dtype=torch.float32, device=dev)
         RQ = _attn_chunk_rows(N, L)
         S = torch.empty((N * RQ * L,), dtype=torch.float32, device=dev)
         dP = torch.empty((N * RQ * L,), dtype=torch.float32, device=dev)
         for ci, r0 in enumerate(range(0, L, RQ)):
             rq = min(RQ, L - r0)
             qc, doc = q + 4 * r0 * C3, do.data_ptr() + 4 * r0 * C
+            dsmax = _max_target(dev)                 # max|dS| of THIS chunk (an arena slot is zero once: one per chunk)
             # scores of the chunk again, dP = dO V^T, then in place: S <- P = exp(S - lse), dP <- dS = alpha P (dP - delta)
             call("favae_bgemm_sp", 0, 0, rq, L, C, alpha, qc, C3, L * C3, ptr(amax), k, C3, L * C3, ptr(amax), ptr(S), L, rq * L, N, 0)
             call("favae_bgemm_sp", 0, 0, rq, L, C, 1.0, doc, C, L * C, ptr(dmax), v, C3, L * C3, ptr(amax), ptr(dP), L, rq * L, N, 0)

@@ -421,6 +421,8 @@ class TrainStep:
     def step(self, x):
         self.model.train()
         K.reset_side_state()                                 # nothing of an aborted earlier pass reaches this step's gradients
+        if self.gflat.is_cuda:
+            K.zero_arena_reset(self.gflat.device)            # one memset for all of this step's max|x| targets (ops._ARENA)
         self.gflat.zero_()
         K.set_dropout_seed(self.t + 1)                       # dropout sites (attention FCM only): fresh masks every step
         out = self.losses(x)

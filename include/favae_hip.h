@@ -121,6 +121,10 @@ int favae_segment_absmax(const float* x, const int64_t* seg_off, int nseg, const
 int favae_conv_wino_ok(const favae_conv_desc* d, int has_affine);
 int favae_set_wino(int on);            /* run-time override of FAVAE_WINO; returns the previous setting */
 int favae_get_wino(void);              /* the current setting, no side effect */
+/* Zero arena: the max|x| outputs of favae_absmax / favae_colsum / favae_conv_fwd_split_stats / favae_attn_bwd_point are atomicMax targets
+ * that must start at zero; each call zeroes its own (one 4-byte memset launch) UNLESS the pointer lies inside [p, p + bytes), a range the
+ * caller keeps zero for such targets (favae_step.TrainStep: one memset per step).  bytes = 0 removes the arena. */
+int favae_set_zero_arena(const void* p, size_t bytes);
 /* Records of many weight tensors in ONE launch (favae_step.TrainStep: every dense 3x3 conv weight of the model, both directions, after each
  * optimizer step).  jobs / block_job are DEVICE arrays: job j = {w, out = header + records (16-byte aligned), amax = device float max|w|,
  * Cout, Cin, flip, block0}; block_job[b] = the job of block b; job j owns the blocks block0 .. block0 + ceil(Cout Cin / 2048) - 1. */
