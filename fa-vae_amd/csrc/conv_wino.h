@@ -202,10 +202,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     const auto rx = make_rsrc(a.x, a.x_bytes);
     const auto rw = make_rsrc(a.w, a.w_bytes);
     float* Aff = reinterpret_cast<float*>(wlds + 2 * V_B + RAW_B);      // [2][AFF_C]: scale, shift of this image's input channels
+    // The prologue issues EVERY first load before it waits for any: the (scale, shift) pair, the halo of chunks 0 and 1 and the weights of
+    // chunk 0.  One after the other (scale -> LDS -> halo 0 -> staged -> halo 1) they were three dependent ~1.7 us round trips with an idle
+    // matrix pipe: 9200 of a forward workgroup's 52900 cycles, 6100 of 43700 in the data gradient (tools/wino_trace.py).
+    float aff_sc = 0.f, aff_sh = 0.f;
     if (XFORM) {                                   // read back per chunk at staging time: no registers held across the K loop
         if (tid < a.Cin) {
-            Aff[tid] = a.scale[n * a.aff_stride + tid];
-            Aff[AFF_C + tid] = a.shift[n * a.aff_stride + tid];
+            aff_sc = a.scale[n * a.aff_stride + tid];
+            aff_sh = a.shift[n * a.aff_stride + tid];
         }
     }
 
@@ -224,12 +228,13 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
         ro[j] = hrow * RAWP + q4 * 16;
     }
     float4 rg[3];
-    auto load_raw = [&](int kc) {
+    auto load_raw_to = [&](float4 (&r)[3], int kc) {
         const unsigned sk = (unsigned)(kc * 64);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) rg[j] = bload(rx, vh[j], sk);
+        for (int j = 0; j < 3; ++j) r[j] = bload(rx, vh[j], sk);
     };
-    auto store_raw = [&](int kc) {                  // kc = the chunk rg holds
+    auto load_raw = [&](int kc) { load_raw_to(rg, kc); };
+    auto store_raw_from = [&](const float4 (&rg)[3], int kc) {      // kc = the chunk the registers hold
         float4 rsc = make_float4(0.f, 0.f, 0.f, 0.f), rsh = rsc;
         if (XFORM) {
             rsc = *reinterpret_cast<const float4*>(Aff + kc * 16 + q4 * 4);
@@ -243,6 +248,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
             if (j < 2 || tid < 272) *reinterpret_cast<float4*>(Rs + ro[j]) = t;
         }
     };
+    auto store_raw = [&](int kc) { store_raw_from(rg, kc); };
 
     // transform item of this thread: Winograd tile (tty, ttx) of the 8 x 8, channel quad q4, half th = rows (2 th, 2 th + 1) of
     // B^T d B.  The lanes of one ds_read_b128 service group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32: MI355X_MICROARCH.md) take
@@ -329,18 +335,25 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
 
     // prologue: V[0] <- chunk 0, raw LDS <- chunk 1, registers <- loads of chunk 2, weights of chunk 0 (chunk indices clamped to KL)
     WTRACE(0, 0);
+    float4 rg1[3];                                  // halo of chunk 1: a second register set, live in the prologue only
     load_raw(0);
+    load_raw_to(rg1, KL < 1 ? KL : 1);
 #pragma unroll
     for (int ar = 0; ar < 4; ++ar) load_b(0, ar);
-    if (XFORM) __syncthreads();                     // (scale, shift) staged
+    if (XFORM) {
+        if (tid < a.Cin) {
+            Aff[tid] = aff_sc;
+            Aff[AFF_C + tid] = aff_sh;
+        }
+        __syncthreads();                            // (scale, shift) staged
+    }
     store_raw(0);
-    load_raw(KL < 1 ? KL : 1);
+    load_raw(KL < 2 ? KL : 2);
     __syncthreads();
     read_patch();
     transform(0);
     __syncthreads();
-    store_raw(KL < 1 ? KL : 1);
-    load_raw(KL < 2 ? KL : 2);
+    store_raw_from(rg1, KL < 1 ? KL : 1);
     __syncthreads();
     WTRACE(0, 1);
 
@@ -424,6 +437,16 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) pre[q][0][0] = pre[q][0][1] = pre[q][1][0] = pre[q][1][1] = 0.f;
     }
+    // per-channel epilogue parameters: requested here, in front of the exchange, not behind its barrier (dependent L2 round trips)
+    const float bv = a.bias ? a.bias[col] : 0.f;
+    float g_mu = 0.f, g_rs = 0.f, g_ga = 0.f, g_be = 0.f;
+    if constexpr (GB) {
+        const int grp = col / (a.Cout / a.gb_groups);
+        g_mu = a.gb_mean[n * a.gb_groups + grp];
+        g_rs = a.gb_rstd[n * a.gb_groups + grp];
+        g_ga = a.gb_gamma[col];
+        g_be = a.gb_beta[col];
+    }
     // t arrays in LDS: [2 i][4 b][64 co][TPITCH = 68 tiles-padded]: the tile index is the fast one -- a lane's four consecutive accumulator
     // rows (r & 3) are four consecutive tiles = one 16-byte store, and the finishing thread's eight tiles of a tile row two 16-byte loads
     // (16 + 16 LDS instructions per thread instead of 64 + 64); the 272-byte channel pitch keeps both conflict-free
@@ -454,15 +477,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     __syncthreads();
     WTRACE(47, 2);
 
-    const float bv = a.bias ? a.bias[col] : 0.f;
-    float g_mu = 0.f, g_rs = 0.f, g_ga = 0.f, g_be = 0.f;
-    if constexpr (GB) {
-        const int grp = col / (a.Cout / a.gb_groups);
-        g_mu = a.gb_mean[n * a.gb_groups + grp];
-        g_rs = a.gb_rstd[n * a.gb_groups + grp];
-        g_ga = a.gb_gamma[col];
-        g_be = a.gb_beta[col];
-    }
     double gs1 = 0.0, gs2 = 0.0;
     float se_amax = 0.f;
     const float* tr = Ts + lane * TPITCH + wid * 8;

@@ -357,9 +357,14 @@ def get_conv_mode():
 _ARENA = {"buf": None, "pos": 0, "epoch": 0, "n": 4096, "stream": None}
 
 
+_ZERO_ARENA = os.environ.get("FAVAE_ZERO_ARENA", "1") != "0"      # A/B switch (0: every library call zeroes its own target)
+
+
 def zero_arena_reset(dev):
     """start of a training step: every slot handed out before is invalid from here on; one memset for all of this step's targets"""
     a = _ARENA
+    if not _ZERO_ARENA:
+        return
     if a["buf"] is None or a["buf"].device != torch.device(dev):
         a["buf"] = torch.zeros((a["n"],), dtype=torch.float32, device=dev)
         query("favae_set_zero_arena", a["buf"].data_ptr(), a["n"] * 4)
