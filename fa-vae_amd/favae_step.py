@@ -72,7 +72,7 @@ class GradExchange:
     everything queued so far on the compute streams); finish() queues whatever has not been fired and makes the current stream
     wait for all of them.  RCCL ("nccl" backend) on the GPU; works unchanged on CPU tensors over gloo (tests)."""
 
-    def __init__(self, gflat, segments, side_stream=None):
+    def __init__(self, gflat, segments, side_stream=None, defer=False, timing=False):
         cover = sorted(r for seg in segments for r in seg if r[1] > r[0])
         pos = 0
         for a, b in cover:
@@ -85,37 +85,77 @@ class GradExchange:
         self.cuda = gflat.is_cuda
         self.comm = torch.cuda.Stream() if self.cuda else None
         self.side_stream = side_stream          # callable -> the stream that carries the weight gradients (or None)
+        # defer: fire(i) only marks segment i; every all-reduce is queued by finish(), behind backward (FAVAE_COMM_DEFER=1).  The
+        # collectives then never compete with the whole-CU conv kernels for CUs -- the A/B arm for the first multi-GPU run: whether the
+        # eagerly queued segments really overlap, or slow the conv chain by more than they hide, has never been observed.
+        self.defer = defer
+        # timing: one event in front of every segment's collective (communication stream) and one behind it (a per-segment watcher
+        # stream that waits for the collective's completion): report() turns them into an overlap table against the backward pass
+        self.timing = timing and self.cuda
         self.fired = [False] * len(self.segments)
         self.works = []
+        self.marks = []                         # (segment, start event, end event, bytes)
+        self.watch = [torch.cuda.Stream() for _ in self.segments] if self.timing else None
 
     def reset(self):
         self.fired = [False] * len(self.segments)
         self.works = []
+        self.marks = []
 
-    def fire(self, i):
-        if self.fired[i]:
-            return
-        self.fired[i] = True
+    def _launch(self, i):
         if not self.segments[i]:
             return
+        nbytes = 4 * sum(b - a for a, b in self.segments[i])
         if self.cuda:
             self.comm.wait_stream(torch.cuda.current_stream())
             side = self.side_stream() if self.side_stream is not None else None
             if side is not None:
                 self.comm.wait_stream(side)
             with torch.cuda.stream(self.comm):
-                for a, b in self.segments[i]:
-                    self.works.append(dist.all_reduce(self.gflat[a:b], async_op=True))
+                ev0 = None
+                if self.timing:
+                    ev0 = torch.cuda.Event(enable_timing=True)
+                    ev0.record(self.comm)
+                ws = [dist.all_reduce(self.gflat[a:b], async_op=True) for a, b in self.segments[i]]
+            self.works += ws
+            if self.timing:
+                with torch.cuda.stream(self.watch[i]):
+                    for w in ws:
+                        w.wait()                      # this stream (only) waits for the collective
+                    ev1 = torch.cuda.Event(enable_timing=True)
+                    ev1.record(self.watch[i])
+                self.marks.append((i, ev0, ev1, nbytes))
         else:
             for a, b in self.segments[i]:
                 self.works.append(dist.all_reduce(self.gflat[a:b], async_op=True))
 
+    def fire(self, i):
+        if self.fired[i]:
+            return
+        self.fired[i] = True
+        if not self.defer:
+            self._launch(i)
+
     def finish(self):
         for i in range(len(self.segments)):
-            self.fire(i)
+            self.fire(i)                          # whatever no mark has fired yet (the last segment always)
+        if self.defer:
+            for i in range(len(self.segments)):
+                self._launch(i)
         for w in self.works:
             w.wait()                              # GPU: the current stream waits for the collective; CPU: blocks
         self.works = []
+
+    def report(self, ev_bwd_start, ev_bwd_end):
+        """after a synchronize: per segment (bytes, start / end of its collective in ms after the start of backward, the part of it that
+        ran before backward ended = overlapped, the rest = exposed)"""
+        rows = []
+        t_end = ev_bwd_start.elapsed_time(ev_bwd_end)
+        for i, e0, e1, nb in self.marks:
+            t0, t1 = ev_bwd_start.elapsed_time(e0), ev_bwd_start.elapsed_time(e1)
+            ov = max(0.0, min(t1, t_end) - min(t0, t_end))
+            rows.append({"segment": i, "MB": nb / 1e6, "start_ms": t0, "end_ms": t1, "overlapped_ms": ov, "exposed_ms": (t1 - t0) - ov})
+        return {"backward_ms": t_end, "segments": rows}
 
 
 class TrainStep:
@@ -222,8 +262,11 @@ class TrainStep:
                 segs[i].append((pos, pos + n))
             pos += n
         assert pos == total
-        self.exchange = GradExchange(self.gflat, segs, side_stream=K.side_stream_flushed)
+        self.exchange = GradExchange(self.gflat, segs, side_stream=K.side_stream_flushed,
+                                     defer=os.environ.get("FAVAE_COMM_DEFER", "0") == "1",
+                                     timing=os.environ.get("FAVAE_COMM_TIMING", "0") == "1")
         self._armed = False
+        self._bwd_events = None
 
         def mark(i):
             def cb():
@@ -391,6 +434,10 @@ class TrainStep:
         if self.exchange is not None:           # the gradient marks start their all-reduces only inside THIS backward pass
             self.exchange.reset()               # (not in the partial passes of adaptive_weight)
             self._armed = True
+            if self.exchange.timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._bwd_events = (e0, e1)
         try:
             if bwd is None:
                 out["loss_g"].sum().backward()
@@ -400,6 +447,15 @@ class TrainStep:
         finally:
             if self.exchange is not None:
                 self._armed = False
+                if self.exchange.timing and self._bwd_events is not None:
+                    K.sync_side_stream()        # "end of backward" = the compute stream behind the last weight gradient
+                    self._bwd_events[1].record()
+
+    def comm_report(self):
+        """FAVAE_COMM_TIMING=1: the overlap table of the last step's gradient exchange (call after torch.cuda.synchronize())"""
+        if self.exchange is None or not self.exchange.timing or self._bwd_events is None:
+            return None
+        return self.exchange.report(*self._bwd_events)
 
     def disc_step(self, x):
         """Stage 1 (train_favae.py:108-116): discriminator update on (x, x_recon.detach()); model(x, stage=1) recomputes the

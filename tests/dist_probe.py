@@ -121,6 +121,12 @@ else:
 # a full step() (exchange + Adam) keeps the ranks identical
 ts.step(x)
 torch.cuda.synchronize()
+rep = ts.comm_report()                       # FAVAE_COMM_TIMING=1: when did each segment's collective run, relative to backward?
+if rep is not None and rank == 0:
+    print("COMM TABLE world=%d defer=%s backward %.2f ms" % (world, ts.exchange.defer, rep["backward_ms"]))
+    for r in rep["segments"]:
+        print("  segment %d  %7.2f MB  start %8.3f ms  end %8.3f ms  overlapped %7.3f ms  exposed %7.3f ms"
+              % (r["segment"], r["MB"], r["start_ms"], r["end_ms"], r["overlapped_ms"], r["exposed_ms"]))
 p0 = ts.pflat.clone()
 dist.broadcast(p0, 0)
 assert torch.equal(p0, ts.pflat), "rank %d: parameters diverged after step()" % rank

@@ -168,8 +168,10 @@ class _ToyModel(torch.nn.Module):
 
 
 def _exchange_worker(rank, world, port, q, overlap):
+    # overlap: True = segments fired by the marks, "defer" = the same segments, every collective queued by finish() (FAVAE_COMM_DEFER=1),
+    # False = one all-reduce after backward
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      FAVAE_OVERLAP_COMM="1" if overlap else "0")
+                      FAVAE_OVERLAP_COMM="1" if overlap else "0", FAVAE_COMM_DEFER="1" if overlap == "defer" else "0")
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from favae_step import TrainStep
@@ -179,7 +181,7 @@ def _exchange_worker(rank, world, port, q, overlap):
     state0 = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}      # numpy: pickled by value through the queue
     order = []
     if overlap:
-        assert ts.exchange is not None
+        assert ts.exchange is not None and ts.exchange.defer == (overlap == "defer")
         fire0 = ts.exchange.fire
         ts.exchange.fire = lambda i: (order.append(i) if not ts.exchange.fired[i] else None, fire0(i))[1]
     xs = torch.randn(4, 6, generator=torch.Generator().manual_seed(7))
@@ -197,6 +199,8 @@ def _exchange_worker(rank, world, port, q, overlap):
         ts.exchange.fire = fire_snap
     loss = ((model(x) - x) ** 2).mean() + 0.1 * model.taps
     ts.backward({"loss_g": loss})
+    if overlap == "defer":
+        assert not ts.exchange.works, "deferred mode queued a collective inside backward"
     for i, parts in snaps.items():
         for (a, b), t in zip(ts.exchange.segments[i], parts):
             assert torch.equal(t, ts.gflat[a:b]), "segment %d [%d, %d) was exchanged before its gradient was complete" % (i, a, b)
@@ -211,7 +215,7 @@ def _exchange_worker(rank, world, port, q, overlap):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap", [True, "defer", False])
 def test_trainstep_host_logic_two_ranks(overlap):
     world = 2
     ctx = mp.get_context("spawn")

@@ -36,9 +36,9 @@ def test_model_under_torch_ddp():
     assert "DDP PROBE OK" in out.stdout
 
 
-def _run_probe(world, variant, overlap, port, backend="nccl"):
+def _run_probe(world, variant, overlap, port, backend="nccl", extra_env=None):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FAVAE_PROBE_VARIANT=variant, FAVAE_OVERLAP_COMM="1" if overlap else "0",
-               FAVAE_PROBE_BACKEND=backend)
+               FAVAE_PROBE_BACKEND=backend, **(extra_env or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_probe.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -52,6 +52,21 @@ def test_product_trainstep_distributed_world1(variant, overlap):
     """TrainStep(distributed=True) through RCCL at world size 1 (what this box has): initial broadcast, codebook all-reduces,
     gradient marks and the overlapped bucketed all-reduce all run, and the result is bit-identical to the non-distributed step."""
     _run_probe(1, variant, overlap, 29561)
+
+
+@pytest.mark.parametrize("defer", ["0", "1"])
+def test_gradient_exchange_overlap_table(defer):
+    """the probe prints, per gradient segment, when its collective started and ended relative to the backward pass
+    (FAVAE_COMM_TIMING=1) -- eagerly queued (default) and deferred to the end of backward (FAVAE_COMM_DEFER=1, the A/B arm for the
+    first real multi-GPU run).  World 1 over RCCL here; the same command prints the table at world N.  Results stay bit-identical."""
+    out = _run_probe(1, "gauss_resblock", True, 29565, extra_env={"FAVAE_COMM_TIMING": "1", "FAVAE_COMM_DEFER": defer})
+    assert "COMM TABLE world=1 defer=%s" % (defer == "1") in out
+    rows = [l for l in out.splitlines() if l.strip().startswith("segment ")]
+    assert len(rows) == 4, out[-1500:]
+    if defer == "1":                                  # nothing may start before backward has ended
+        for l in rows:
+            assert float(l.split("overlapped")[1].split("ms")[0]) < 0.05, l
+    print(out[out.index("COMM TABLE"):])
 
 
 @pytest.mark.parametrize("variant", ["gauss_resblock", "same_conv_gauss"])
