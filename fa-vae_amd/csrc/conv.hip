@@ -766,10 +766,19 @@ static int thin_kind(const favae_conv_desc* d, bool has_affine) {
 }
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// geometry of conv3x3_wino_sp_kernel (conv_wino.h): dense 3x3, stride 1, pad 1, 16 x 16-pixel tiles x 64 output channels, h3 scheme.  Its
+// 64-channel tile also takes Cout == 64 (the direct split kernels need more than 64: their tiles are 128 wide) and, through XFORM = 3,
+// any fused activation (LeakyReLU / ReLU on load: the VGG16 convs of LPIPS, losses/lpips.py:74-96).
+static bool wino_geometry(const favae_conv_desc* d) {
+    return use_wino() && conv_mode() == 2 && !desc_special(d) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
+           d->gather == FAVAE_GATHER_PLAIN && d->Hout == d->Hin && d->Wout == d->Win && d->Hin % 16 == 0 && d->Win % 16 == 0 &&
+           d->Cout % 64 == 0 && d->Cin % 16 == 0;
+}
 static bool sp_fwd_eligible(const favae_conv_desc* d, bool has_affine) {
     if (!desc_ok(d) || force_generic() || force_nobuf() || !use_b6()) return false;
     const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, wb = (size_t)d->Cout * d->KH * d->KW * d->Cin * 6;
-    return d->Cout > 64 && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) && (d->gather == FAVAE_GATHER_PLAIN || !has_affine);
+    return (d->Cout > 64 || (d->Cout == 64 && wino_geometry(d))) && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) &&
+           (d->gather == FAVAE_GATHER_PLAIN || !has_affine);
 }
 
 static int wrec_bytes(int planes) {
@@ -948,13 +957,18 @@ extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, co
 static bool halo3_fp16_ok(const favae_conv_desc* d, bool has_affine);
 static bool wino_ok(const favae_conv_desc* d, bool has_affine);
 
-static bool planes_producer_ok(const favae_conv_desc* d, bool has_affine) { return conv_mode() == 2 && halo3_fp16_ok(d, has_affine); }
+static bool planes_producer_ok(const favae_conv_desc* d, bool has_affine) {      // the direct halo kernel stores them: its shapes only
+    return conv_mode() == 2 && halo3_fp16_ok(d, has_affine) && d->Cout > 64 &&
+           (!has_affine || d->act == FAVAE_ACT_NONE || d->act == FAVAE_ACT_SILU);
+}
 
 static bool halo3_fp16_ok(const favae_conv_desc* d, bool has_affine) {
     if (!sp_fwd_eligible(d, has_affine) || conv_mode() == 3 || conv_mode() == 0 || desc_special(d) || !use_halo()) return false;
     const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, wb = (size_t)d->Cout * 9 * d->Cin * 4;
-    if (has_affine && d->act != FAVAE_ACT_NONE && d->act != FAVAE_ACT_SILU) return false;
-    return d->Cout > 64 && d->Cin % 16 == 0 && d->stride == 1 && d->gather == FAVAE_GATHER_PLAIN && d->KH == 3 && d->KW == 3 &&
+    // shapes only the Winograd kernel takes (64 output channels; a fused activation other than SiLU): eligible exactly when IT runs them
+    const bool wg = wino_geometry(d) && (size_t)d->Cout * d->Cin * 64 < (1u << 31) && (!has_affine || d->Cin <= wino::AFF_C);
+    if (has_affine && d->act != FAVAE_ACT_NONE && d->act != FAVAE_ACT_SILU && !wg) return false;
+    return (d->Cout > 64 || wg) && d->Cin % 16 == 0 && d->stride == 1 && d->gather == FAVAE_GATHER_PLAIN && d->KH == 3 && d->KW == 3 &&
            d->pad == 1 && d->Hout == d->Hin && d->Wout == d->Win && d->Hin % 8 == 0 && d->Win % 16 == 0 && xb < (1u << 31) &&
            wb < (1u << 31) && (size_t)d->N * d->Hout * d->Wout * d->Cout * 4 < ((size_t)1 << 32);
 }
@@ -1204,7 +1218,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     const bool halo2_ok = special && halo_common && use_halo2() && d->KH == 2 && d->KW == 2 && d->lat_step == 2 && xf == 0 &&
                           (d->pad == 0 || d->pad == 1) && (a.pad_w == 0 || a.pad_w == 1);
     if (wino) {
-        if (!(halo_ok && wplanes == 2 && !planes_out && d->Hin % 16 == 0 && d->Win % 16 == 0 && d->Cout % 64 == 0 && d->w_rec_offset == 0))
+        if (!(!special && buf_ok && use_b6() && w6 && wino_geometry(d) && wplanes == 2 && !planes_out && d->w_rec_offset == 0))
             return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (gb && (xf != 0 || bias || resid)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (stats_part && !(xf == 0 || xf == 2)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
