@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void vq_dist_top2_kernel(const float* __restri
 
 // one wave per token: merge tile partials, flag near-ties
 __global__ __launch_bounds__(256) void vq_select_kernel(const Top2* part, int T, int tiles_c, float tie_eps, long long* idx,
-                                                        int* flag) {
+                                                        int* flag, float* best32) {
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tok >= T) return;
     Top2 t;
@@ -185,42 +185,77 @@ __global__ __launch_bounds__(256) void vq_select_kernel(const Top2* part, int T,
         // maximum and returns the first one, i.e. index 0 of an all-NaN score row (the NaN then propagates through zn / the loss)
         idx[tok] = t.i1 == 0x7fffffff ? 0 : t.i1;
         flag[tok] = (t.v1 - t.v2 < tie_eps) ? 1 : 0;
+        best32[tok] = t.v1;
     }
 }
 
-// flagged tokens: full fp64 re-score (first max wins)
-__global__ __launch_bounds__(256) void vq_refine_kernel(const float* en, const float* zn, const int* flag, int C, int d,
-                                                        long long* idx) {
+// flagged tokens: fp64 re-score, first maximum wins (what torch's argmax over the reference's fp32 scores is compared with).  One
+// workgroup per flagged token -- a handful per step, so the kernel's time is ONE workgroup's latency: round 1-3 let every thread walk
+// whole code rows (64 distinct cache lines per load, 256 fp64 FMAs per code: 0.54 ms for 16384 codes).  Now the code rows go through LDS
+// in tiles of 32 (coalesced float4 loads, rows padded by 4 floats: conflict-free ds_read_b128), eight threads per code form the fp32
+// score of their slice, and only codes whose fp32 score is within 2 tie_eps of the fp32 maximum -- the fp64 winner is always among them:
+// an fp32 score is off by < 3e-7, tie_eps is 4e-6 -- are re-scored in fp64 by the thread that owns them.
+constexpr int VQ_RT = 32;                                // codes per tile
+__global__ __launch_bounds__(256) void vq_refine_kernel(const float* en, const float* zn, const int* flag, const float* best32, int C,
+                                                        int d, float tie_eps, long long* idx) {
     const int tok = blockIdx.x;
     if (!flag[tok]) return;
-    __shared__ double bv[256];
-    __shared__ int bi[256];
-    extern __shared__ float zrow[];
+    extern __shared__ __attribute__((aligned(16))) float rsm[];
+    const int P = d + 4;                                 // row pitch (floats)
+    float* zrow = rsm;                                   // [d]
+    float* tile = rsm + P;                               // [VQ_RT][P]
+    float* part = tile + VQ_RT * P;                      // [VQ_RT][8]
+    __shared__ double bv[VQ_RT];
+    __shared__ int bi[VQ_RT];
     for (int i = threadIdx.x; i < d; i += 256) zrow[i] = zn[(size_t)tok * d + i];
-    __syncthreads();
+    const int code = threadIdx.x >> 3, sl = threadIdx.x & 7;      // 32 codes x 8 slices of d / 8 (d % 32 == 0 here; tails handled)
+    const int k0 = (d / 8) * sl, k1 = sl == 7 ? d : k0 + d / 8;
+    const float thr = best32[tok] - 2.f * tie_eps;
     double best = -1e300;
     int besti = 0x7fffffff;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float* e = en + (size_t)c * d;
-        double s = 0.0;
-        for (int k = 0; k < d; ++k) s += (double)e[k] * (double)zrow[k];
-        if (s > best) { best = s; besti = c; }          // ascending c per thread: first max kept
-    }
-    bv[threadIdx.x] = best;
-    bi[threadIdx.x] = besti;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) {
-            const double ov = bv[threadIdx.x + o];
-            const int oi = bi[threadIdx.x + o];
-            if (ov > bv[threadIdx.x] || (ov == bv[threadIdx.x] && oi < bi[threadIdx.x])) {
-                bv[threadIdx.x] = ov;
-                bi[threadIdx.x] = oi;
+    const int d4 = d / 4;
+    for (int c0 = 0; c0 < C; c0 += VQ_RT) {
+        __syncthreads();
+        if (d % 4 == 0) {
+            for (int i = threadIdx.x; i < VQ_RT * d4; i += 256) {
+                const int r = i / d4, k4 = i - r * d4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + r < C) v = *reinterpret_cast<const float4*>(en + (size_t)(c0 + r) * d + 4 * k4);
+                *reinterpret_cast<float4*>(tile + r * P + 4 * k4) = v;
+            }
+        } else {
+            for (int i = threadIdx.x; i < VQ_RT * d; i += 256) {
+                const int r = i / d, k = i - r * d;
+                tile[r * P + k] = c0 + r < C ? en[(size_t)(c0 + r) * d + k] : 0.f;
             }
         }
         __syncthreads();
+        float s32 = 0.f;
+        const float* e = tile + code * P;
+        for (int k = k0; k < k1; ++k) s32 = fmaf(e[k], zrow[k], s32);
+        part[code * 8 + sl] = s32;
+        __syncthreads();
+        if (sl == 0 && c0 + code < C) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += part[code * 8 + j];
+            if (t >= thr) {                                      // candidate: fp64 score over the whole row
+                double sd = 0.0;
+                for (int k = 0; k < d; ++k) sd += (double)e[k] * (double)zrow[k];
+                if (sd > best) { best = sd; besti = c0 + code; }      // ascending codes per thread: first maximum kept
+            }
+        }
     }
-    if (threadIdx.x == 0) idx[tok] = bi[0] == 0x7fffffff ? 0 : bi[0];
+    __syncthreads();
+    if (sl == 0) { bv[code] = best; bi[code] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double b = bv[0];
+        int ix = bi[0];
+        for (int j = 1; j < VQ_RT; ++j)
+            if (bv[j] > b || (bv[j] == b && bi[j] < ix)) { b = bv[j]; ix = bi[j]; }
+        idx[tok] = ix == 0x7fffffff ? 0 : ix;
+    }
 }
 
 __global__ __launch_bounds__(256) void vq_gather_kernel(const float* embed, const long long* idx, float* zq, int T, int d, int C) {
@@ -404,7 +439,7 @@ __global__ __launch_bounds__(256) void vq_ema_kernel(float* embed, float* cluste
 
 extern "C" size_t favae_vq_workspace(int T, int d, int C) {
     const size_t tiles_c = (size_t)(C + VBM - 1) / VBM;
-    return (size_t)T * tiles_c * sizeof(Top2) + (size_t)T * sizeof(int) + 256;
+    return (size_t)T * tiles_c * sizeof(Top2) + (size_t)T * (sizeof(int) + sizeof(float)) + 256;
 }
 
 extern "C" int favae_vq_lookup(const float* z, const float* embed, int T, int d, int C, float tie_eps, int64_t* idx, float* zq,
@@ -416,6 +451,7 @@ extern "C" int favae_vq_lookup(const float* z, const float* embed, int T, int d,
     const int tiles_c = cdiv(C, VBM), tiles_t = cdiv(T, VBN);
     Top2* part = (Top2*)ws;
     int* flag = (int*)((char*)ws + (size_t)T * tiles_c * sizeof(Top2));
+    float* best32 = (float*)(flag + T);
     FAVAE_KLAUNCH(l2norm_rows_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, z, zn, T, d);
     FAVAE_CHECK_LAUNCH();
     FAVAE_KLAUNCH(l2norm_rows_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, embed, en, C, d);
@@ -424,11 +460,14 @@ extern "C" int favae_vq_lookup(const float* z, const float* embed, int T, int d,
                        T, d, tiles_c);
     FAVAE_CHECK_LAUNCH();
     FAVAE_KLAUNCH(vq_select_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, (const Top2*)part, T, tiles_c, tie_eps,
-                       (long long*)idx, flag);
+                       (long long*)idx, flag, best32);
     FAVAE_CHECK_LAUNCH();
     if (tie_eps > 0.f) {
-        FAVAE_KLAUNCH(vq_refine_kernel, dim3(T), dim3(256), (size_t)d * sizeof(float), s, (const float*)en, (const float*)zn,
-                           (const int*)flag, C, d, (long long*)idx);
+        const size_t rshm = ((size_t)(d + 4) * (VQ_RT + 1) + VQ_RT * 8) * sizeof(float);
+        if (rshm > 150 * 1024) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+        if (rshm > 48 * 1024) (void)hipFuncSetAttribute((const void*)vq_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rshm);
+        FAVAE_KLAUNCH(vq_refine_kernel, dim3(T), dim3(256), rshm, s, (const float*)en, (const float*)zn, (const int*)flag,
+                           (const float*)best32, C, d, tie_eps, (long long*)idx);
         FAVAE_CHECK_LAUNCH();
     }
     FAVAE_KLAUNCH(vq_gather_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, embed, (const long long*)idx, zq, T, d, C);
