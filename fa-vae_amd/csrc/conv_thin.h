@@ -34,24 +34,26 @@ struct ThinArgs {
 };
 
 
-// Sum over the QW (16 or 32) lanes of a pixel group.  A butterfly from the SMALL offsets up (1, 2, 4, 8, 16):
-// the four steps inside a 16-lane row are DPP moves on the vector ALU -- xor 1 / xor 2 as quad permutations; then, all lanes of a quad
-// (of a half row) holding the same partial sum, the half-row mirror pairs every lane with a lane of the other quad and the row mirror
-// with a lane of the other half row -- instead of ds_bpermute round trips through the LDS crossbar (15 per pixel and lane in
-// thin_out_kernel: 1.03 -> 0.69 ms for conv_out at batch 32).  The total is valid in the LAST lane of the group (in all lanes for
-// QW = 16).  (Rounds 1-3 summed from offset 16 down with __shfl_xor: the same five additions per lane in another association, so
-// results differ in the last bit from those builds.)
+// Sum over the QW (16 or 32) lanes of a pixel group, every lane gets the total: the xor butterfly acc += shfl_xor(acc, off), off = QW/2 .. 1,
+// with the same operands in the same order as rounds 1-3 (bit-identical results: the random-init training trajectory of bench.py is
+// unchanged), but the four steps inside a 16-lane row are DPP moves on the vector ALU instead of ds_bpermute round trips through the LDS
+// crossbar (15 per pixel and lane in thin_out_kernel: what bounded it): xor 8 = row_ror:8, xor 4 = row_shl:4 for the lanes with bit 2
+// clear (banks 0, 2) merged with row_shr:4 for the others (banks 1, 3), xor 2 / xor 1 = quad permutations.  Only the xor-16 step of a
+// 32-lane group crosses a row and stays a shuffle.
 __device__ __forceinline__ float thin_group_sum(float acc, int QW) {
+    if (QW == 32) acc += __shfl_xor(acc, 16);
     auto dpp = [](float v, auto ctrl) {
         return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
     };
-    acc += dpp(acc, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]: xor 1
-    acc += dpp(acc, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]: xor 2
-    acc += dpp(acc, std::integral_constant<int, 0x141>{});      // row_half_mirror: i <-> 7 - i   (a lane of the other quad of the half row)
-    acc += dpp(acc, std::integral_constant<int, 0x140>{});      // row_mirror: i <-> 15 - i       (a lane of the other half row)
-    // 32-lane group = two rows: row_bcast:15 adds lane 15 of the even row to every lane of the odd row (row mask 0b1010; the even rows
-    // receive the zero of `old`) -- the total is then in the LAST lanes of the group (q >= 16), which is where the caller stores from
-    if (QW == 32) acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x142, 0xA, 0xF, false));
+    acc += dpp(acc, std::integral_constant<int, 0x128>{});                               // row_ror:8: lane i <- lane i ^ 8
+    {
+        const int v = __builtin_bit_cast(int, acc);
+        int t = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);               // row_shl:4, banks 0 and 2: lane i <- lane i + 4
+        t = __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);                    // row_shr:4, banks 1 and 3: lane i <- lane i - 4
+        acc += __builtin_bit_cast(float, t);
+    }
+    acc += dpp(acc, std::integral_constant<int, 0x4E>{});                                // quad_perm [2,3,0,1]: xor 2
+    acc += dpp(acc, std::integral_constant<int, 0xB1>{});                                // quad_perm [1,0,3,2]: xor 1
     return acc;
 }
 
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void thin_out_kernel(ThinArgs a) {
                 acc = thin_group_sum(acc, QW);
                 s[co] = acc;
             }
-            if (q == QW - 1) {                                      // the lane thin_group_sum leaves the total in
+            if (q == 0) {
                 float* op = a.y + ((size_t)(n * a.H + y) * a.W + xx) * CT;
 #pragma unroll
                 for (int co = 0; co < CT; ++co) {
