@@ -64,6 +64,28 @@ __device__ __forceinline__ double block_sum_d256(double v, double* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// Sum over aligned groups of LP = 16, 32 or 64 lanes, every lane gets its group's total: the xor butterfly v += shfl_xor(v, off),
+// off = LP/2 .. 1, with the same operands in the same order (bit-identical to that loop), but the four steps inside a 16-lane row are
+// DPP moves on the vector ALU instead of ds_bpermute round trips through the LDS crossbar (15 per pixel and lane in thin_out_kernel:
+// what bounded it, 1.03 -> 0.77 ms): xor 8 = row_ror:8, xor 4 = row_shl:4 for the lanes with bit 2 clear (banks 0, 2) merged with
+// row_shr:4 for the others (banks 1, 3), xor 2 / xor 1 = quad permutations.  Only the steps that cross a row (16, 32) stay shuffles.
+template <int LP>
+__device__ __forceinline__ float group_sum_xor(float acc) {
+    static_assert(LP == 16 || LP == 32 || LP == 64, "group of 16, 32 or 64 lanes");
+    if (LP == 64) acc += __shfl_xor(acc, 32, 64);
+    if (LP >= 32) acc += __shfl_xor(acc, 16, 64);
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x128, 0xF, 0xF, true));      // row_ror:8
+    {
+        const int v = __builtin_bit_cast(int, acc);
+        int u = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);               // row_shl:4, banks 0 and 2: lane i <- lane i + 4
+        u = __builtin_amdgcn_update_dpp(u, v, 0x114, 0xF, 0xA, false);                    // row_shr:4, banks 1 and 3: lane i <- lane i - 4
+        acc += __builtin_bit_cast(float, u);
+    }
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x4E, 0xF, 0xF, true));       // xor 2
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0xB1, 0xF, 0xF, true));       // xor 1
+    return acc;
+}
+
 // ---- buffer addressing: wave-uniform descriptor + per-lane 32-bit byte offset (VGPR) + scalar byte offset (SGPR); offsets at or
 // beyond the descriptor's size (FAVAE_OOB) load zeros / drop the store in hardware (no exec-mask predication, no 64-bit address math)
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));

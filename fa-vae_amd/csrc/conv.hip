@@ -1129,6 +1129,24 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     if (!w6) {
         const int tk = thin_kind(d, scale != nullptr);
         const int xf0 = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_NONE ? 1 : 3)) : 0;
+        if (d->Cout == 1 && d->Cin % 4 == 0 && d->gather == FAVAE_GATHER_PLAIN && !desc_special(d) && !resid && !force_generic() &&
+            thin_enabled() && al16(x) && al16(w) && al16(scale) && al16(shift)) {            // one output channel: a wave per output pixel
+            ThinArgs t{};
+            t.x = x; t.w = w; t.bias = bias; t.scale = scale; t.shift = shift; t.y = y;
+            t.N = d->N; t.H = d->Hin; t.W = d->Win; t.Cw = d->Cin;
+            t.aff_stride = d->affine_per_image ? d->Cin : 0;
+            t.act = d->act;
+            const long M1 = (long)d->N * d->Hout * d->Wout;
+            const dim3 g1((unsigned)((M1 + 3) / 4));
+#define FAVAE_LAUNCH_COUT1(X) FAVAE_KLAUNCH((conv_cout1_kernel<X>), g1, dim3(256), 0, (hipStream_t)stream, t, d->Hout, d->Wout, d->KH, d->KW, d->stride, d->pad)
+            if (xf0 == 0) FAVAE_LAUNCH_COUT1(0);
+            else if (xf0 == 1) FAVAE_LAUNCH_COUT1(1);
+            else if (xf0 == 2) FAVAE_LAUNCH_COUT1(2);
+            else FAVAE_LAUNCH_COUT1(3);
+#undef FAVAE_LAUNCH_COUT1
+            FAVAE_CHECK_LAUNCH();
+            return FAVAE_OK;
+        }
         if (tk && al16(x) && al16(y) && al16(resid) && al16(scale) && al16(shift)) {
             ThinArgs t{};
             t.x = x; t.w = w; t.bias = bias; t.resid = resid; t.scale = scale; t.shift = shift; t.y = y;

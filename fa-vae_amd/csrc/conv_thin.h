@@ -34,28 +34,8 @@ struct ThinArgs {
 };
 
 
-// Sum over the QW (16 or 32) lanes of a pixel group, every lane gets the total: the xor butterfly acc += shfl_xor(acc, off), off = QW/2 .. 1,
-// with the same operands in the same order as rounds 1-3 (bit-identical results: the random-init training trajectory of bench.py is
-// unchanged), but the four steps inside a 16-lane row are DPP moves on the vector ALU instead of ds_bpermute round trips through the LDS
-// crossbar (15 per pixel and lane in thin_out_kernel: what bounded it): xor 8 = row_ror:8, xor 4 = row_shl:4 for the lanes with bit 2
-// clear (banks 0, 2) merged with row_shr:4 for the others (banks 1, 3), xor 2 / xor 1 = quad permutations.  Only the xor-16 step of a
-// 32-lane group crosses a row and stays a shuffle.
-__device__ __forceinline__ float thin_group_sum(float acc, int QW) {
-    if (QW == 32) acc += __shfl_xor(acc, 16);
-    auto dpp = [](float v, auto ctrl) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
-    };
-    acc += dpp(acc, std::integral_constant<int, 0x128>{});                               // row_ror:8: lane i <- lane i ^ 8
-    {
-        const int v = __builtin_bit_cast(int, acc);
-        int t = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);               // row_shl:4, banks 0 and 2: lane i <- lane i + 4
-        t = __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);                    // row_shr:4, banks 1 and 3: lane i <- lane i - 4
-        acc += __builtin_bit_cast(float, t);
-    }
-    acc += dpp(acc, std::integral_constant<int, 0x4E>{});                                // quad_perm [2,3,0,1]: xor 2
-    acc += dpp(acc, std::integral_constant<int, 0xB1>{});                                // quad_perm [1,0,3,2]: xor 1
-    return acc;
-}
+// pixel-group sum of thin_out_kernel: common.h group_sum_xor (DPP butterfly, bit-identical to the __shfl_xor loop of rounds 1-3)
+__device__ __forceinline__ float thin_group_sum(float acc, int QW) { return QW == 32 ? group_sum_xor<32>(acc) : group_sum_xor<16>(acc); }
 
 template <int XFORM>
 __device__ __forceinline__ float4 thin_xform(float4 v, float4 sc, float4 sh, bool ok, int act) {
@@ -311,4 +291,45 @@ __global__ __launch_bounds__(256) void thin_out_kernel(ThinArgs a) {
                 }
         }
     }
+}
+
+// ---- one output channel (the PatchGAN head, models/discriminator.py:213: Conv2d(512, 1, 4, 1, 1)) ----------------------------------------
+// y[p] = bias + sum_{tap, ci} T(x)[p + tap][ci] w[tap][ci]: a dot product of K = KH KW Cin terms per output pixel.  The implicit-GEMM
+// kernels pad the single output channel to a 32-wide MFMA tile and walk K in 512 barrier-separated steps with 225 workgroups on 256 CUs
+// (285 us for 0.5 GFLOP at batch 32).  Here ONE WAVE owns an output pixel: its lanes stride over the (tap, channel quad) pairs -- weights
+// are one contiguous float4 stream (OHWI with O = 1), the input rows of a tap are contiguous channel runs -- and fold with the fixed-order
+// wave sum.  Any kernel size / stride / pad, plain gather, fused input transform (BatchNorm / activation on load).
+template <int XFORM>
+__global__ __launch_bounds__(256) void conv_cout1_kernel(ThinArgs a, int Hout, int Wout, int KH, int KW, int stride, int pad) {
+    const int lane = threadIdx.x & 63;
+    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long M = (long)a.N * Hout * Wout;
+    if (p >= M) return;
+    const int ow = (int)(p % Wout), oh = (int)((p / Wout) % Hout), n = (int)(p / ((long)Wout * Hout));
+    const int C4 = a.Cw >> 2, K4 = KH * KW * C4;
+    const float4* w4 = reinterpret_cast<const float4*>(a.w);
+    // four independent partial sums (e, e + 64, e + 128, e + 192: four loads in flight per lane), folded in a fixed order
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int e0 = lane; e0 < K4; e0 += 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 64 * u;
+            if (e >= K4) continue;
+            const int tap = e / C4, cq = e - tap * C4;
+            const int kh = tap / KW, kw = tap - kh * KW;
+            const int ih = oh * stride + kh - pad, iw = ow * stride + kw - pad;
+            if ((unsigned)ih >= (unsigned)a.H || (unsigned)iw >= (unsigned)a.W) continue;   // zero padding of the TRANSFORMED tensor
+            float4 v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + ih) * a.W + iw) * a.Cw + 4 * cq);
+            if (XFORM) {
+                const float4 sc = *reinterpret_cast<const float4*>(a.scale + (size_t)n * a.aff_stride + 4 * cq);
+                const float4 sh = *reinterpret_cast<const float4*>(a.shift + (size_t)n * a.aff_stride + 4 * cq);
+                v = xform4_t<XFORM>(v, sc, sh, a.act);
+            }
+            const float4 w = w4[e];
+            ps[u] = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, fmaf(v.w, w.w, ps[u]))));
+        }
+    }
+    float acc = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    acc = wave_sum(acc);
+    if (lane == 0) a.y[p] = acc + (a.bias ? a.bias[0] : 0.f);
 }

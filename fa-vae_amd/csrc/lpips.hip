@@ -26,6 +26,7 @@ struct LpGeom {
 
 template <int LP>
 __device__ __forceinline__ float group_sum(float v) {
+    if constexpr (LP >= 16) return group_sum_xor<LP>(v);             // DPP butterfly, same operand order (common.h)
 #pragma unroll
     for (int o = LP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
