@@ -51,7 +51,8 @@ def _run_probe(world, variant, overlap, port, backend="nccl", extra_env=None):
 def test_product_trainstep_distributed_world1(variant, overlap):
     """TrainStep(distributed=True) through RCCL at world size 1 (what this box has): initial broadcast, codebook all-reduces,
     gradient marks and the overlapped bucketed all-reduce all run, and the result is bit-identical to the non-distributed step."""
-    _run_probe(1, variant, overlap, 29561)
+    port = 29551 + 2 * [("gauss_resblock", True), ("same_conv_gauss", True), ("gauss_resblock", False)].index((variant, overlap))
+    _run_probe(1, variant, overlap, port)
 
 
 @pytest.mark.parametrize("defer", ["0", "1"])
@@ -59,7 +60,7 @@ def test_gradient_exchange_overlap_table(defer):
     """the probe prints, per gradient segment, when its collective started and ended relative to the backward pass
     (FAVAE_COMM_TIMING=1) -- eagerly queued (default) and deferred to the end of backward (FAVAE_COMM_DEFER=1, the A/B arm for the
     first real multi-GPU run).  World 1 over RCCL here; the same command prints the table at world N.  Results stay bit-identical."""
-    out = _run_probe(1, "gauss_resblock", True, 29565, extra_env={"FAVAE_COMM_TIMING": "1", "FAVAE_COMM_DEFER": defer})
+    out = _run_probe(1, "gauss_resblock", True, 29565 + int(defer), extra_env={"FAVAE_COMM_TIMING": "1", "FAVAE_COMM_DEFER": defer})
     assert "COMM TABLE world=1 defer=%s" % (defer == "1") in out
     rows = [l for l in out.splitlines() if l.strip().startswith("segment ")]
     assert len(rows) == 4, out[-1500:]
@@ -84,7 +85,9 @@ def test_product_trainstep_two_ranks_on_one_gpu(variant, overlap):
     on device tensors -- real VQGANFCM + HIP kernels + gradient marks / GradExchange + the two codebook all-reduces
     (models/l2_quantize.py:419,427; favae_scripts/train_favae.py:344-347), 2 ranks x batch 2 against one rank on the concatenated
     batch: gradients <= 2e-5 of the max, codebooks <= 1e-6, cluster sizes equal, parameters identical on both ranks after step()."""
-    out = _run_probe(2, variant, overlap, 29571, backend="gloo")
+    # one rendezvous port per variant: consecutive launches on the same port raced with the previous store's teardown once (round 4)
+    port = 29571 + 2 * [("gauss_resblock", True), ("same_conv_gauss", True), ("gauss_resblock", False)].index((variant, overlap))
+    out = _run_probe(2, variant, overlap, port, backend="gloo")
     assert "backend=gloo" in out
 
 
