@@ -324,11 +324,13 @@ def test_winograd_conv_path_matches_direct_kernels(K, cin, cout, hw):
 
 
 @pytest.mark.parametrize("N,cin,cout,H,W", [(1, 16, 128, 16, 16), (3, 32, 192, 16, 48), (2, 48, 128, 32, 16), (1, 512, 128, 16, 16),
-                                            (2, 64, 320, 48, 32)])
+                                            (2, 64, 320, 48, 32), (2, 64, 64, 32, 32), (1, 128, 64, 16, 32)])
 def test_winograd_conv_shapes_against_direct_kernel(K, N, cin, cout, H, W):
     """Edge shapes of the Winograd kernel: one / two / three K chunks (Cin = 16, 32, 48), a 32-chunk K loop, non-square images, batch 1
-    and 3, a channel count that is not a power of two (five 64-channel tiles), with bias + residual and with the fused GroupNorm+SiLU
-    (16 groups): forward, data gradient and the gradients that flow through the epilogue by-products, against the direct kernel."""
+    and 3, a channel count that is not a power of two (five 64-channel tiles), exactly ONE channel tile (Cout = 64, round 4: only the
+    Winograd kernel takes it on the split path, the comparison arm is then the fp32-MFMA kernel), with bias + residual and with the
+    fused GroupNorm+SiLU (16 groups): forward, data gradient and the gradients that flow through the epilogue by-products, against the
+    direct kernel."""
     import favae_hip as H_
     if not H_.query("favae_get_wino"):
         pytest.skip("Winograd path switched off (FAVAE_WINO=0)")
@@ -362,6 +364,41 @@ def test_winograd_conv_shapes_against_direct_kernel(K, N, cin, cout, H, W):
         scale = float(v.abs().max())
         assert float((u - v).abs().max()) <= 2e-5 * scale, "%s: Winograd and direct kernels differ by %.2e of the maximum" % (
             nm, float((u - v).abs().max()) / scale)
+
+
+@pytest.mark.parametrize("cout", [64, 128])
+def test_winograd_conv_with_fused_leaky_relu(K, cout):
+    """Round 4: any fused activation goes through the Winograd kernel (XFORM = 3), not only SiLU -- the LeakyReLU / ReLU-on-load convs
+    of the discriminator-style and VGG16 stacks (cfg.norm == "act").  Forward and data gradient against the direct path."""
+    from ctypes import byref
+    import favae_hip as H_
+    if not H_.query("favae_get_wino"):
+        pytest.skip("Winograd path switched off (FAVAE_WINO=0)")
+    torch.manual_seed(77 + cout)
+    d = dev()
+    x = torch.randn(2, 64, 32, 48, device=d)
+    w = torch.randn(cout, 64, 3, 3, device=d) * math.sqrt(1.0 / (9 * 64))
+    b = torch.randn(cout, device=d) * 0.1
+    gy = torch.randn(2, cout, 32, 48, device=d)
+    cfg = K.ConvCfg(3, 3, 1, 1, act=H_.ACT_LEAKY02, norm="act")
+    dd = H_.make_conv_desc(2, 32, 48, 64, 32, 48, cout, 3, 3, 1, 1, H_.GATHER_PLAIN, H_.ACT_LEAKY02, 0)
+    assert H_.query("favae_conv_wino_ok", byref(dd), 1) == 1, "the Winograd kernel does not take this shape"
+
+    def run(wino):
+        prev = H_.query("favae_set_wino", 1 if wino else 0)
+        try:
+            xg = x.clone().requires_grad_(True)
+            y = K.fused_conv(xg, w, b, cfg=cfg)
+            (dx,) = torch.autograd.grad(y, (xg,), gy)
+            torch.cuda.synchronize()
+            return y.detach(), dx
+        finally:
+            H_.query("favae_set_wino", prev)
+    (y1, dx1), (y0, dx0) = run(True), run(False)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.leaky_relu(x.double().cpu(), 0.2), w.double().cpu(), b.double().cpu(), padding=1)
+    for nm, u, v in (("y", y1, y0), ("dx", dx1, dx0)):
+        assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()), nm
+    assert float((y1.double().cpu() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
 BLOCK_DIMS = {"res_same": ("res", (64, 64)), "res_short": ("res", (32, 96)), "nonres": ("nonres", (64, 64)),
