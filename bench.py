@@ -260,6 +260,8 @@ class Prof:
 
 def kernel_planes(name):
     """operand planes of a split-precision conv kernel from its instantiation name (None: not a split kernel)"""
+    if name.startswith(("vq_dist_top2_h3_kernel", "bgemm_sp_kernel")):      # h3 (sp::Scheme<2>) whatever the build mode: codebook scores, SDPA
+        return 2
     if not name.endswith(">"):
         return None
     args = [a.strip() for a in name[name.index("<") + 1:-1].split(",")]

@@ -41,7 +41,8 @@ __device__ __forceinline__ void top2_merge(Top2& a, const Top2& b) {
     }
 }
 
-__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* x, float* out, int rows, int d) {
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* x, float* out, int rows, int d, int* zero) {
+    if (zero && blockIdx.x == 0 && threadIdx.x == 0) *zero = 0;          // the near-tie counter of this lookup (vq_select_kernel counts)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* p = x + (size_t)row * d;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void vq_dist_top2_h3_kernel(const float* __res
 
 // one wave per token: merge tile partials, flag near-ties
 __global__ __launch_bounds__(256) void vq_select_kernel(const Top2* part, int T, int tiles_c, float tie_eps, long long* idx,
-                                                        int* flag, float* best32) {
+                                                        int* list, int* count, float* best32) {
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tok >= T) return;
     Top2 t;
@@ -311,22 +312,25 @@ __global__ __launch_bounds__(256) void vq_select_kernel(const Top2* part, int T,
         // a token with a NaN component compares false everywhere and keeps the sentinel: torch.argmax treats NaN as the
         // maximum and returns the first one, i.e. index 0 of an all-NaN score row (the NaN then propagates through zn / the loss)
         idx[tok] = t.i1 == 0x7fffffff ? 0 : t.i1;
-        flag[tok] = (t.v1 - t.v2 < tie_eps) ? 1 : 0;
+        if (t.v1 - t.v2 < tie_eps) list[atomicAdd(count, 1)] = tok;      // list order is arbitrary, every entry is settled on its own
         best32[tok] = t.v1;
     }
 }
 
-// flagged tokens: fp64 re-score, first maximum wins (what torch's argmax over the reference's fp32 scores is compared with).  One
-// workgroup per flagged token -- a handful per step, so the kernel's time is ONE workgroup's latency: round 1-3 let every thread walk
-// whole code rows (64 distinct cache lines per load, 256 fp64 FMAs per code: 0.54 ms for 16384 codes).  Now the code rows go through LDS
-// in tiles of 32 (coalesced float4 loads, rows padded by 4 floats: conflict-free ds_read_b128), eight threads per code form the fp32
-// score of their slice, and only codes whose fp32 score is within 2 tie_eps of the fp32 maximum -- the fp64 winner is always among them:
-// an fp32 score is off by < 3e-7, tie_eps is 4e-6 -- are re-scored in fp64 by the thread that owns them.
-constexpr int VQ_RT = 32;                                // codes per tile
-__global__ __launch_bounds__(256) void vq_refine_kernel(const float* en, const float* zn, const int* flag, const float* best32, int C,
-                                                        int d, float tie_eps, long long* idx) {
-    const int tok = blockIdx.x;
-    if (!flag[tok]) return;
+// near-tie tokens: fp64 re-score, first maximum wins (what torch's argmax over the reference's fp32 scores is compared with).  One
+// workgroup per near-tie token (compacted list, vq_select_kernel).  Round 1-3 let every thread walk whole code rows of the whole codebook
+// (0.54 ms for 16384 codes); the first round-4 kernel tiled all rows through LDS (512 tiles x three barriers: 2.4 ms in every step that
+// has a near tie, rocprofv3 trace of steps 0-2, and the first steps have hundreds).  Now the token's own top-2 partials choose the work:
+// only a 128-code tile of the distance kernel whose best score reaches the threshold can hold the fp64 winner (a score of either
+// arithmetic is off by < 3e-7, tie_eps is 4e-6, the threshold is the maximum - 2 tie_eps) -- one or two tiles of 128 instead of all.
+// Within a tile: code rows go through LDS 32 at a time (coalesced float4 loads, rows padded by 4 floats: conflict-free ds_read_b128),
+// eight threads per code form the fp32 score of their part of the row, and only codes whose fp32 score reaches the threshold are
+// re-scored in fp64 by the thread that owns them.
+constexpr int VQ_RT = 32;                                // codes per LDS tile
+constexpr int VQ_SLOTS = 1024;                           // workgroups; more near ties than that take another turn of the loop
+__global__ __launch_bounds__(256) void vq_refine_kernel(const float* en, const float* zn, const Top2* top, int tiles_c, const int* list,
+                                                        const int* count, const float* best32, int C, int d, float tie_eps,
+                                                        long long* idx) {
     extern __shared__ __attribute__((aligned(16))) float rsm[];
     const int P = d + 4;                                 // row pitch (floats)
     float* zrow = rsm;                                   // [d]
@@ -334,54 +338,63 @@ __global__ __launch_bounds__(256) void vq_refine_kernel(const float* en, const f
     float* part = tile + VQ_RT * P;                      // [VQ_RT][8]
     __shared__ double bv[VQ_RT];
     __shared__ int bi[VQ_RT];
-    for (int i = threadIdx.x; i < d; i += 256) zrow[i] = zn[(size_t)tok * d + i];
-    const int code = threadIdx.x >> 3, sl = threadIdx.x & 7;      // 32 codes x 8 slices of d / 8 (d % 32 == 0 here; tails handled)
+    const int n = *count;
+    const int code = threadIdx.x >> 3, sl = threadIdx.x & 7;      // 32 codes x 8 parts of d / 8 floats (the last takes the tail)
     const int k0 = (d / 8) * sl, k1 = sl == 7 ? d : k0 + d / 8;
-    const float thr = best32[tok] - 2.f * tie_eps;
-    double best = -1e300;
-    int besti = 0x7fffffff;
     const int d4 = d / 4;
-    for (int c0 = 0; c0 < C; c0 += VQ_RT) {
+    for (int slot = blockIdx.x; slot < n; slot += gridDim.x) {
+        const int tok = list[slot];
         __syncthreads();
-        if (d % 4 == 0) {
-            for (int i = threadIdx.x; i < VQ_RT * d4; i += 256) {
-                const int r = i / d4, k4 = i - r * d4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c0 + r < C) v = *reinterpret_cast<const float4*>(en + (size_t)(c0 + r) * d + 4 * k4);
-                *reinterpret_cast<float4*>(tile + r * P + 4 * k4) = v;
-            }
-        } else {
-            for (int i = threadIdx.x; i < VQ_RT * d; i += 256) {
-                const int r = i / d, k = i - r * d;
-                tile[r * P + k] = c0 + r < C ? en[(size_t)(c0 + r) * d + k] : 0.f;
-            }
-        }
-        __syncthreads();
-        float s32 = 0.f;
-        const float* e = tile + code * P;
-        for (int k = k0; k < k1; ++k) s32 = fmaf(e[k], zrow[k], s32);
-        part[code * 8 + sl] = s32;
-        __syncthreads();
-        if (sl == 0 && c0 + code < C) {
-            float t = 0.f;
+        for (int i = threadIdx.x; i < d; i += 256) zrow[i] = zn[(size_t)tok * d + i];
+        const float thr = best32[tok] - 2.f * tie_eps;
+        double best = -1e300;
+        int besti = 0x7fffffff;
+        for (int t = 0; t < tiles_c; ++t) {
+            if (!(top[(size_t)tok * tiles_c + t].v1 >= thr)) continue;       // same value for the whole workgroup
+            const int cend = min(C, (t + 1) * VBM);
+            for (int c0 = t * VBM; c0 < cend; c0 += VQ_RT) {
+                __syncthreads();
+                if (d % 4 == 0) {
+                    for (int i = threadIdx.x; i < VQ_RT * d4; i += 256) {
+                        const int r = i / d4, k4 = i - r * d4;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (c0 + r < cend) v = *reinterpret_cast<const float4*>(en + (size_t)(c0 + r) * d + 4 * k4);
+                        *reinterpret_cast<float4*>(tile + r * P + 4 * k4) = v;
+                    }
+                } else {
+                    for (int i = threadIdx.x; i < VQ_RT * d; i += 256) {
+                        const int r = i / d, k = i - r * d;
+                        tile[r * P + k] = c0 + r < cend ? en[(size_t)(c0 + r) * d + k] : 0.f;
+                    }
+                }
+                __syncthreads();
+                float s32 = 0.f;
+                const float* e = tile + code * P;
+                for (int k = k0; k < k1; ++k) s32 = fmaf(e[k], zrow[k], s32);
+                part[code * 8 + sl] = s32;
+                __syncthreads();
+                if (sl == 0 && c0 + code < cend) {
+                    float u = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t += part[code * 8 + j];
-            if (t >= thr) {                                      // candidate: fp64 score over the whole row
-                double sd = 0.0;
-                for (int k = 0; k < d; ++k) sd += (double)e[k] * (double)zrow[k];
-                if (sd > best) { best = sd; besti = c0 + code; }      // ascending codes per thread: first maximum kept
+                    for (int j = 0; j < 8; ++j) u += part[code * 8 + j];
+                    if (u >= thr) {                                      // candidate: fp64 score over the whole row
+                        double sd = 0.0;
+                        for (int k = 0; k < d; ++k) sd += (double)e[k] * (double)zrow[k];
+                        if (sd > best) { best = sd; besti = c0 + code; }      // ascending codes per thread: first maximum kept
+                    }
+                }
             }
         }
-    }
-    __syncthreads();
-    if (sl == 0) { bv[code] = best; bi[code] = besti; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double b = bv[0];
-        int ix = bi[0];
-        for (int j = 1; j < VQ_RT; ++j)
-            if (bv[j] > b || (bv[j] == b && bi[j] < ix)) { b = bv[j]; ix = bi[j]; }
-        idx[tok] = ix == 0x7fffffff ? 0 : ix;
+        __syncthreads();
+        if (sl == 0) { bv[code] = best; bi[code] = besti; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double b = bv[0];
+            int ix = bi[0];
+            for (int j = 1; j < VQ_RT; ++j)
+                if (bv[j] > b || (bv[j] == b && bi[j] < ix)) { b = bv[j]; ix = bi[j]; }
+            if (ix != 0x7fffffff) idx[tok] = ix;                 // (a NaN token keeps what vq_select_kernel wrote)
+        }
     }
 }
 
@@ -566,6 +579,7 @@ __global__ __launch_bounds__(256) void vq_ema_kernel(float* embed, float* cluste
 
 extern "C" size_t favae_vq_workspace(int T, int d, int C) {
     const size_t tiles_c = (size_t)(C + VBM - 1) / VBM;
+    // top-2 partials | near-tie list [T] + counter | fp32 maxima [T]
     return (size_t)T * tiles_c * sizeof(Top2) + (size_t)T * (sizeof(int) + sizeof(float)) + 256;
 }
 
@@ -577,11 +591,12 @@ extern "C" int favae_vq_lookup(const float* z, const float* embed, int T, int d,
     hipStream_t s = (hipStream_t)stream;
     const int tiles_c = cdiv(C, VBM), tiles_t = cdiv(T, VBN);
     Top2* part = (Top2*)ws;
-    int* flag = (int*)((char*)ws + (size_t)T * tiles_c * sizeof(Top2));
-    float* best32 = (float*)(flag + T);
-    FAVAE_KLAUNCH(l2norm_rows_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, z, zn, T, d);
+    int* list = (int*)((char*)ws + (size_t)T * tiles_c * sizeof(Top2));
+    int* count = list + T;                                       // 16 ints reserved
+    float* best32 = (float*)(count + 16);
+    FAVAE_KLAUNCH(l2norm_rows_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, z, zn, T, d, count);
     FAVAE_CHECK_LAUNCH();
-    FAVAE_KLAUNCH(l2norm_rows_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, embed, en, C, d);
+    FAVAE_KLAUNCH(l2norm_rows_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, embed, en, C, d, (int*)nullptr);
     FAVAE_CHECK_LAUNCH();
     static int vq_h3 = -1;                           // FAVAE_VQ_H3=0: the fp32-MFMA tile product (A/B arm; also taken when d % 16 != 0)
     if (vq_h3 < 0) { const char* e = getenv("FAVAE_VQ_H3"); vq_h3 = (e && e[0] == '0') ? 0 : 1; }
@@ -594,14 +609,15 @@ extern "C" int favae_vq_lookup(const float* z, const float* embed, int T, int d,
                            T, d, tiles_c);
     FAVAE_CHECK_LAUNCH();
     FAVAE_KLAUNCH(vq_select_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, (const Top2*)part, T, tiles_c, tie_eps,
-                       (long long*)idx, flag, best32);
+                       (long long*)idx, list, count, best32);
     FAVAE_CHECK_LAUNCH();
     if (tie_eps > 0.f) {
         const size_t rshm = ((size_t)(d + 4) * (VQ_RT + 1) + VQ_RT * 8) * sizeof(float);
         if (rshm > 150 * 1024) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (rshm > 48 * 1024) (void)hipFuncSetAttribute((const void*)vq_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rshm);
-        FAVAE_KLAUNCH(vq_refine_kernel, dim3(T), dim3(256), rshm, s, (const float*)en, (const float*)zn, (const int*)flag,
-                           (const float*)best32, C, d, tie_eps, (long long*)idx);
+        FAVAE_KLAUNCH(vq_refine_kernel, dim3(std::min(T, VQ_SLOTS)), dim3(256), rshm, s, (const float*)en, (const float*)zn,
+                           (const Top2*)part, tiles_c, (const int*)list, (const int*)count, (const float*)best32, C, d, tie_eps,
+                           (long long*)idx);
         FAVAE_CHECK_LAUNCH();
     }
     FAVAE_KLAUNCH(vq_gather_kernel, dim3(cdiv(T, 4)), dim3(256), 0, s, embed, (const long long*)idx, zq, T, d, C);

@@ -156,6 +156,61 @@ def gen_blocks():
     np.savez_compressed(os.path.join(OUT, "blocks.npz"), **out)
 
 
+# ---- the same blocks at the product's own shapes -------------------------
+# Input, output gradient and parameters are closed-form (regenerated by the tests); the fixture holds the reference's output, input
+# gradient and conv-weight gradients at O.sample_positions, their per-channel sums / sums of squares in fp64 (every element
+# contributes), and the small parameter gradients in full.
+BLOCKS_LARGE = {
+    "res128_256": ("res", (128, 128), (1, 128, 256, 256)),        # codec.py:38-46 at the decoder's / encoder's 256^2 level
+    "res256to128_128": ("res", (256, 128), (1, 256, 128, 128)),   # channel-changing block: 1x1 shortcut, 256 -> 128 conv
+    "res512_16": ("res", (512, 512), (2, 512, 16, 16)),           # the 16^2 level
+    "down128_256": ("down", (128,), (1, 128, 256, 256)),          # codec.py:100-113
+    "up128_128": ("up", (128,), (1, 128, 128, 128)),              # codec.py:84-97
+}
+LARGE_SAMPLES = 32768
+
+
+def large_summary(out, key, t):
+    """what the fixture keeps of a large tensor `t` (N, C, H, W) or a conv weight (Co, Ci, kh, kw)"""
+    t = t.detach()
+    flat = t.reshape(-1)
+    out[key + ".at"] = npy(flat[O.sample_positions(flat.numel(), LARGE_SAMPLES)])
+    d = t.double().transpose(0, 1).reshape(t.shape[1], -1)          # per channel (dim 1)
+    out[key + ".csum"] = d.sum(1).numpy()
+    out[key + ".csq"] = d.pow(2).sum(1).numpy()
+    out[key + ".absmax"] = np.array(float(t.abs().max()), np.float64)
+
+
+def gen_blocks_large():
+    out = {}
+    for name, (kind, dims, shp) in BLOCKS_LARGE.items():
+        mod = {"res": lambda: RC.ResnetBlock(dims[0], dims[1], 0.0), "down": lambda: RC.Downsample(dims[0]),
+               "up": lambda: RC.Upsample(dims[0])}[kind]()
+        P = fill_module(mod, "blk")
+        n = int(np.prod(shp))
+        x = (2 * O._hash_uniform(n, 177 + len(name)).reshape(shp) - 1).float().requires_grad_(True)
+        y = mod(x)
+        gy = (2 * O._hash_uniform(y.numel(), 1991).reshape(y.shape) - 1).float()
+        (y * gy).sum().backward()
+        out[f"{name}.shape"] = np.array(shp, np.int64)
+        large_summary(out, f"{name}.y", y)
+        large_summary(out, f"{name}.gx", x.grad)
+        for k, p in mod.named_parameters():
+            if p.dim() == 4 and p.numel() > LARGE_SAMPLES:
+                large_summary(out, f"{name}.g.{k}", p.grad)
+            else:
+                out[f"{name}.g.{k}"] = npy(p.grad)
+        Po = leafify({k: v.clone() for k, v in P.items()})
+        xo = x.detach().clone().requires_grad_(True)
+        yo = {"res": O.resnet_block, "down": O.downsample, "up": O.upsample}[kind](Po, "blk", xo)
+        (yo * gy).sum().backward()
+        check(f"blocks_large/{name}/y", yo, y)
+        check(f"blocks_large/{name}/gx", xo.grad, x.grad)
+        for k, p in mod.named_parameters():
+            check(f"blocks_large/{name}/g.{k}", Po["blk." + k].grad, p.grad, tol=1e-4)
+    np.savez_compressed(os.path.join(OUT, "blocks_large.npz"), **out)
+
+
 # =============================================================================================
 # G2: gaussian blur with learnable sigma (codec.py:255-277)
 # =============================================================================================
@@ -866,10 +921,12 @@ def gen_attn_fcm():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["blocks", "blur", "vq", "vq_large", "hinge", "models", "cfg1", "cfg2", "f4_256", "gan", "cfg5", "lpips", "attn_fcm",
+    which = sys.argv[1:] or ["blocks", "blocks_large", "blur", "vq", "vq_large", "hinge", "models", "cfg1", "cfg2", "f4_256", "gan", "cfg5", "lpips", "attn_fcm",
                              "variants"]
     if "blocks" in which:
         gen_blocks()
+    if "blocks_large" in which:
+        gen_blocks_large()
     if "blur" in which:
         gen_blur()
     if "vq" in which:

@@ -41,6 +41,16 @@ def test_winograd_kernel_is_priced_on_executed_flops():
     assert abs(e["frac_of_pipe_peak"] - 0.150) < 1e-3 and abs(e["frac_fp32_equivalent"] - 0.337) < 1e-3
 
 
+def test_no_matrix_kernel_is_priced_above_its_pipe():
+    """The h3 kernels without a scheme template argument (codebook scores, SDPA batched GEMM) run on the 16-bit pipe with 3 products per
+    multiply-add: priced against 2500, not against the fp32-MFMA 157.3 (the round-4 table once showed the VQ product at frac 1.52)."""
+    for name in ("vq_dist_top2_h3_kernel", "bgemm_sp_kernel<0, 1>"):
+        e = bench.roofline_entry(name, _rec(2, 286.8, 68.7, 0.025), 2 * 135000.0, {}, None)       # 2*8192*16384*256 FLOP in 287 us
+        assert e["peak"] == 2500.0 and e["products_per_fma"] == 3 and e["frac"] < 0.2 and abs(e["frac_of_pipe_peak"] - 3 * e["frac"]) < 1e-9
+    e = bench.roofline_entry("vq_dist_top2_kernel", _rec(2, 780.0, 68.7, 0.025), 2 * 135000.0, {}, None)   # the fp32-MFMA arm
+    assert e["peak"] == 157.3 and e["frac"] < 1.0
+
+
 def test_line_is_trimmed_not_asserted():
     res = {"metric": "m", "value": 1.0, "config": {"workload": "w" * 300}, "roofline": {"kernel": "k"}, "with_lpips": {"x": "y" * 5000},
            "cpu_baseline": {"value": 1}}

@@ -436,6 +436,39 @@ def test_blocks_against_reference_golden(K, golden_dir, name):
         check(p.grad, torch.from_numpy(g[f"{name}.g.{k}"]), 2e-4, "g." + k)
 
 
+BLOCKS_LARGE = {"res128_256": ("res", (128, 128)), "res256to128_128": ("res", (256, 128)), "res512_16": ("res", (512, 512)),
+                "down128_256": ("down", (128,)), "up128_128": ("up", (128,))}
+
+
+@pytest.mark.parametrize("name", list(BLOCKS_LARGE))
+def test_blocks_at_product_shapes_against_reference_golden(K, golden_dir, name):
+    """The blocks at the shapes the hot kernels are tiled for -- ResnetBlock 128->128 at 256^2 (Winograd forward / data gradient, nine-tap
+    weight gradient), 256->128 at 128^2 with its 1x1 shortcut, 512 at 16^2, Downsample / Upsample at 128 channels -- against the
+    reference's own tensors (tests/golden/blocks_large.npz: values at fixed positions + per-channel sums over every element; the
+    whole-model goldens were the only reference-pinned evidence at these shapes before).  Reference: models/codec.py:38-46,84-113."""
+    from large_check import check_large
+    from test_oracle_golden import large_block_inputs, large_out_shape
+    from models import codec as C
+    g = np.load(os.path.join(golden_dir, "blocks_large.npz"))
+    kind, dims = BLOCKS_LARGE[name]
+    mod = {"res": lambda: C.ResnetBlock(dims[0], dims[1], 0.0), "down": lambda: C.Downsample(dims[0]),
+           "up": lambda: C.Upsample(dims[0])}[kind]()
+    mod.load_state_dict({k: O.det_value("blk." + k, tuple(v.shape)) for k, v in mod.state_dict().items()}, strict=True)
+    mod.to(dev())
+    x, gy = large_block_inputs(g, name, lambda shp: large_out_shape(kind, dims, shp))
+    x = x.to(dev()).requires_grad_(True)
+    y = mod(x)
+    (y * gy.to(dev())).sum().backward()
+    check_large(g, f"{name}.y", y, 3e-5)
+    check_large(g, f"{name}.gx", x.grad, 1e-4)
+    for k, p in mod.named_parameters():
+        key = f"{name}.g.{k}"
+        if key + ".at" in g.files:
+            check_large(g, key, p.grad, 2e-4)
+        else:
+            check(p.grad, torch.from_numpy(g[key]), 2e-4, "g." + k)
+
+
 def test_attention_core(K):
     N, C, H, W = 2, 64, 6, 5
     qkv = rnd((N, 3 * C, H, W), 21).requires_grad_(True)
@@ -851,6 +884,25 @@ def test_vq_exact_ties_pick_first_index(K):
     assert int(idx.max()) < 8
     ref = (F.normalize(tok.cpu(), dim=-1) @ F.normalize(emb.cpu(), dim=-1).t()).argmax(-1)
     assert torch.equal(idx.cpu(), ref)
+
+
+@pytest.mark.parametrize("C0,dd,T", [(2048, 64, 1000), (700, 30, 300), (96, 256, 129)])
+def test_vq_every_token_ties_across_refine_slices(K, C0, dd, T):
+    """The near-tie re-score cuts the code range into slices (one workgroup each) and handles at most 128 tokens per turn: a codebook
+    whose second half repeats the first makes EVERY token an exact tie between codes in different slices, with more tokens than slots
+    (and a row length that is not a multiple of 4 in one case).  torch.argmax semantics: the lower index, bit-exact for all tokens."""
+    d = dev()
+    emb = F.normalize(rnd((C0, dd), 57), dim=-1)
+    emb = torch.cat([emb, emb], 0).contiguous()
+    tok = rnd((T, dd), 58)
+    idx, zq, zn, en = K.vq_lookup(tok.to(d), emb.to(d))
+    sc = zn.cpu().double() @ en.cpu().double().t()               # the lookup's own normalised rows, scored in fp64
+    ref = sc.argmax(-1)
+    got = idx.cpu()
+    assert int(got.max()) < C0
+    bad = (got != ref).nonzero().flatten()
+    # a differing token must be an fp64 near-tie of the reference's own scores (never seen; the message tells which if it happens)
+    assert bad.numel() == 0, [(int(i), int(got[i]), int(ref[i]), float(sc[i, ref[i]] - sc[i, got[i]])) for i in bad[:5]]
 
 
 def test_l1_and_adam(K):

@@ -82,6 +82,49 @@ def test_blocks(golden_dir, name):
             close(P[k].grad, g[f"{name}.g.{k[4:]}"], rtol=1e-4, name=name + ".g." + k)
 
 
+BLOCKS_LARGE = {"res128_256": ("res", (128, 128)), "res256to128_128": ("res", (256, 128)), "res512_16": ("res", (512, 512)),
+                "down128_256": ("down", (128,)), "up128_128": ("up", (128,))}
+
+
+def large_block_inputs(g, name, y_shape_of):
+    """the closed-form input and output gradient of a blocks_large case (oracle/gen_golden.py gen_blocks_large)"""
+    shp = tuple(int(v) for v in g[f"{name}.shape"])
+    n = int(np.prod(shp))
+    x = (2 * O._hash_uniform(n, 177 + len(name)).reshape(shp) - 1).float()
+    ys = y_shape_of(shp)
+    gy = (2 * O._hash_uniform(int(np.prod(ys)), 1991).reshape(ys) - 1).float()
+    return x, gy
+
+
+def large_out_shape(kind, dims, shp):
+    N, C, H, W = shp
+    return {"res": (N, dims[-1], H, W), "down": (N, C, H // 2, W // 2), "up": (N, C, 2 * H, 2 * W)}[kind]
+
+
+@pytest.mark.parametrize("name", list(BLOCKS_LARGE))
+def test_blocks_at_product_shapes(golden_dir, name):
+    """the oracle's blocks at the shapes the product kernels are tiled for (128 channels at 256^2 ...), against what the fixture keeps
+    of the reference's tensors: values at fixed positions, per-channel sums over every element."""
+    from large_check import check_large
+    g = np.load(os.path.join(golden_dir, "blocks_large.npz"))
+    kind, dims = BLOCKS_LARGE[name]
+    P = leafify(_block_params(kind, dims))
+    x, gy = large_block_inputs(g, name, lambda shp: large_out_shape(kind, dims, shp))
+    x.requires_grad_(True)
+    y = {"res": O.resnet_block, "down": O.downsample, "up": O.upsample}[kind](P, "blk", x)
+    (y * gy).sum().backward()
+    check_large(g, f"{name}.y", y, 2e-5)
+    check_large(g, f"{name}.gx", x.grad, 2e-5)
+    for k in P:
+        if P[k].grad is None:
+            continue
+        key = f"{name}.g.{k[4:]}"
+        if key + ".at" in g.files:
+            check_large(g, key, P[k].grad, 1e-4)
+        else:
+            close(P[k].grad, g[key], rtol=1e-4, name=key)
+
+
 def test_blur(golden_dir):
     g = np.load(os.path.join(golden_dir, "blur.npz"))
     tags = sorted({k.split(".")[0] for k in g.files})
@@ -548,7 +591,7 @@ def test_dropout_mask_is_counter_based_and_reproducible():
 def test_generator_reproduces_committed_fixtures(golden_dir, tmp_path):
     import subprocess
     import sys
-    groups = [] if os.environ.get("FAVAE_REGEN_ALL") == "1" else ["blocks", "blur", "vq", "hinge", "lpips", "gan", "cfg5"]
+    groups = [] if os.environ.get("FAVAE_REGEN_ALL") == "1" else ["blocks", "blocks_large", "blur", "vq", "hinge", "lpips", "gan", "cfg5"]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FAVAE_GOLDEN_OUT=str(tmp_path))
     env.pop("FAVAE_GAN_SEED", None)
@@ -556,7 +599,7 @@ def test_generator_reproduces_committed_fixtures(golden_dir, tmp_path):
                        text=True, timeout=3000)
     assert r.returncode == 0, "gen_golden.py failed its own oracle-vs-reference checks:\n" + r.stderr[-3000:]
     made = sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz"))
-    assert len(made) >= (7 if groups else 15)
+    assert len(made) >= (8 if groups else 16)
     for f in made:
         a, b = np.load(os.path.join(tmp_path, f)), np.load(os.path.join(golden_dir, f))
         assert set(a.files) == set(b.files), f
