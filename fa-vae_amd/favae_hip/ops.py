@@ -429,7 +429,9 @@ _SERIALIZE_MFMA = os.environ.get("FAVAE_SERIALIZE_MFMA", "0") == "1"
 
 def _side_stream():
     if _SIDE["stream"] is None:
-        _SIDE["stream"] = torch.cuda.Stream()
+        # FAVAE_SIDE_PRIORITY (A/B switch): HIP priority of the weight-gradient stream (torch: lower number = higher priority, clamped
+        # to the device's range); default = the normal priority the main stream has
+        _SIDE["stream"] = torch.cuda.Stream(priority=int(os.environ.get("FAVAE_SIDE_PRIORITY", "0")))
     return _SIDE["stream"]
 
 
