@@ -103,12 +103,40 @@ for t, name in ((g_dist, "gradients"), (embed, "codebook"), (cluster, "cluster s
     dist.broadcast(ref, 0)
     assert torch.equal(ref, t), "rank %d: %s differ from rank 0" % (rank, name)
 
+# the same exchange without any overlap: a non-distributed step on this rank's slice, ONE all-reduce of the whole buffer after backward.
+# Two ranks: a + b in either order, so the overlapped, segmented exchange must reproduce it bit for bit (diagnostic for the comparison
+# below: tells an exchange problem from a gradient problem)
+model2, ts2 = make(False, perturb=False)
+grads(ts2, x)
+g_simple = ts2.gflat.clone()
+dist.all_reduce(g_simple)
+torch.cuda.synchronize()
+g_simple /= world
+del model2, ts2
+
 # one non-distributed step on the whole batch (every rank computes it: no collectives inside)
 model1, ts1 = make(False, perturb=False)
 grads(ts1, xg.to(dev))
 scale = float(ts1.gflat.abs().max())
 err = float((g_dist - ts1.gflat).abs().max()) / scale
 e_err = float((embed - model1.quantizer._codebook.embed).abs().max())
+if world > 1 and not err < 2e-5:                 # say where and which side before failing
+    g_ref1 = ts1.gflat.clone()
+    grads(ts1, xg.to(dev))
+    print("[rank %d] DIAG err %.3e; overlapped exchange == plain all-reduce of local gradients: %s (max diff %.3e); global-batch "
+          "reference reproducible: %s (max diff %.3e); plain exchange vs reference %.3e"
+          % (rank, err, torch.equal(g_dist, g_simple), float((g_dist - g_simple).abs().max()) / scale, torch.equal(g_ref1, ts1.gflat),
+             float((g_ref1 - ts1.gflat).abs().max()) / scale, float((g_simple - g_ref1).abs().max()) / scale), file=sys.stderr, flush=True)
+    off, rows = 0, []
+    names = {id(p): n for n, p in model.named_parameters()}
+    for p in ts.params:
+        n = p.numel()
+        rows.append((float((g_dist[off:off + n] - g_ref1[off:off + n]).abs().max()) / scale,
+                     float((g_simple[off:off + n] - g_ref1[off:off + n]).abs().max()) / scale, names.get(id(p), "?"), off, n))
+        off += n
+    for e1, e2, nm, o, n in sorted(rows, reverse=True)[:10]:
+        print("[rank %d] DIAG   %-50s [%9d, +%8d)  overlapped %.3e  plain %.3e" % (rank, nm, o, n, e1, e2), file=sys.stderr, flush=True)
+    ts1.gflat.copy_(g_ref1)
 if world == 1:
     assert torch.equal(g_dist, ts1.gflat), "world 1: distributed step is not bit-identical (%g)" % err
     assert torch.equal(embed, model1.quantizer._codebook.embed)

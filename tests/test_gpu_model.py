@@ -284,6 +284,38 @@ def test_side_stream_weight_gradients_are_race_free(mtag, hw):
     assert float((ref1 - ref2).abs().max()) < 2e-5 * scale, float((ref1 - ref2).abs().max()) / scale
 
 
+@pytest.mark.parametrize("switch", ["_DYCS_FUSE", "_GNBWD_FUSE", "_DEFER_REDUCE", "_DIRECT_GRAD"])
+def test_ab_switches_give_the_same_gradients(switch):
+    """Every A/B arm of the backward pass (FAVAE_DYCS_FUSE / FAVAE_GNBWD_FUSE / FAVAE_DEFER_REDUCE / FAVAE_DIRECT_GRAD = 0) is a
+    different schedule of the same sums: whole-model gradients must agree with the default path to rounding.  (Round 4: FAVAE_DYCS_FUSE=0
+    had silently produced garbage gradients in a model while its op-level test stayed green.)"""
+    from favae_hip import ops as K
+    from favae_step import TrainStep
+    if not hasattr(K, switch):
+        pytest.skip("no such switch in this build")
+    x = O.det_input(2, 64, 64, 31).to(DEV)
+
+    def grads(value):
+        model, _, _ = build("cfg1_k3")
+        prev = getattr(K, switch)
+        setattr(K, switch, value)
+        try:
+            ts = TrainStep(model, lr=1e-4)
+            model.train()
+            ts.gflat.zero_()
+            out = ts.losses(x)
+            ts.backward(out)
+            K.sync_side_stream()
+            torch.cuda.synchronize()
+            return ts.gflat.clone()
+        finally:
+            setattr(K, switch, prev)
+    ref, got = grads(True), grads(False)
+    assert torch.isfinite(got).all()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 2e-5 * scale, "%s=0 changes the gradients by %g of the max" % (switch, float((got - ref).abs().max()) / scale)
+
+
 def test_gan_stage1_discriminator_alone_against_reference_golden(golden_dir):
     """Stage 1 of train() without the chaotic generator step in front of it: the discriminator on (x, the reference's own stage-1
     reconstruction stored in the fixture): logits, hinge_d and every discriminator gradient against the reference, tight."""
