@@ -1119,9 +1119,13 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
                          favae_stream_t stream, void* planes_out, const GnBwdEpi* gb, double* stats_part, float* stats_amax) {
     FAVAE_REQUIRE(desc_ok(d) && x && w && y);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
-    // roofline numerators of this conv: 2*M*Cout*KH*KW*Cin FLOP; one read of x (+ resid), one write of y, the weights
+    // roofline numerators of this conv: 2*M*Cout*KH*KW*Cin FLOP; one read of x (+ resid), one write of y, the weights --
+    // and, for a data gradient with the GroupNorm-backward epilogue, the forward activation the epilogue reads next to its output tile
+    // (pass 1 of that GroupNorm's backward, which would otherwise read both tensors in a kernel of its own).  Rounds 1-4 left that
+    // tensor out: the data-gradient line of the bench showed traffic / algorithmic = 1.94 where the kernel fetches 1.29 x its operands.
     FAVAE_PROF_NOTE(2.0 * d->N * d->Hout * d->Wout * d->Cout * d->KH * d->KW * d->Cin,
-                    4.0 * ((double)d->N * d->Hin * d->Win * d->Cin + (double)d->N * d->Hout * d->Wout * d->Cout * (resid ? 2 : 1) +
+                    4.0 * ((double)d->N * d->Hin * d->Win * d->Cin +
+                           (double)d->N * d->Hout * d->Wout * d->Cout * (1 + (resid ? 1 : 0) + (gb ? 1 : 0)) +
                            (double)d->Cout * d->KH * d->KW * d->Cin));
     const bool wino = (wplanes & FAVAE_PLANES_WINO) != 0;     // Winograd records (favae_wino_weights): conv3x3_wino_sp_kernel
     wplanes &= 0xff;
