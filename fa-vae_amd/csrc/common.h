@@ -98,6 +98,14 @@ __device__ __forceinline__ float4 bload(R rsrc, unsigned voff, unsigned soff) {
 template <typename R>
 __device__ __forceinline__ void bstore(R rsrc, unsigned voff, unsigned soff, float4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, voff, soff, 0);
+#ifndef FAVAE_NO_STORE_NOP
+    // A vector instruction that overwrites the first data register of a 128-bit buffer store in the very next issue slot changes what
+    // the store writes (gfx950, measured: tools/experiments/apply_race.py).  The ISA manuals list this hazard (one wait state between a
+    // VMEM store of more than 64 bits and a VALU write of its data registers); the compiler's hazard recogniser skips it when the store
+    // takes its soffset from an SGPR -- as every store through this helper does.  The hazard only shows when the wave gets consecutive
+    // issue slots, e.g. next to a kernel of another stream whose waves sit in long MFMA sequences.
+    asm volatile("s_nop 0" ::: "memory");
+#endif
 }
 __device__ __forceinline__ auto make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);

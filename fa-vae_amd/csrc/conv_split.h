@@ -504,6 +504,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 
                 const uint2 p0 = *reinterpret_cast<const uint2*>(src), p1 = *reinterpret_cast<const uint2*>(src + 32);
                 const u32x4_t rec = {p0.x, p0.y, p1.x, p1.y};
                 __builtin_amdgcn_raw_buffer_store_b128(rec, rpl, hin[j] ? vh[j] : FAVAE_OOB, (unsigned)(kc * 64), 0);
+                asm volatile("s_nop 0" ::: "memory");      // store-data hazard with an SGPR soffset: see common.h bstore
             }
         }
     };

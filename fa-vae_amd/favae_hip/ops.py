@@ -958,12 +958,9 @@ class FusedConvFn(torch.autograd.Function):
                     dgb = torch.empty_like(dgw)
                 # BatchNorm = GroupNorm with one channel per group over the batch folded into the pixel dimension
                 gN, gHW, gG = (1, N * Hin * Win, Cin) if cfg.norm == "batch" else (N, Hin * Win, cfg.groups)
-                # FAVAE_DYCS_FUSE=0 (A/B arm) drops the by-products instead of choosing another kernel: the row-organised apply pass
-                # WITHOUT the column-sum epilogue (gn_bwd_apply_rows_kernel<., false>) returned a few hundred wrong elements per image
-                # whenever it ran next to the weight-gradient stream's kernel (round 4, tools/experiments/dycs_debug.py: right on a quiet
-                # GPU, right with FAVAE_WGRAD_STREAM=0, no out-of-bounds writer; not root-caused) -- the variant with the epilogue is the
-                # one every golden and the 600-step reproducibility run cover, so it is the only one launched here.
-                cs_blocks = query("favae_gn_bwd_colsum_blocks", gN, gHW, Cin)
+                # (FAVAE_DYCS_FUSE=0 runs the apply pass without its column-sum epilogue.  In round 4 that variant returned wrong first
+                # components next to the weight-gradient stream: a store-data hazard of its 128-bit buffer stores, fixed in common.h bstore)
+                cs_blocks = query("favae_gn_bwd_colsum_blocks", gN, gHW, Cin) if _DYCS_FUSE else 0
                 if not gn_tiles:
                     gn_ws = workspace(query("favae_gn_workspace", gN, gHW, Cin), dev)
                 if cs_blocks:                                 # the apply pass also leaves colsum / max|dx| for the conv in front
@@ -972,8 +969,7 @@ class FusedConvFn(torch.autograd.Function):
                     call("favae_gn_act_bwd_colsum", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin, gG, act,
                          ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0, gn_tiles,
                          ptr(gn_ws), gn_ws.numel(), ptr(cs_part), ptr(cs_amax))
-                    if _DYCS_FUSE:
-                        dx._favae_dycs = (cs_part, cs_blocks, cs_amax, dx._version, _ARENA["epoch"])
+                    dx._favae_dycs = (cs_part, cs_blocks, cs_amax, dx._version, _ARENA["epoch"])
                 elif gn_tiles:                                # pass 1 came out of the data-gradient conv's epilogue
                     call("favae_gn_act_bwd_tiles", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin,
                          gG, act, ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,

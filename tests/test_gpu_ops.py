@@ -469,6 +469,56 @@ def test_blocks_at_product_shapes_against_reference_golden(K, golden_dir, name):
             check(p.grad, torch.from_numpy(g[key]), 2e-4, "g." + k)
 
 
+def test_apply_pass_next_to_a_weight_gradient_on_a_second_stream(K):
+    """The row-organised GroupNorm-backward apply pass WITHOUT its column-sum epilogue (favae_gn_act_bwd) must give the same bits on a
+    quiet GPU and while a nine-tap weight gradient runs on a second stream.  Round 4: it returned wrong FIRST components of its float4
+    outputs in 299 of 300 such runs -- a vector instruction overwrote the first data register of a 128-bit buffer store in the next issue
+    slot (the ISA's store-data hazard; the compiler's hazard recogniser skips it for stores with an SGPR soffset; only visible when the
+    wave gets back-to-back issue slots next to waves that sit in MFMA sequences).  Fixed by a wait state in common.h bstore."""
+    import favae_hip as H
+    from ctypes import byref
+    d = dev()
+    N, C, Hh, W, G = 4, 128, 64, 64, 32
+    x = (rnd((N, C, Hh, W), 301) * 1.5).to(d).contiguous(memory_format=torch.channels_last)
+    da = (rnd((N, C, Hh, W), 302) * 1e-5).to(d).contiguous(memory_format=torch.channels_last)
+    gw, gb = (1 + 0.2 * rnd((C,), 303)).to(d), (0.2 * rnd((C,), 304)).to(d)
+    mean, rstd, scale, shift, xb = K.gn_stats(x, gw, gb, G, with_bound=True)
+    nws = H.query("favae_gn_workspace", N, Hh * W, C)
+
+    def apply():
+        dx = K.new_cl(N, C, Hh, W, d)
+        ws = torch.empty(nws, dtype=torch.uint8, device=d)
+        dg, dbt = torch.zeros(C, device=d), torch.zeros(C, device=d)
+        H.call("favae_gn_act_bwd", H.ptr(da), H.ptr(x), H.ptr(gw), H.ptr(gb), H.ptr(mean), H.ptr(rstd), N, Hh * W, C, G, 1, None,
+               H.ptr(dx), H.ptr(dg), H.ptr(dbt), 0, H.ptr(ws), ws.numel())
+        return dx
+    ref = apply()
+    torch.cuda.synchronize()
+    NB = 32
+    xa = rnd((NB, C, Hh, W), 305).to(d).contiguous(memory_format=torch.channels_last)
+    ya = (rnd((NB, C, Hh, W), 306) * 1e-3).to(d).contiguous(memory_format=torch.channels_last)
+    m2, r2, sc2, sh2, xb2 = K.gn_stats(xa, gw, gb, G, with_bound=True)
+    yb2 = K.absmax(ya)
+    cd = H.make_conv_desc(NB, Hh, W, C, Hh, W, C, 3, 3, 1, 1, 0, H.ACT_SILU, 1)
+    wws = H.workspace(H.query("favae_conv_wgrad_workspace", byref(cd)), d)
+    dw = torch.empty(C, 3, 3, C, device=d)
+    side = torch.cuda.Stream()
+
+    def kick():
+        with torch.cuda.stream(side):
+            H.call("favae_conv_wgrad", byref(cd), H.ptr(xa), H.ptr(ya), H.ptr(sc2), H.ptr(sh2), H.ptr(xb2), H.ptr(yb2), H.ptr(dw), 0,
+                   H.ptr(wws), wws.numel())
+    torch.cuda.synchronize()
+    bad = 0
+    for _ in range(40):
+        kick(); kick(); kick()
+        dx = apply()
+        kick()
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(dx, ref))
+    assert bad == 0, "%d of 40 results differ from the quiet-GPU result" % bad
+
+
 def test_attention_core(K):
     N, C, H, W = 2, 64, 6, 5
     qkv = rnd((N, 3 * C, H, W), 21).requires_grad_(True)
