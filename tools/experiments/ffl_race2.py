@@ -37,6 +37,23 @@ import time
 time.sleep(float(os.environ.get("FFL_WAIT", "0")))
 badA = badB = 0
 inproc = os.environ.get("FFL_INPROC") == "1"
+if os.environ.get("FFL_INPROC") == "wgrad":          # the aggressor is this library's nine-tap weight gradient on a second stream
+    from ctypes import byref
+    side = torch.cuda.Stream()
+    NB, Cw, Hw = 32, 128, 64
+    gww, gbw = torch.ones(Cw, device=dev), torch.zeros(Cw, device=dev)
+    xa = torch.randn(NB, Cw, Hw, Hw, device=dev).contiguous(memory_format=torch.channels_last)
+    ya = (torch.randn(NB, Cw, Hw, Hw, device=dev) * 1e-3).contiguous(memory_format=torch.channels_last)
+    m2, r2, sc2, sh2, xb2 = K.gn_stats(xa, gww, gbw, 32, with_bound=True)
+    yb2 = K.absmax(ya)
+    cd = H.make_conv_desc(NB, Hw, Hw, Cw, Hw, Hw, Cw, 3, 3, 1, 1, 0, H.ACT_SILU, 1)
+    wws = H.workspace(H.query("favae_conv_wgrad_workspace", byref(cd)), dev)
+    dwt = torch.empty(Cw, 3, 3, Cw, device=dev)
+    pend = []
+    inproc = False
+    wg_aggr = True
+else:
+    wg_aggr = False
 if inproc:
     side = torch.cuda.Stream()
     ma = torch.randn(8192, 8192, device=dev, dtype=torch.float16)
@@ -44,6 +61,15 @@ if inproc:
     mc = torch.empty(8192, 8192, device=dev, dtype=torch.float16)
     pend = []
 for r in range(reps):
+    if wg_aggr and r % 8 == 0:
+        pend = [e for e in pend if not e.query()]
+        while len(pend) < 6:
+            with torch.cuda.stream(side):
+                H.call("favae_conv_wgrad", byref(cd), H.ptr(xa), H.ptr(ya), H.ptr(sc2), H.ptr(sh2), H.ptr(xb2), H.ptr(yb2), H.ptr(dwt), 0,
+                       H.ptr(wws), wws.numel())
+                e = torch.cuda.Event()
+                e.record(side)
+            pend.append(e)
     if inproc and r % 16 == 0:
         pend = [e for e in pend if not e.query()]
         while len(pend) < 4:                      # keep a few GEMMs (about 1.5 ms each) queued on the side stream

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Static scan of gfx950 assembly (hipcc -S --cuda-device-only, or the .s of --save-temps) for the pattern measured in round 4: a store
+(ds_write*, buffer_store*, global_store*, flat_store*, scratch_store*) whose ADDRESS or DATA vector registers are overwritten by the
+instruction in the next issue slot (labels / comments / s_nop skipped; an s_nop between them clears it).  On this part such a vector
+instruction can change what the store does when the wave gets back-to-back issue slots.
+usage: tools/store_hazard_scan.py file.s [...]   -> prints every hit with its kernel; exit code 1 if any"""
+import re
+import sys
+
+STORE = re.compile(r"^\s*(ds_write\w*|ds_store\w*|buffer_store\w*|global_store\w*|flat_store\w*|scratch_store\w*)\s+(.*)$")
+# --loads: also report memory READS whose address registers are overwritten in the next slot (not known to be a problem; diagnostic)
+LOAD = re.compile(r"^\s*(ds_read\w*|ds_load\w*|buffer_load\w*|global_load\w*|flat_load\w*|scratch_load\w*)\s+([^,]+),(.*)$")
+WITH_LOADS = "--loads" in sys.argv
+REG = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)")
+
+
+def vregs(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(3) is not None:
+            out.add(int(m.group(3)))
+        else:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def dest_regs(line):
+    """vector registers WRITTEN by a (non-store) instruction: its first operand for v_* / ds_read* / *_load* instructions"""
+    m = re.match(r"^\s*(\w+)\s+(.*)$", line)
+    if not m:
+        return set()
+    op, rest = m.group(1), m.group(2)
+    if not (op.startswith("v_") or op.startswith("ds_read") or op.startswith("ds_load") or "_load" in op):
+        return set()
+    if op.startswith(("v_cmp", "v_cmpx", "v_nop")) and not op.endswith("_e64"):
+        return set()
+    first = rest.split(",")[0]
+    return vregs(first)
+
+
+def scan(path):
+    hits, kernel, pending = [], None, None
+    for n, raw in enumerate(open(path, errors="replace"), 1):
+        line = raw.split(";")[0].rstrip()
+        s = line.strip()
+        if not s:
+            continue
+        if re.match(r"^[\w.$]+:$", s):
+            if not s.startswith(".L"):
+                kernel = s[:-1]
+            continue                      # labels do not take an issue slot (a branch target may, conservatively ignored)
+        if s.startswith("."):
+            continue
+        if pending is not None:
+            st_line, st_n, st_regs = pending
+            pending = None
+            if not s.startswith("s_nop"):
+                d = dest_regs(s)
+                if d & st_regs:
+                    hits.append((kernel, st_n, st_line.strip(), s, sorted(d & st_regs)))
+        m = STORE.match(line)
+        if m:
+            pending = (line, n, vregs(m.group(2)))
+        elif WITH_LOADS:
+            m = LOAD.match(line)
+            if m:
+                pending = (line, n, vregs(m.group(3)) - vregs(m.group(2)))      # address registers that are not also the destination
+    return hits
+
+
+if __name__ == "__main__":
+    total = 0
+    for p in [a for a in sys.argv[1:] if not a.startswith('--')]:
+        h = scan(p)
+        total += len(h)
+        for kernel, n, st, nxt, regs in h:
+            print("%s:%d  %s\n      %s\n      -> %s   overwrites v%s" % (p, n, (kernel or "?")[:90], st, nxt, regs))
+    print("%d hit(s)" % total)
+    sys.exit(1 if total else 0)
