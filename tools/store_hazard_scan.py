@@ -11,6 +11,10 @@ STORE = re.compile(r"^\s*(ds_write\w*|ds_store\w*|buffer_store\w*|global_store\w
 # --loads: also report memory READS whose address registers are overwritten in the next slot (not known to be a problem; diagnostic)
 LOAD = re.compile(r"^\s*(ds_read\w*|ds_load\w*|buffer_load\w*|global_load\w*|flat_load\w*|scratch_load\w*)\s+([^,]+),(.*)$")
 WITH_LOADS = "--loads" in sys.argv
+# --buffer128: only the case measured to corrupt data on gfx950 and not guarded by the compiler -- buffer stores of more than 64 bits whose
+# DATA registers the next instruction writes (tests/test_store_hazard.py)
+BUFFER128 = "--buffer128" in sys.argv
+B128 = re.compile(r"^\s*(buffer_store_dwordx[34]|buffer_store_format_xyzw?|buffer_store_format_d16_xyzw)\s+([^,]+),(.*)$")
 REG = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)")
 
 
@@ -58,6 +62,11 @@ def scan(path):
                 d = dest_regs(s)
                 if d & st_regs:
                     hits.append((kernel, st_n, st_line.strip(), s, sorted(d & st_regs)))
+        if BUFFER128:
+            m = B128.match(line)
+            if m:
+                pending = (line, n, vregs(m.group(2)))
+            continue
         m = STORE.match(line)
         if m:
             pending = (line, n, vregs(m.group(2)))
