@@ -144,7 +144,7 @@ else:
     # per-sample-mean losses: sum over ranks / world == global-batch gradient up to fp32 summation order
     assert err < 2e-5, "all-reduced gradients differ from the global-batch gradients: %g of the max" % err
     assert e_err < 1e-6, "codebook differs from the global-batch EMA update: %g" % e_err
-    assert torch.equal(cluster, model1.quantizer._codebook.cluster_size)
+    assert torch.equal(cluster, model1.quantizer._codebook.cluster_size), "cluster sizes differ from the global-batch EMA update"
 
 # a full step() (exchange + Adam) keeps the ranks identical
 ts.step(x)

@@ -51,7 +51,8 @@ def _run_probe(world, variant, overlap, port, backend="nccl", extra_env=None, sh
                "--master-port", str(port + 20 * attempt), os.path.join(ROOT, "tests", "dist_probe.py")]
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         diag = "\n".join(l for l in out.stderr.splitlines() if "DIAG" in l or "Error" in l)
-        numerical = "differ from the global-batch gradients" in out.stderr or "differs from the global-batch EMA" in out.stderr
+        numerical = any(m in out.stderr for m in ("differ from the global-batch gradients", "differs from the global-batch EMA",
+                                                   "differ from the global-batch EMA"))
         if out.returncode != 0 and numerical and attempt < shared_gpu_retries:
             print("two processes on one GPU: numerical disagreement on attempt %d, repeating\n%s" % (attempt, diag[-3000:]))
             continue
