@@ -166,6 +166,8 @@ BLOCKS_LARGE = {
     "res512_16": ("res", (512, 512), (2, 512, 16, 16)),           # the 16^2 level
     "down128_256": ("down", (128,), (1, 128, 256, 256)),          # codec.py:100-113
     "up128_128": ("up", (128,), (1, 128, 128, 128)),              # codec.py:84-97
+    "nonres128_128": ("nonres", (128, 128), (1, 128, 128, 128)),  # codec.py:65-73
+    "attn512_16": ("attn", (512,), (2, 512, 16, 16)),             # codec.py:116-160 at the f=16 bottleneck
 }
 LARGE_SAMPLES = 32768
 
@@ -185,7 +187,8 @@ def gen_blocks_large():
     out = {}
     for name, (kind, dims, shp) in BLOCKS_LARGE.items():
         mod = {"res": lambda: RC.ResnetBlock(dims[0], dims[1], 0.0), "down": lambda: RC.Downsample(dims[0]),
-               "up": lambda: RC.Upsample(dims[0])}[kind]()
+               "up": lambda: RC.Upsample(dims[0]), "nonres": lambda: RC.NonResnetBlock(dims[0], dims[1], 0.0),
+               "attn": lambda: RC.AttnBlock(dims[0])}[kind]()
         P = fill_module(mod, "blk")
         n = int(np.prod(shp))
         x = (2 * O._hash_uniform(n, 177 + len(name)).reshape(shp) - 1).float().requires_grad_(True)
@@ -196,13 +199,14 @@ def gen_blocks_large():
         large_summary(out, f"{name}.y", y)
         large_summary(out, f"{name}.gx", x.grad)
         for k, p in mod.named_parameters():
-            if p.dim() == 4 and p.numel() > LARGE_SAMPLES:
+            if p.dim() >= 2 and p.numel() > LARGE_SAMPLES:
                 large_summary(out, f"{name}.g.{k}", p.grad)
             else:
                 out[f"{name}.g.{k}"] = npy(p.grad)
         Po = leafify({k: v.clone() for k, v in P.items()})
         xo = x.detach().clone().requires_grad_(True)
-        yo = {"res": O.resnet_block, "down": O.downsample, "up": O.upsample}[kind](Po, "blk", xo)
+        yo = {"res": O.resnet_block, "down": O.downsample, "up": O.upsample, "attn": O.attn_block,
+              "nonres": lambda P_, pre, x_: O.resnet_block(P_, pre, x_, residual=False)}[kind](Po, "blk", xo)
         (yo * gy).sum().backward()
         check(f"blocks_large/{name}/y", yo, y)
         check(f"blocks_large/{name}/gx", xo.grad, x.grad)

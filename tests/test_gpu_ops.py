@@ -437,7 +437,8 @@ def test_blocks_against_reference_golden(K, golden_dir, name):
 
 
 BLOCKS_LARGE = {"res128_256": ("res", (128, 128)), "res256to128_128": ("res", (256, 128)), "res512_16": ("res", (512, 512)),
-                "down128_256": ("down", (128,)), "up128_128": ("up", (128,))}
+                "down128_256": ("down", (128,)), "up128_128": ("up", (128,)), "nonres128_128": ("nonres", (128, 128)),
+                "attn512_16": ("attn", (512,))}
 
 
 @pytest.mark.parametrize("name", list(BLOCKS_LARGE))
@@ -452,7 +453,8 @@ def test_blocks_at_product_shapes_against_reference_golden(K, golden_dir, name):
     g = np.load(os.path.join(golden_dir, "blocks_large.npz"))
     kind, dims = BLOCKS_LARGE[name]
     mod = {"res": lambda: C.ResnetBlock(dims[0], dims[1], 0.0), "down": lambda: C.Downsample(dims[0]),
-           "up": lambda: C.Upsample(dims[0])}[kind]()
+           "up": lambda: C.Upsample(dims[0]), "nonres": lambda: C.NonResnetBlock(dims[0], dims[1], 0.0),
+           "attn": lambda: C.AttnBlock(dims[0])}[kind]()
     mod.load_state_dict({k: O.det_value("blk." + k, tuple(v.shape)) for k, v in mod.state_dict().items()}, strict=True)
     mod.to(dev())
     x, gy = large_block_inputs(g, name, lambda shp: large_out_shape(kind, dims, shp))

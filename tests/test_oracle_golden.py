@@ -83,7 +83,8 @@ def test_blocks(golden_dir, name):
 
 
 BLOCKS_LARGE = {"res128_256": ("res", (128, 128)), "res256to128_128": ("res", (256, 128)), "res512_16": ("res", (512, 512)),
-                "down128_256": ("down", (128,)), "up128_128": ("up", (128,))}
+                "down128_256": ("down", (128,)), "up128_128": ("up", (128,)), "nonres128_128": ("nonres", (128, 128)),
+                "attn512_16": ("attn", (512,))}
 
 
 def large_block_inputs(g, name, y_shape_of):
@@ -98,7 +99,8 @@ def large_block_inputs(g, name, y_shape_of):
 
 def large_out_shape(kind, dims, shp):
     N, C, H, W = shp
-    return {"res": (N, dims[-1], H, W), "down": (N, C, H // 2, W // 2), "up": (N, C, 2 * H, 2 * W)}[kind]
+    return {"res": (N, dims[-1], H, W), "nonres": (N, dims[-1], H, W), "attn": (N, C, H, W), "down": (N, C, H // 2, W // 2),
+            "up": (N, C, 2 * H, 2 * W)}[kind]
 
 
 @pytest.mark.parametrize("name", list(BLOCKS_LARGE))
@@ -111,7 +113,8 @@ def test_blocks_at_product_shapes(golden_dir, name):
     P = leafify(_block_params(kind, dims))
     x, gy = large_block_inputs(g, name, lambda shp: large_out_shape(kind, dims, shp))
     x.requires_grad_(True)
-    y = {"res": O.resnet_block, "down": O.downsample, "up": O.upsample}[kind](P, "blk", x)
+    y = {"res": O.resnet_block, "down": O.downsample, "up": O.upsample, "attn": O.attn_block,
+         "nonres": lambda P_, pre, x_: O.resnet_block(P_, pre, x_, residual=False)}[kind](P, "blk", x)
     (y * gy).sum().backward()
     check_large(g, f"{name}.y", y, 2e-5)
     check_large(g, f"{name}.gx", x.grad, 2e-5)
