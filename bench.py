@@ -85,7 +85,7 @@ def build_stamp():
     import hashlib
     h = hashlib.sha256()
     for p in sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.h")) +
-                    [os.path.join(ROOT, "include", "favae_hip.h")]):
+                    [os.path.join(PKG, "csrc", "Makefile"), os.path.join(ROOT, "include", "favae_hip.h")]):   # Makefile: per-file flags
         h.update(os.path.basename(p).encode())
         h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
