@@ -37,13 +37,12 @@ def test_model_under_torch_ddp():
 
 
 def _run_probe(world, variant, overlap, port, backend="nccl", extra_env=None, shared_gpu_retries=0):
-    """shared_gpu_retries: only for the runs that put TWO PROCESSES ON ONE GPU (the gloo vehicle below).  On this platform the FFT kernels
-    of a process are not bit-reproducible while ANOTHER process runs matrix-pipe kernels on the same GPU (DESIGN.md 6 "two processes on
-    one GPU", tools/race_probe.py, tools/experiments/ffl_race2.py: a few rows of an FFT come out different once in ~10^3-10^4 launches;
-    never with one process per GPU -- 0 of 600 steps -- and never with the matrix kernels on a second stream of the same process).  A
-    flipped code index behind such a difference moves the global-batch reference of ONE rank by ~1e-3 of the gradient maximum, about
-    once in 70 probe runs.  The product runs one process per GPU; this vehicle repeats a run whose ranks disagree NUMERICALLY (the
-    probe's DIAG lines say which side moved) and fails on anything else, or if it happens again."""
+    """shared_gpu_retries: only for the runs that put TWO PROCESSES ON ONE GPU (the gloo vehicle below).  Until the last build of round 4
+    such a run failed once in ~70: the FFT kernels (SLP-packed radix-4 butterflies) were not bit-reproducible when their waves shared a SIMD
+    with another kernel's MFMA waves, a changed spectrum flipped a near-tie code index, and the global-batch reference of ONE rank moved
+    by ~1e-3 of the gradient maximum (tools/race_probe.py, tools/experiments/ffl_race2.py).  `ffl.hip` is now built without
+    SLP vectorisation (0 of 400 two-process steps differ).  The guard stays: a run whose ranks disagree NUMERICALLY is repeated (at most
+    `shared_gpu_retries` times, printing the probe's DIAG lines); anything else fails at once."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FAVAE_PROBE_VARIANT=variant, FAVAE_OVERLAP_COMM="1" if overlap else "0",
                FAVAE_PROBE_BACKEND=backend, **(extra_env or {}))
     for attempt in range(shared_gpu_retries + 1):
