@@ -118,11 +118,23 @@ def _cases():
         K.adam_step(p, g128.reshape(-1), m, v, 1, 1e-3)
         return l.detach().clone(), a.grad, p, m, v
 
-    return {"ffl_image": lambda: ffl(x3, t3), "ffl_features": lambda: ffl(x128, g128 * 1e3), "blur_tap": blur, "conv_in": thin_in,
+    w_c = (_rnd((128, 128, 3, 3), 24, 0.03)).to(d)
+    b_c = (_rnd((128,), 25, 0.1)).to(d)
+
+    def winograd_conv():                      # GroupNorm + SiLU + 3x3 conv 128 -> 128 with residual: Winograd forward / data gradient, apply pass
+        x = x128.clone().requires_grad_(True)
+        w, b = w_c.clone().requires_grad_(True), b_c.clone().requires_grad_(True)
+        gwp, gbp = gw.clone().requires_grad_(True), gb.clone().requires_grad_(True)
+        y = K.fused_conv(x, w, b, gwp, gbp, x, K.ConvCfg(3, 3, 1, 1, act=1, groups=32))
+        (y * g128).sum().backward()
+        K.sync_side_stream()
+        return y.detach(), x.grad, w.grad, b.grad, gwp.grad, gbp.grad
+
+    return {"winograd_conv": winograd_conv, "ffl_image": lambda: ffl(x3, t3), "ffl_features": lambda: ffl(x128, g128 * 1e3), "blur_tap": blur, "conv_in": thin_in,
             "conv_out": thin_out, "gn_stats_absmax": stats, "vq": vq, "attention": attn, "l1_adam": l1_adam}
 
 
-@pytest.mark.parametrize("name", ["ffl_image", "ffl_features", "blur_tap", "conv_in", "conv_out", "gn_stats_absmax", "vq", "attention",
+@pytest.mark.parametrize("name", ["winograd_conv", "ffl_image", "ffl_features", "blur_tap", "conv_in", "conv_out", "gn_stats_absmax", "vq", "attention",
                                   "l1_adam"])
 def test_same_bits_next_to_the_weight_gradient_stream(aggressor, name):
     fn = _cases()[name]
