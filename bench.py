@@ -412,7 +412,8 @@ def main():
         return TrainStep(model, lr=lr, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, distributed=use_dist,
                          train_disc=args.gan, lpips=lpips, perceptual_weight=1.0)
     ts = build(args.lpips)
-    exchange_desc = ("RCCL all-reduce, %d segments overlapped with backward" % len(ts.exchange.segments)
+    exchange_desc = (("RCCL all-reduce, %d segments " % len(ts.exchange.segments)) +
+                     ("queued behind backward (FAVAE_COMM_DEFER=0: overlapped with it)" if ts.exchange.defer else "overlapped with backward")
                      if ts.exchange is not None else ("one RCCL all-reduce after backward" if use_dist else "none (1 GPU)"))
     xs = [synthetic_batch(args.batch, args.res, args.res, 1234 + 17 * rank + i).to(dev) for i in range(2)]
     prof = Prof(favae_hip)

@@ -263,7 +263,11 @@ class TrainStep:
             pos += n
         assert pos == total
         self.exchange = GradExchange(self.gflat, segs, side_stream=K.side_stream_flushed,
-                                     defer=os.environ.get("FAVAE_COMM_DEFER", "0") == "1",
+                                     # default since the end of round 4: every collective behind backward.  RCCL's reduction kernels
+                                     # would otherwise share SIMDs with this library's MFMA waves -- the situation in which two of its own
+                                     # kernels turned out not to be bit-reproducible and which nobody has been able to run
+                                     # here (single-GPU boxes).  331 MB over xGMI is ~2 ms of a 135 ms step; FAVAE_COMM_DEFER=0 = eager overlap
+                                     defer=os.environ.get("FAVAE_COMM_DEFER", "1") != "0",
                                      timing=os.environ.get("FAVAE_COMM_TIMING", "0") == "1")
         self._armed = False
         self._bwd_events = None

@@ -72,7 +72,7 @@ def test_product_trainstep_distributed_world1(variant, overlap):
 @pytest.mark.parametrize("defer", ["0", "1"])
 def test_gradient_exchange_overlap_table(defer):
     """the probe prints, per gradient segment, when its collective started and ended relative to the backward pass
-    (FAVAE_COMM_TIMING=1) -- eagerly queued (default) and deferred to the end of backward (FAVAE_COMM_DEFER=1, the A/B arm for the
+    (FAVAE_COMM_TIMING=1) -- eagerly queued (FAVAE_COMM_DEFER=0) and deferred to the end of backward (FAVAE_COMM_DEFER=1, the default; the two arms for the
     first real multi-GPU run).  World 1 over RCCL here; the same command prints the table at world N.  Results stay bit-identical."""
     out = _run_probe(1, "gauss_resblock", True, 29565 + int(defer), extra_env={"FAVAE_COMM_TIMING": "1", "FAVAE_COMM_DEFER": defer})
     assert "COMM TABLE world=1 defer=%s" % (defer == "1") in out
