@@ -556,6 +556,8 @@ def gen_cfg1_full(tag="cfg1_256"):
     report.append((f"{tag}/index flips inside near-ties (count)", float(mism.sum())))
     out[p + "indices"] = npy(ind_ref)
     out[p + "index_gap"] = npy(gap)
+    # the whole reconstruction, not only its 8 x 8 corner slice: 32768 hashed positions + per-channel fp64 sums
+    large_summary(out, p + "x_recon", res["x_recon"])
     out[p + "logits_fake_sum"] = np.float64(res["logits_fake"].double().sum().item())
     out[p + "logits_fake_abs"] = np.float64(res["logits_fake"].double().abs().sum().item())
     out[p + "embed_after_sum"] = np.float64(model.quantizer._codebook.embed.double().sum().item())
@@ -571,6 +573,11 @@ def gen_cfg1_full(tag="cfg1_256"):
             out[p + "g." + k + ".sum"] = np.float64(g.double().sum().item())
             out[p + "g." + k + ".abs"] = np.float64(g.double().abs().sum().item())
             out[p + "g." + k + ".head"] = npy(g.reshape(-1)[:16])
+            # the whole gradient tensor: small ones in full, large ones at hashed positions + per-channel sums
+            if g.dim() >= 2 and g.numel() > LARGE_SAMPLES:
+                large_summary(out, p + "g." + k, g)
+            else:
+                out[p + "g." + k + ".full"] = npy(g)
             check(f"{tag}/g.{k}", Po[k].grad, g, tol=2e-3)
     # one Adam step (torch.optim.Adam, train_favae.py:292-301) and post-step parameter checksums
     g_params = list(model.encoder.parameters()) + list(model.decoder.parameters()) + list(model.quantizer.parameters())
@@ -703,6 +710,7 @@ def gen_gan(tag="gan_128"):
     check(f"{tag}/disc_only/logits_fake_d", lf_c, logits_fake, tol=2e-5)
     p = tag + "."
     summarize(p, res, model, out, x)
+    large_summary(out, p + "x_recon", res["x_recon"])          # the whole stage-0 reconstruction
     out[p + "indices"] = npy(ro["out"]["indices"])
     out[p + "weight_d"] = np.float64(weight_d)
     out[p + "loss_disc"] = npy(loss_disc.reshape(-1))
@@ -714,6 +722,10 @@ def gen_gan(tag="gan_128"):
         out[p + "g." + k + ".sum"] = np.float64(g.double().sum().item())
         out[p + "g." + k + ".abs"] = np.float64(g.double().abs().sum().item())
         out[p + "g." + k + ".head"] = npy(g.reshape(-1)[:16])
+        if g.dim() >= 2 and g.numel() > LARGE_SAMPLES:
+            large_summary(out, p + "g." + k, g)
+        else:
+            out[p + "g." + k + ".full"] = npy(g)
         check(f"{tag}/g.{k}", ro["grads"][k], g, tol=2e-3)
     for k, g in d_grads.items():
         out[p + "dg." + k + ".sum"] = np.float64(g.double().sum().item())

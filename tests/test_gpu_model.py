@@ -105,6 +105,9 @@ def test_forward_against_reference_golden(golden_dir, gtag, mtag):
     assert abs(float(model.quantizer._codebook.embed.double().abs().sum()) - float(g[p + "embed_after_abs"])) < 1e-5 * float(g[p + "embed_after_abs"])
 
 
+from test_oracle_golden import large_close  # noqa: E402  (fixture summaries of large tensors: hashed positions + channel sums)
+
+
 def test_indices_against_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "models.npz"))
     for gtag, mtag in GOLDEN_FWD:
@@ -133,8 +136,15 @@ def _golden_step(g, gtag, mtag, grad_tol=5e-3):
     close(torch.stack([v.reshape(()) for v in out["loss_dsl_levels"]]), g[p + "loss_dsl_levels"], 1e-4, "dsl levels")
     xr = out["x_recon"].detach().cpu()
     close(xr[:, :, ::max(1, H // 8), ::max(1, W // 8)], g[p + "x_recon_slice"], 1e-4, "x_recon")
+    # the slice above sits on the corners of the conv kernels' 16 x 16-pixel workgroup tiles; these cover every element: the sum and
+    # abs-sum over the whole tensor, and (fixtures of the BASELINE sizes) 32768 hashed positions + per-channel sums / sums of squares
+    xd = xr.double()
+    assert abs(float(xd.sum()) - float(g[p + "x_recon_sum"])) < 1e-4 * float(g[p + "x_recon_abs"]), "x_recon sum"
+    assert abs(float(xd.abs().sum()) - float(g[p + "x_recon_abs"])) < 1e-4 * float(g[p + "x_recon_abs"]), "x_recon abs-sum"
+    if p + "x_recon.at" in g.files:
+        large_close(g, p + "x_recon", xr, 1e-4, "x_recon")
     named = dict(model.named_parameters())
-    n = 0
+    n = n_full = 0
     for k, prm in named.items():
         key = p + "g." + k + ".head"
         if key in g.files:
@@ -145,8 +155,19 @@ def _golden_step(g, gtag, mtag, grad_tol=5e-3):
             assert err < tol, f"grad head {k}: {err:.3e}"
             ref_abs = float(g[p + "g." + k + ".abs"])
             assert abs(float(gr.double().abs().sum()) - ref_abs) < tol * ref_abs, f"grad abs-sum {k}"
+            # whole tensor (fixtures of the BASELINE sizes): every element of the small ones, hashed positions + channel sums of the large
+            if p + "g." + k + ".full" in g.files:
+                ref = g[p + "g." + k + ".full"]
+                err = float(np.abs(gr.numpy().reshape(ref.shape) - ref).max()) / (float(np.abs(ref).max()) + 1e-30)
+                assert err < tol, f"grad (every element) {k}: {err:.3e}"
+                n_full += 1
+            elif p + "g." + k + ".at" in g.files:
+                large_close(g, p + "g." + k, gr, tol, "grad " + k)
+                n_full += 1
             n += 1
     assert n >= 8
+    if p + "x_recon.at" in g.files:
+        assert n_full >= 8, "the full-size fixtures carry whole-tensor gradients"
     return model, ts, out
 
 
@@ -482,7 +503,7 @@ def test_gan_iteration_against_reference_golden(golden_dir, tag):
     ts.backward(out)
     named = dict(model.named_parameters())
     res = {"loss_disc": out["loss_disc"].detach().cpu(), "weight_d": float(out["weight_d"]), "loss_g": out["loss_g"].detach().cpu(),
-           "logits_fake": out["logits_fake"].detach().cpu(),
+           "logits_fake": out["logits_fake"].detach().cpu(), "x_recon": out["x_recon"].detach().cpu(),
            "grads": {k: p.grad.detach().clone().cpu() for k, p in named.items() if not k.startswith("discriminator.")}}
     ts.t += 1
     nm = ts.n_main
@@ -493,7 +514,17 @@ def test_gan_iteration_against_reference_golden(golden_dir, tag):
     # stage 1 by hand as well (gradients before the discriminator's Adam step)
     from losses.hinge import hinge_d_loss
     ts.dgflat.zero_()
+    seen = []                                         # the reconstruction stage 1 feeds the discriminator with (post-Adam generator)
+    hook = model.decoder.register_forward_hook(lambda m, i, o: seen.append(o[0].detach().cpu().contiguous()))
     logits_real, logits_fake = model(x, stage=1)
+    hook.remove()
+    # EVERY element of the stage-1 reconstruction against the reference's (x_recon_d is stored in full).  It sits behind the generator's
+    # first Adam step (-lr * sign(g): noise-level gradient elements move their parameter by 2 lr in opposite directions in two fp32
+    # implementations), hence 3e-4 instead of the 1e-4 the stage-0 reconstruction holds in check_gan_golden.
+    ref_d = torch.from_numpy(g[tag + ".x_recon_d"])
+    err_d = float((seen[0] - ref_d).abs().max() / ref_d.abs().max())
+    print(f"\n[{tag}] stage-1 x_recon vs reference, every element: max err / max {err_d:.2e}")
+    assert err_d < 3e-4, err_d
     loss_d = hinge_d_loss(logits_real, logits_fake)
     loss_d.backward()
     res.update({"loss_d": loss_d.detach().cpu(), "logits_real": logits_real.detach().cpu(), "logits_fake_d": logits_fake.detach().cpu(),

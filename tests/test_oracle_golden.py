@@ -238,8 +238,14 @@ def _check_model_case(g, tag, cfg, with_disc=False):
         if key in g.files:
             close(P[k].grad.reshape(-1)[:16], g[key], rtol=5e-3, name="g." + k)
             close(P[k].grad.double().abs().sum(), g[p + "g." + k + ".abs"], rtol=1e-3, name="gabs." + k)
+            if p + "g." + k + ".full" in g.files:                    # full-size fixtures: every element / hashed positions + channel sums
+                close(P[k].grad.reshape(-1), g[p + "g." + k + ".full"].reshape(-1), rtol=5e-3, name="g(all)." + k)
+            elif p + "g." + k + ".at" in g.files:
+                large_close(g, p + "g." + k, P[k].grad, 5e-3, "g(all)." + k)
             n += 1
     assert n >= 8
+    if p + "x_recon.at" in g.files:
+        large_close(g, p + "x_recon", out["x_recon"], 1e-4, "x_recon")
     return P, r
 
 
@@ -363,6 +369,23 @@ GAN_TOLS_ORACLE = dict(stage0=1e-4, weight_d=2e-3, loss_g=5e-4, grads=5e-3, logi
                        bn=1e-3)
 
 
+def large_close(g, key, t, tol, what):
+    """`t` against what a fixture keeps of a large reference tensor (oracle/gen_golden.py large_summary): its values at
+    O.sample_positions (max error / absmax), the per-channel (dim 1) fp64 sums and sums of squares over EVERY element."""
+    t = t.detach().cpu().contiguous()
+    flat = t.reshape(-1)
+    amax = float(g[key + ".absmax"]) + 1e-30
+    at = flat[O.sample_positions(flat.numel(), len(g[key + ".at"]))].numpy()
+    err = float(np.abs(at - g[key + ".at"]).max()) / amax
+    assert err < tol, f"{what} at {len(at)} positions: {err:.3e}"
+    d = t.double().transpose(0, 1).reshape(t.shape[1], -1)
+    per = d.shape[1]
+    csum, csq = d.sum(1).numpy(), d.pow(2).sum(1).numpy()
+    # `per` elements each within tol * amax move a channel sum by at most per * tol * amax; independent errors: ~ sqrt(per)
+    assert float(np.abs(csum - g[key + ".csum"]).max()) < 4 * tol * amax * per ** 0.5 + 1e-30, f"{what} channel sums"
+    assert float((np.abs(csq - g[key + ".csq"]) / (g[key + ".csq"] + tol * amax * amax * per + 1e-30)).max()) < 4 * tol, f"{what} channel sq-sums"
+
+
 def check_gan_golden(g, res, P, lr, close_fn=close, tols=GAN_TOLS_ORACLE, tag="gan_128"):
     """Shared by the CPU (oracle) and GPU (HIP path) tests: one full train() iteration with discriminator training against the
     outputs captured from the reference modules (tests/golden/gan_128.npz, oracle/gen_golden.py::gen_gan).
@@ -387,10 +410,16 @@ def check_gan_golden(g, res, P, lr, close_fn=close, tols=GAN_TOLS_ORACLE, tag="g
     close_fn(res["logits_real"], g[p + "logits_real"], rtol=tols["stage0"], name="logits_real")
     close_fn(res["loss_d"].reshape(-1), g[p + "loss_d"], rtol=tols["stage0"], name="loss_d")
     close_fn(res["logits_fake_d"], g[p + "logits_fake_d"], rtol=tols["logits_fake_d"], name="logits_fake_d")
+    if "x_recon" in res and p + "x_recon.at" in g.files:            # the whole stage-0 reconstruction: hashed positions + channel sums
+        large_close(g, p + "x_recon", res["x_recon"], tols["stage0"], "x_recon (stage 0)")
     n = 0
     for k, gr in res["grads"].items():
         if p + "g." + k + ".head" in g.files:
             close_fn(gr.reshape(-1)[:16], g[p + "g." + k + ".head"], rtol=tols["grads"], name="g." + k)
+            if p + "g." + k + ".full" in g.files:                    # every element of the small tensors
+                close_fn(gr.detach().cpu().contiguous().reshape(-1), g[p + "g." + k + ".full"].reshape(-1), rtol=tols["grads"], name="g(all)." + k)
+            elif p + "g." + k + ".at" in g.files:                    # hashed positions + per-channel sums of the large ones
+                large_close(g, p + "g." + k, gr, tols["grads"], "g(all)." + k)
             n += 1
     assert n >= 8
     for k, gr in res["dgrads"].items():
@@ -425,6 +454,7 @@ def test_gan_iteration(golden_dir, tag):
     r = tr.step(O.det_input(B, H, W, seed))
     assert np.array_equal(r["out"]["indices"].numpy(), g[tag + ".indices"])
     r["logits_fake"] = r["out"]["logits_fake"]
+    r["x_recon"] = r["out"]["x_recon"]
     check_gan_golden(g, r, tr.P, lr, tols=GAN_TOLS_ORACLE if tag == "gan_128" else GAN_TOLS_ORACLE_256, tag=tag)
 
 
