@@ -774,10 +774,18 @@ static bool wino_geometry(const favae_conv_desc* d) {
            d->gather == FAVAE_GATHER_PLAIN && d->Hout == d->Hin && d->Wout == d->Win && d->Hin % 16 == 0 && d->Win % 16 == 0 &&
            d->Cout % 64 == 0 && d->Cin % 16 == 0;
 }
+// Cout == 64 has exactly ONE split-operand kernel, the Winograd one (the direct split tiles are 128 channels wide): such a conv wants split
+// weights exactly when wino_ok() will hand it to that kernel -- the same conditions, spelled out here because wino_ok() itself is
+// defined through this predicate (with FAVAE_CONV_HALO=0 the geometry alone said "eligible", Python built plain h3 records
+// and the fp32 buffer kernel read them as weights).
+static bool wino64_only_ok(const favae_conv_desc* d, bool has_affine) {
+    return d->Cout == 64 && wino_geometry(d) && use_halo() && (size_t)d->Cout * d->Cin * 64 < (1u << 31) &&
+           (!has_affine || d->Cin <= wino::AFF_C) && (size_t)d->N * d->Hout * d->Wout * d->Cout * 4 < ((size_t)1 << 32);
+}
 static bool sp_fwd_eligible(const favae_conv_desc* d, bool has_affine) {
     if (!desc_ok(d) || force_generic() || force_nobuf() || !use_b6()) return false;
     const size_t xb = (size_t)d->N * d->Hin * d->Win * d->Cin * 4, wb = (size_t)d->Cout * d->KH * d->KW * d->Cin * 6;
-    return (d->Cout > 64 || (d->Cout == 64 && wino_geometry(d))) && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) &&
+    return (d->Cout > 64 || wino64_only_ok(d, has_affine)) && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) &&
            (d->gather == FAVAE_GATHER_PLAIN || !has_affine);
 }
 
@@ -1239,6 +1247,9 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     // 2x2 phase convs (Upsample forward / data gradient, first phase of the Downsample data gradient): one side on a sub-grid
     const bool halo2_ok = special && halo_common && use_halo2() && d->KH == 2 && d->KW == 2 && d->lat_step == 2 && xf == 0 &&
                           (d->pad == 0 || d->pad == 1) && (a.pad_w == 0 || a.pad_w == 1);
+    // pre-split records are only understood by the 128-channel split tiles and by the Winograd kernel: never let them reach a kernel
+    // that would read them as fp32 weights
+    if (w6 && !wino && bn != 128) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (wino) {
         if (!(!special && buf_ok && use_b6() && w6 && wino_geometry(d) && wplanes == 2 && !planes_out && d->w_rec_offset == 0))
             return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);

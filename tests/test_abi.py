@@ -104,3 +104,39 @@ def test_weight_cache_keys_follow_every_visible_write():
     wm.versions = [K._weights_key(p) for p in wm.params]
     K.invalidate_weight_caches(flat)                              # a raw-pointer write announced by its author
     assert K._weight_amax(p1) is None and K._weight_amax(p2) is None
+
+
+def test_cout64_wants_split_weights_exactly_when_the_winograd_kernel_takes_it():
+    """a dense 3x3 conv with 64 output channels has ONE split-operand kernel, the Winograd one.
+    `favae_conv_wants_split_weights` must say "h3 records" exactly when `favae_conv_wino_ok` does -- under every A/B switch that takes
+    the Winograd kernel away (FAVAE_CONV_HALO=0, FAVAE_WINO=0), with a fused affine, and for an input-channel count the fused
+    GroupNorm staging does not hold -- or Python would build plain h3 records that only the 128-channel tiles understand.
+    Host logic only (child processes: the switches are read once per process)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from ctypes import byref\n"
+        "from favae_hip import query\n"
+        "from favae_hip.ops import make_conv_desc, GATHER_PLAIN, ACT_NONE, ACT_SILU\n"
+        "for cin, aff, act in ((64, 0, ACT_NONE), (64, 1, ACT_SILU), (1024, 1, ACT_SILU), (128, 0, ACT_NONE)):\n"
+        "    d = make_conv_desc(2, 32, 32, cin, 32, 32, 64, 3, 3, 1, 1, GATHER_PLAIN, act, 1)\n"
+        "    print(cin, aff, query('favae_conv_wants_split_weights', byref(d), aff), query('favae_conv_wino_ok', byref(d), aff))\n"
+    ) % os.path.join(ROOT, "fa-vae_amd")
+    seen_on = seen_off = 0
+    for env_extra in ({}, {"FAVAE_CONV_HALO": "0"}, {"FAVAE_WINO": "0"}):
+        env = dict(os.environ, **env_extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        for line in out.stdout.strip().splitlines():
+            cin, aff, wants, wino = (int(v) for v in line.split())
+            assert (wants == 2) == (wino == 1) and wants in (0, 2), (env_extra, line)
+            if env_extra:
+                assert wants == 0, (env_extra, line)
+                seen_off += 1
+            elif cin <= 512:
+                assert wants == 2, line
+                seen_on += 1
+            else:
+                assert wants == 0, line                 # 1024 input channels with a fused affine: beyond the LDS staging of (scale, shift)
+    assert seen_on == 3 and seen_off == 8

@@ -366,6 +366,41 @@ def test_winograd_conv_shapes_against_direct_kernel(K, N, cin, cout, H, W):
             nm, float((u - v).abs().max()) / scale)
 
 
+@pytest.mark.parametrize("switch", ["FAVAE_CONV_HALO", "FAVAE_WINO"])
+def test_cout64_conv_without_the_winograd_kernel(switch):
+    """with the A/B switch that takes the Winograd kernel away a 64 -> 64 3x3 conv (the VGG16 convs of LPIPS) must
+    fall back to the fp32-MFMA kernels and stay CORRECT -- round 4's eligibility predicate said "split weights" on geometry alone, Python
+    built plain h3 records and the fp32 kernel read them as weights.  Child process (the switch is read once), forward + both gradients
+    against an fp64 convolution on the CPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, math, torch
+sys.path.insert(0, %r)
+import favae_hip; favae_hip.load()
+from favae_hip import ops as K
+torch.manual_seed(5)
+d = torch.device("cuda:0")
+x = torch.randn(2, 64, 32, 32, device=d); w = torch.randn(64, 64, 3, 3, device=d) * math.sqrt(1.0 / 576); b = torch.randn(64, device=d) * 0.1
+gy = torch.randn(2, 64, 32, 32, device=d)
+xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+y = K.fused_conv(xg, wg, b, None, None, None, K.ConvCfg(3, 3, 1, 1))
+dx, dw = torch.autograd.grad(y, (xg, wg), gy)
+K.sync_side_stream(); torch.cuda.synchronize()
+xr, wr = x.cpu().double().requires_grad_(True), w.cpu().double().requires_grad_(True)
+yr = torch.nn.functional.conv2d(xr, wr, b.cpu().double(), padding=1)
+dxr, dwr = torch.autograd.grad(yr, (xr, wr), gy.cpu().double())
+for nm, u, v in (("y", y, yr), ("dx", dx, dxr), ("dw", dw, dwr)):
+    e = float((u.detach().cpu().double() - v).abs().max() / v.abs().max())
+    print(nm, e)
+    assert e < 2e-5, (nm, e)
+print("COUT64 OK")
+""" % os.path.join(root, "fa-vae_amd")
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{switch: "0"}), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "COUT64 OK" in out.stdout, out.stdout[-1500:] + out.stderr[-2500:]
+
+
 @pytest.mark.parametrize("cout", [64, 128])
 def test_winograd_conv_with_fused_leaky_relu(K, cout):
     """Round 4: any fused activation goes through the Winograd kernel (XFORM = 3), not only SiLU -- the LeakyReLU / ReLU-on-load convs
