@@ -533,6 +533,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #include "conv_buf.h"
 #include "conv_split.h"
 #include "conv_wino.h"
+#include "conv_wino4.h"
 #include "conv_thin.h"
 
 // out[i] (+)= sum_z part[z][i] in a fixed order (4 interleaved partial sums -> 4 loads in flight per thread)
@@ -945,12 +946,19 @@ extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const fl
 }
 
 static bool wino_ok(const favae_conv_desc* d, bool has_affine);
+static bool wino4_ok(const favae_conv_desc* d, bool has_affine);
+// planes word of a call that passes Winograd records: F(2x2) records go with wino_ok, F(4x4) records (FAVAE_PLANES_WINO4 on top) with wino4_ok
+static bool wino_planes_ok(const favae_conv_desc* d, int planes, bool has_affine) {
+    if (planes == (2 | FAVAE_PLANES_WINO)) return wino_ok(d, has_affine);
+    if (planes == (2 | FAVAE_PLANES_WINO | FAVAE_PLANES_WINO4)) return wino4_ok(d, has_affine);
+    return false;
+}
 extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, const void* wsplit, int planes,
                                     const float* x_absmax, const float* bias, const float* resid, const float* scale,
                                     const float* shift, float* y, favae_stream_t stream) {
     if (!sp_fwd_eligible(d, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (planes & FAVAE_PLANES_WINO) {
-        if (planes != (2 | FAVAE_PLANES_WINO) || !wino_ok(d, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+        if (!wino_planes_ok(d, planes, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         FAVAE_REQUIRE(wsplit && x_absmax);
     } else {
         FAVAE_REQUIRE(wsplit && (planes == 3 || planes == 4 || ((planes == 2 || planes == 1) && x_absmax)));
@@ -986,6 +994,29 @@ static bool halo3_fp16_ok(const favae_conv_desc* d, bool has_affine) {
 static bool wino_ok(const favae_conv_desc* d, bool has_affine) {
     return use_wino() && conv_mode() == 2 && halo3_fp16_ok(d, has_affine) && d->Hin % 16 == 0 && d->Win % 16 == 0 && d->Cout % 64 == 0 &&
            (size_t)d->Cout * d->Cin * 64 < (1u << 31) && (!has_affine || d->Cin <= wino::AFF_C);
+}
+
+// F(4x4, 3x3) variant (conv_wino4.h): 32 x 16-pixel tiles, K loop unrolled by four chunks, records of 144 bytes per (co, ci) pair.  The
+// geometry check only: WHERE it is used (data gradients; decoder layers) is the caller's policy (ops.py, FAVAE_WINO4) because the
+// accuracy bar depends on what consumes the result.  FAVAE_WINO4=0 in the environment: never.
+int g_wino4 = -1;
+static bool use_wino4() {
+    if (g_wino4 < 0) { const char* e = getenv("FAVAE_WINO4"); g_wino4 = (e && e[0] == '0') ? 0 : 1; }
+    return g_wino4 == 1;
+}
+static bool wino4_ok(const favae_conv_desc* d, bool has_affine) {
+    return use_wino4() && wino_ok(d, has_affine) && d->Win % 32 == 0 && d->Cin % 64 == 0 && d->Cin <= 736 &&
+           (size_t)d->Cout * d->Cin * 144 < (1u << 31);
+}
+extern "C" int favae_conv_wino4_ok(const favae_conv_desc* d, int has_affine) { return desc_ok(d) && wino4_ok(d, has_affine != 0) ? 1 : 0; }
+extern "C" int favae_set_wino4(int on) {
+    const int prev = use_wino4() ? 1 : 0;
+    g_wino4 = on ? 1 : 0;
+    return prev;
+}
+extern "C" size_t favae_wino4_weights_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0 || Cout % 16 || Cin % 16) return 0;
+    return (size_t)sp::WHDR + (size_t)Cout * Cin * 144;
 }
 
 // switch the Winograd path on / off at run time (overrides FAVAE_WINO); returns the previous setting
@@ -1029,8 +1060,10 @@ extern "C" size_t favae_wino_weights_bytes(int Cout, int Cin) {
 // planes, in MFMA fragment order.  flip = 0: the forward conv (Cout outputs); flip = 1: its data gradient (Cin outputs, taps
 // flipped).  amax: device float max|w| (nullptr: computed here).  The header (float[0]) holds max|w|.
 extern "C" int favae_wino_weights(const float* w, void* out, int Cout, int Cin, int flip, const float* amax, favae_stream_t stream) {
-    FAVAE_REQUIRE(w && out && favae_wino_weights_bytes(Cout, Cin) && (((uintptr_t)out) & 15) == 0);
+    FAVAE_REQUIRE(w && out && favae_wino_weights_bytes(Cout, Cin) && (((uintptr_t)out) & 15) == 0 && flip >= 0 && flip <= 3);
     const int vec = (((uintptr_t)w) & 15) == 0 ? 1 : 0;
+    const bool f43 = (flip & 2) != 0;            // bit 1: F(4x4, 3x3) records (favae_wino4_weights_bytes) for conv3x3_wino4_sp_kernel
+    flip &= 1;
     FAVAE_REQUIRE(flip ? (Cin % 64 == 0 && Cout % 16 == 0) : (Cout % 64 == 0 && Cin % 16 == 0));
     hipStream_t s = (hipStream_t)stream;
     float* hdr = nullptr;
@@ -1042,7 +1075,13 @@ extern "C" int favae_wino_weights(const float* w, void* out, int Cout, int Cin, 
         hdr = (float*)out;
     }
     const unsigned blocks = (unsigned)(((size_t)Cout * Cin / 8 + 255) / 256);
-    FAVAE_PROF_NOTE(0, 4.0 * Cout * 9 * Cin + 64.0 * Cout * Cin);
+    FAVAE_PROF_NOTE(0, 4.0 * Cout * 9 * Cin + (f43 ? 144.0 : 64.0) * Cout * Cin);
+    if (f43) {
+        if (flip) FAVAE_KLAUNCH((wino4_weights_kernel<true>), dim3(blocks), dim3(256), 0, s, w, (unsigned char*)out + sp::WHDR, Cout, Cin, amax, hdr, vec);
+        else FAVAE_KLAUNCH((wino4_weights_kernel<false>), dim3(blocks), dim3(256), 0, s, w, (unsigned char*)out + sp::WHDR, Cout, Cin, amax, hdr, vec);
+        FAVAE_CHECK_LAUNCH();
+        return FAVAE_OK;
+    }
     if (flip) FAVAE_KLAUNCH((wino_weights_kernel<true>), dim3(blocks), dim3(256), 0, s, w, (unsigned char*)out + sp::WHDR, Cout, Cin, amax, hdr, vec);
     else FAVAE_KLAUNCH((wino_weights_kernel<false>), dim3(blocks), dim3(256), 0, s, w, (unsigned char*)out + sp::WHDR, Cout, Cin, amax, hdr, vec);
     FAVAE_CHECK_LAUNCH();
@@ -1100,7 +1139,7 @@ extern "C" int favae_conv_fwd_split_stats(const favae_conv_desc* d, const float*
     const int tiles = favae_conv_stats_tiles(d, scale != nullptr);
     // the tile grid of the partial sums is the kernel's: Winograd records go with the Winograd kernel's 16 x 16 tiles and nothing else
     if (((planes & FAVAE_PLANES_WINO) != 0) != wino_ok(d, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-    if (planes & FAVAE_PLANES_WINO) planes = planes == (2 | FAVAE_PLANES_WINO) ? planes : 0;
+    if (planes & FAVAE_PLANES_WINO) planes = wino_planes_ok(d, planes, scale != nullptr) ? planes : 0;
     if (!tiles || ((planes & 0xff) != 2 && planes != 1 && planes != 4)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     if (y_absmax && favae_zero_target(y_absmax, sizeof(float), (hipStream_t)stream) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
@@ -1115,7 +1154,7 @@ extern "C" int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy,
     FAVAE_REQUIRE(desc_ok(d) && dy && wsplit && (dy_absmax || planes == 4) && da && x && mean && rstd && gamma && beta && part && groups > 0);
     const int tiles = favae_conv_gnbwd_tiles(d);
     if (((planes & FAVAE_PLANES_WINO) != 0) != wino_ok(d, false)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-    if (planes & FAVAE_PLANES_WINO) planes = planes == (2 | FAVAE_PLANES_WINO) ? planes : 0;
+    if (planes & FAVAE_PLANES_WINO) planes = wino_planes_ok(d, planes, false) ? planes : 0;
     if (!tiles || ((planes & 0xff) != 2 && planes != 1 && planes != 4) || d->Cout % groups != 0) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     GnBwdEpi gb{x, mean, rstd, gamma, beta, (double*)part, groups, act};
@@ -1136,6 +1175,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
                            (double)d->N * d->Hout * d->Wout * d->Cout * (1 + (resid ? 1 : 0) + (gb ? 1 : 0)) +
                            (double)d->Cout * d->KH * d->KW * d->Cin));
     const bool wino = (wplanes & FAVAE_PLANES_WINO) != 0;     // Winograd records (favae_wino_weights): conv3x3_wino_sp_kernel
+    const bool wino4 = (wplanes & FAVAE_PLANES_WINO4) != 0;   // ... F(4x4, 3x3) records: conv3x3_wino4_sp_kernel
     wplanes &= 0xff;
     const bool w6 = wplanes != 0;                            // pre-split weights: records start behind the header
     if (!w6) {
@@ -1255,6 +1295,33 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
             return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (gb && (xf != 0 || bias || resid)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (stats_part && !(xf == 0 || xf == 2)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+        if (wino4) {
+            if (!wino4_ok(d, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+            a.tiles_n = d->Cout / 64;
+            a.w_bytes = (unsigned)((size_t)d->Cout * d->Cin * 144);
+            auto rcp32 = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };
+            a.wino_rcp_n = rcp32(a.tiles_n); a.wino_rcp_w = rcp32(d->Win / 32); a.wino_rcp_h = rcp32(d->Hin / 16);
+            const dim3 wgrid((unsigned)(d->N * (d->Hin / 16) * (d->Win / 32) * a.tiles_n));
+#define FAVAE_LAUNCH_WINO4(X, GBV, SEV)                                                                                     \
+    do {                                                                                                                    \
+        static bool attr_set = false;                                                                                       \
+        if (!attr_set) {                                                                                                    \
+            (void)hipFuncSetAttribute((const void*)conv3x3_wino4_sp_kernel<X, GBV, SEV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      wino4::LDS_B);                                                                        \
+            attr_set = true;                                                                                                \
+        }                                                                                                                   \
+        FAVAE_KLAUNCH((conv3x3_wino4_sp_kernel<X, GBV, SEV>), wgrid, dim3(512), wino4::LDS_B, s, a);                        \
+    } while (0)
+            if (gb) FAVAE_LAUNCH_WINO4(0, true, false);
+            else if (stats_part && xf == 0) FAVAE_LAUNCH_WINO4(0, false, true);
+            else if (stats_part) FAVAE_LAUNCH_WINO4(2, false, true);
+            else if (xf == 0) FAVAE_LAUNCH_WINO4(0, false, false);
+            else if (xf == 2) FAVAE_LAUNCH_WINO4(2, false, false);
+            else return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+#undef FAVAE_LAUNCH_WINO4
+            FAVAE_CHECK_LAUNCH();
+            return FAVAE_OK;
+        }
         a.tiles_n = d->Cout / 64;
         a.w_bytes = (unsigned)((size_t)d->Cout * d->Cin * 64);
         auto rcp32 = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };   // 0: divisor 1

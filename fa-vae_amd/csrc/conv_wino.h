@@ -140,6 +140,10 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     wino_weights_body<FLIP>(w, out, Cout, Cin, amax, hdr_out, vec, blockIdx.x * 256 + threadIdx.x);
 }
 
+template <bool FLIP>
+__device__ __forceinline__ void wino4_weights_body(const float* __restrict__ w, unsigned char* __restrict__ out, int Cout, int Cin,
+                                                   const float* __restrict__ amax, float* __restrict__ hdr_out, int vec, int idx);   // conv_wino4.h
+
 // All Winograd records of a model in ONE launch (favae_wino_weights_grouped): jobs[] = one (weight tensor, direction) each, block_job[b] =
 // the job of block b (blocks of a job are consecutive from job.block0).  `out` points at the job's record buffer INCLUDING its header.
 struct WinoJob {
@@ -152,6 +156,11 @@ __global__ __launch_bounds__(256) void wino_weights_grouped_kernel(const WinoJob
     const WinoJob j = jobs[block_job[blockIdx.x]];
     const int idx = (blockIdx.x - j.block0) * 256 + threadIdx.x;
     const int vec = ((reinterpret_cast<uintptr_t>(j.w) & 15) == 0) ? 1 : 0;
+    if (j.flip & 2) {                               // bit 1: F(4x4, 3x3) records (conv_wino4.h)
+        if (j.flip & 1) wino4_weights_body<true>(j.w, j.out + sp::WHDR, j.Cout, j.Cin, j.amax, reinterpret_cast<float*>(j.out), vec, idx);
+        else wino4_weights_body<false>(j.w, j.out + sp::WHDR, j.Cout, j.Cin, j.amax, reinterpret_cast<float*>(j.out), vec, idx);
+        return;
+    }
     if (j.flip) wino_weights_body<true>(j.w, j.out + sp::WHDR, j.Cout, j.Cin, j.amax, reinterpret_cast<float*>(j.out), vec, idx);
     else wino_weights_body<false>(j.w, j.out + sp::WHDR, j.Cout, j.Cin, j.amax, reinterpret_cast<float*>(j.out), vec, idx);
 }

@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FAVAE_HIP_LIB") or os.path.join(_HERE, "libfavae_hip.so")     # FAVAE_HIP_LIB: same-box A/B of two builds
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02, ACT_RELU = 0, 1, 2, 3
@@ -132,6 +132,9 @@ SIGNATURES = {
     "favae_conv_wino_ok": (c_int, [_P, c_int]),
     "favae_set_wino": (c_int, [c_int]),
     "favae_get_wino": (c_int, []),
+    "favae_conv_wino4_ok": (c_int, [_P, c_int]),
+    "favae_set_wino4": (c_int, [c_int]),
+    "favae_wino4_weights_bytes": (c_size_t, [c_int, c_int]),
     "favae_set_zero_arena": (c_int, [c_void_p, c_size_t]),
     "favae_wino_weights_grouped": (c_int, [_P, _P, c_int, _S]),
     "favae_wino_weights_bytes": (c_size_t, [c_int, c_int]),

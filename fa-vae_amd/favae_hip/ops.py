@@ -253,7 +253,7 @@ class WinoRecords:
 
     def __init__(self, params):
         self.params, self._jobs, self.bufs, self.versions = [], [], {}, {}
-        self.dev, self.nbytes, self.store = None, 0, None
+        self.dev, self.store, self._dirty, self._have = None, None, False, set()
         for p in params:
             ent = getattr(p, "_favae_wmax", None)
             if ent is None or p.dim() != 4 or tuple(p.shape[2:]) != (3, 3) or not _is_cl(p):
@@ -263,40 +263,62 @@ class WinoRecords:
                 o, i = (ci, co) if flip else (co, ci)
                 if o % 64 or i % 16:
                     continue
-                size = int(query("favae_wino_weights_bytes", co, ci))
-                self._jobs.append((p, flip, co, ci, self.nbytes, size))
-                self.nbytes += (size + 255) // 256 * 256
+                self._add(p, flip, co, ci)
             self.dev = p.device
             self.params.append(p)
-        self.n = len(self._jobs)
         for p in self.params:
             p._favae_wino = self
 
+    def _add(self, p, key, co, ci):
+        self._jobs.append((p, key, co, ci))
+        self._have.add((id(p), key))
+        self._dirty = True
+
+    @property
+    def n(self):
+        return len(self._jobs)
+
+    def want(self, p, key):
+        """F(4x4, 3x3) records (key = 2 forward, 3 data gradient; csrc/conv_wino4.h) are made for the (weight, direction) pairs a conv launch
+        actually asked for -- which layers tile into that kernel depends on their spatial size, which this object does not know.  The first
+        request is served by a one-off favae_wino_weights launch of the caller; from the next refresh() on the grouped launch makes them."""
+        if (id(p), key) in self._have or not any(q is p for q in self.params):
+            return
+        self._add(p, key, int(p.shape[0]), int(p.shape[1]))
+
     def _materialize(self):
-        """record store + device job table, on the first refresh that needs them (64 bytes per (Cout, Cin) pair and direction: ~1 GB for the
-        f=16 model -- not spent when the conv mode is not h3 or the Winograd path is off)"""
+        """record store + device job table, on the first refresh that needs them (64 bytes per (Cout, Cin) pair and direction, 144 for the
+        F(4x4) records: ~1 GB for the f=16 model -- not spent when the conv mode is not h3 or the Winograd path is off)"""
         from . import WinoJob
-        self.store = torch.empty((self.nbytes,), dtype=torch.uint8, device=self.dev)
+        sizes = [int(query("favae_wino4_weights_bytes" if key & 2 else "favae_wino_weights_bytes", co, ci)) for (p, key, co, ci) in self._jobs]
+        offs, nbytes = [], 0
+        for sz in sizes:
+            offs.append(nbytes)
+            nbytes += (sz + 255) // 256 * 256
+        self.nbytes = nbytes
+        self.store = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
+        self.bufs = {}
         arr = (WinoJob * self.n)()
         block_job, b0 = [], 0
-        for k, (p, flip, co, ci, off, size) in enumerate(self._jobs):
+        for k, (p, key, co, ci) in enumerate(self._jobs):
             wm, i = p._favae_wmax
             nb = (co * ci // 8 + 255) // 256
-            arr[k].w, arr[k].out, arr[k].amax = p.data_ptr(), self.store.data_ptr() + off, wm.out[i:i + 1].data_ptr()
-            arr[k].Cout, arr[k].Cin, arr[k].flip, arr[k].block0 = co, ci, flip, b0
+            arr[k].w, arr[k].out, arr[k].amax = p.data_ptr(), self.store.data_ptr() + offs[k], wm.out[i:i + 1].data_ptr()
+            arr[k].Cout, arr[k].Cin, arr[k].flip, arr[k].block0 = co, ci, key, b0
             block_job += [k] * nb
             b0 += nb
-            self.bufs.setdefault(id(p), {})[flip] = self.store[off:off + size]
+            self.bufs.setdefault(id(p), {})[key] = self.store[offs[k]:offs[k] + sizes[k]]
         self.jobs = torch.frombuffer(bytearray(bytes(memoryview(arr))), dtype=torch.uint8).to(self.dev)
         self.block_job = torch.tensor(block_job, dtype=torch.int32, device=self.dev)
         self.nblocks = b0
+        self._dirty = False
 
     def refresh(self):
         on = bool(query("favae_get_wino"))
         if not self.n or not on or get_conv_mode() != "h3":
             self.versions = {}
             return
-        if self.store is None:
+        if self.store is None or self._dirty:
             self._materialize()
         call("favae_wino_weights_grouped", ptr(self.jobs), ptr(self.block_job), self.nblocks)
         self.versions = {id(p): _weights_key(p) for p in self.params}
@@ -309,7 +331,47 @@ class WinoRecords:
 
 def _wino_cached(w, flip):
     wr = getattr(w, "_favae_wino", None)
-    return wr.get(w, flip) if wr is not None else None
+    if wr is None:
+        return None
+    if flip & 2:
+        wr.want(w, flip)
+    return wr.get(w, flip)
+
+
+# Winograd F(4x4, 3x3) (csrc/conv_wino4.h): 0.56 x the matrix work of the F(2x2) kernel at ~6 x its rounding error (2.3e-6 rms of the output
+# range per conv).  FAVAE_WINO4: "0" never; "1" (default) data gradients only -- no codebook index depends on them and their parity bar is
+# 5e-3; "2" also the forward convs of modules that opted in (`wino4_forward(True)` around the call: the decoder, behind the quantizer).
+_WINO4 = os.environ.get("FAVAE_WINO4", "1")
+_WINO4_FWD = [False]
+
+
+class wino4_forward:
+    """context: forward convs launched inside may take the F(4x4, 3x3) kernel when FAVAE_WINO4=2 (never the encoder: indices)"""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = _WINO4_FWD[0]
+        _WINO4_FWD[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _WINO4_FWD[0] = self.prev
+        return False
+
+
+def set_wino4(mode):
+    """"0" / "1" / "2" (see FAVAE_WINO4); returns the previous mode"""
+    global _WINO4
+    prev, _WINO4 = _WINO4, str(mode)
+    return prev
+
+
+def _wino4_wanted(d, has_affine, dgrad):
+    if _WINO4 == "0" or not (dgrad or (_WINO4 == "2" and _WINO4_FWD[0])):
+        return False
+    return bool(query("favae_conv_wino4_ok", byref(d), 1 if has_affine else 0))
 
 
 def _fp16_planes():
@@ -325,6 +387,7 @@ def _fp16_planes():
 _WREC = {1: 8, 2: 16, 3: 24, 4: 8}    # bytes of one pre-split record (4 weights) per scheme id
 _WINO_FLIP_FWD = os.environ.get("FAVAE_WINO_FLIP_FWD", "1") != "0"
 PLANES_WINO = 0x100                   # include/favae_hip.h FAVAE_PLANES_WINO: the records are Winograd records (favae_wino_weights)
+PLANES_WINO4 = 0x200                  # ... F(4x4, 3x3) records (flip | 2): conv3x3_wino4_sp_kernel
 CONV_MODES = {"fp32": 0, "h1": 1, "h3": 2, "b6": 3, "b1": 4}
 
 
@@ -658,8 +721,9 @@ def _order_behind_deferred(tgt):
 
 
 def _wino_records(w, co, ci, flip, w_amax):
-    """Winograd weight records of the OHWI tensor w (csrc/conv_wino.h): flip = 0 forward conv, 1 its data gradient."""
-    wsp = torch.empty(query("favae_wino_weights_bytes", co, ci), dtype=torch.uint8, device=w.device)
+    """Winograd weight records of the OHWI tensor w (csrc/conv_wino.h): flip = 0 forward conv, 1 its data gradient; + 2: F(4x4, 3x3)
+    records (csrc/conv_wino4.h)."""
+    wsp = torch.empty(query("favae_wino4_weights_bytes" if flip & 2 else "favae_wino_weights_bytes", co, ci), dtype=torch.uint8, device=w.device)
     call("favae_wino_weights", ptr(w), ptr(wsp), co, ci, flip, ptr(w_amax))
     return wsp
 
@@ -677,20 +741,23 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
     if planes == 2 and planes_out is None and query("favae_conv_wino_ok", byref(d), 0 if scale is None else 1):
         # dense 3x3 conv of the h3 scheme: Winograd F(2x2, 3x3) kernel, records = G g G^T in fragment order (csrc/conv_wino.h)
         if wino_rec is not None:                 # made by the forward pass (FusedConvFn.forward)
-            wsp = wino_rec
+            wsp, f43 = wino_rec
         else:
             if flip_of is not None:
                 w, co, kh, kw, ci, w_amax = flip_of
                 flip = 1
             else:
                 w, co, ci, flip = w_ohwi, d.Cout, d.Cin, 0        # OHWI memory, whatever the logical shape
+            f43 = _wino4_wanted(d, scale is not None, flip == 1)
+            if f43:
+                flip |= 2
             wsp = _wino_cached(w, flip)              # made for the whole model after the optimizer step (WinoRecords)
             if wsp is None:
                 if w_amax is None:
                     w_amax = _weight_amax(w)
                 wsp = _wino_records(w, co, ci, flip, w_amax)
         w_amax = wsp[:4].view(torch.float32)
-        planes |= PLANES_WINO
+        planes |= PLANES_WINO | (PLANES_WINO4 if f43 else 0)
     if planes & PLANES_WINO:
         pass
     elif planes:
@@ -810,9 +877,12 @@ class FusedConvFn(torch.autograd.Function):
                 and any(ctx.needs_input_grad) and (ctx.needs_input_grad[0] or gn_w is not None)):   # no backward (no_grad, eval): no records
             d2 = make_conv_desc(N, Ho, Wo, Cout, Hin, Win, Cin, cfg.kh, cfg.kw, 1, cfg.kh - 1 - cfg.pad, GATHER_PLAIN, ACT_NONE, 1)
             if query("favae_conv_wants_split_weights", byref(d2), 0) == 2 and query("favae_conv_wino_ok", byref(d2), 0):
-                ctx.wflip = _wino_cached(wk, 1)
-                if ctx.wflip is None:
-                    ctx.wflip = _wino_records(wk, Cout, Cin, 1, w_amax)
+                f43 = _wino4_wanted(d2, False, True)
+                key = 3 if f43 else 1
+                rec = _wino_cached(wk, key)
+                if rec is None:
+                    rec = _wino_records(wk, Cout, Cin, key, w_amax)
+                ctx.wflip = (rec, f43)
         ctx.cfg = cfg
         ctx.has_b = b is not None
         ctx.has_gn = gn_w is not None

@@ -121,6 +121,18 @@ int favae_segment_absmax(const float* x, const int64_t* seg_off, int nseg, const
 int favae_conv_wino_ok(const favae_conv_desc* d, int has_affine);
 int favae_set_wino(int on);            /* run-time override of FAVAE_WINO; returns the previous setting */
 int favae_get_wino(void);              /* the current setting, no side effect */
+/* Winograd F(4x4, 3x3) (csrc/conv_wino4.h, ABI 18): 36 instead of 64 multiplies per 16 outputs -- 0.56 x the matrix work and operand
+ * splitting of the F(2x2) kernel, at 2.3e-6 rms (F(2x2): 3.6e-7) of the output range per conv.  Meant for results no codebook index
+ * depends on: the data gradients (autograd of models/codec.py:38-46) and, by the caller's choice, decoder layers.
+ * favae_conv_wino4_ok(d, has_affine) = 1 when d ALSO tiles into that kernel (favae_conv_wino_ok plus W % 32 == 0, Cin % 64 == 0); the
+ * caller may then pass records made by favae_wino_weights with bit 1 of `flip` set (flip = 2 forward, 3 data gradient;
+ * favae_wino4_weights_bytes(Cout, Cin) bytes; favae_wino_job.flip likewise) and planes = 2 | FAVAE_PLANES_WINO | FAVAE_PLANES_WINO4 to
+ * favae_conv_fwd_split / _stats / favae_conv_dgrad_gnbwd.  The tile grid of the partial sums stays the F(2x2) kernel's (16 x 16 pixels).
+ * FAVAE_WINO4=0 in the environment (favae_set_wino4(0)) makes favae_conv_wino4_ok return 0 for every shape. */
+#define FAVAE_PLANES_WINO4 0x200
+int favae_conv_wino4_ok(const favae_conv_desc* d, int has_affine);
+int favae_set_wino4(int on);           /* returns the previous setting */
+size_t favae_wino4_weights_bytes(int Cout, int Cin);
 /* Zero arena: the max|x| outputs of favae_absmax / favae_colsum / favae_conv_fwd_split_stats / favae_attn_bwd_point are atomicMax targets
  * that must start at zero; each call zeroes its own (one 4-byte memset launch) UNLESS the pointer lies inside [p, p + bytes), a range the
  * caller keeps zero for such targets (favae_step.TrainStep: one memset per step).  bytes = 0 removes the arena. */

@@ -366,6 +366,49 @@ def test_winograd_conv_shapes_against_direct_kernel(K, N, cin, cout, H, W):
             nm, float((u - v).abs().max()) / scale)
 
 
+def _wino4_run(K, fn, mode):
+    prev = K.set_wino4(mode)
+    try:
+        with K.wino4_forward(mode == "2"):
+            return fn()
+    finally:
+        K.set_wino4(prev)
+
+
+@pytest.mark.parametrize("N,cin,cout,H,W", [(1, 64, 64, 16, 32), (2, 128, 64, 32, 64), (1, 64, 192, 48, 32)])
+def test_winograd_f44_is_exact_on_integer_data(K, N, cin, cout, H, W):
+    """F(4x4, 3x3) kernel (csrc/conv_wino4.h) on data for which every intermediate is exactly representable: inputs in {-1, 0, 1},
+    weights 576 * {-1, 0, 1} (G g G^T is then integral: G has 1/4, 1/6, 1/12, 1/24), so the transforms, both fp16 planes, the fp32
+    accumulation and the output transform are exact and the result must EQUAL the direct convolution -- forward (with bias and residual)
+    and data gradient.  Any wrong position, plane, tile or channel mapping shows as a non-zero difference."""
+    import favae_hip as H_
+    d = dev()
+    g = torch.Generator().manual_seed(N * 100 + cin)
+    x = torch.randint(-1, 2, (N, cin, H, W), generator=g).float().to(d)
+    w = (576.0 * torch.randint(-1, 2, (cout, cin, 3, 3), generator=g).float()).to(d)
+    b = torch.randint(-3, 4, (cout,), generator=g).float().to(d)
+    res = torch.randint(-3, 4, (N, cout, H, W), generator=g).float().to(d)
+    gy = torch.randint(-1, 2, (N, cout, H, W), generator=g).float().to(d)
+    desc = H_.make_conv_desc(N, H, W, cin, H, W, cout, 3, 3, 1, 1, 0, 0, 1)
+    from ctypes import byref
+    if not H_.query("favae_conv_wino4_ok", byref(desc), 0):
+        pytest.skip("F(4x4, 3x3) path switched off")
+
+    def run():
+        xg = x.clone().requires_grad_(True)
+        y = K.fused_conv(xg, w, b, None, None, res, K.ConvCfg(3, 3, 1, 1))
+        dx, = torch.autograd.grad(y, (xg,), gy)
+        K.sync_side_stream()
+        torch.cuda.synchronize()
+        return y.detach(), dx
+    y4, dx4 = _wino4_run(K, run, "2")
+    xr, wr = x.cpu().double().requires_grad_(True), w.cpu().double()
+    yr = F.conv2d(xr, wr, b.cpu().double(), padding=1) + res.cpu().double()
+    dxr, = torch.autograd.grad(yr, (xr,), gy.cpu().double())
+    assert float((y4.cpu().double() - yr).abs().max()) == 0.0, "forward"
+    assert float((dx4.cpu().double() - dxr).abs().max()) == 0.0, "data gradient"
+
+
 @pytest.mark.parametrize("switch", ["FAVAE_CONV_HALO", "FAVAE_WINO"])
 def test_cout64_conv_without_the_winograd_kernel(switch):
     """with the A/B switch that takes the Winograd kernel away a 64 -> 64 3x3 conv (the VGG16 convs of LPIPS) must
