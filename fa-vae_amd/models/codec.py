@@ -336,6 +336,11 @@ class _DecoderFcmBase(nn.Module, _BlurMixin):
         return h, (None if self.RES_FCM else h)     # DecoderFcmResGauss appends None under inference (codec.py:973-1000)
 
     def forward(self, z, inference=False):
+        # behind the quantizer no codebook index depends on a conv: with FAVAE_WINO4=2 the 256^2 layers may take the F(4x4, 3x3) kernel
+        with K.wino4_forward(True):
+            return self._forward(z, inference)
+
+    def _forward(self, z, inference=False):
         feats = []
         conv_in = lambda t: K.fused_conv(t, self.conv_in.weight, self.conv_in.bias, cfg=_C3)
         z = K.as_cl(z)
