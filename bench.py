@@ -171,6 +171,8 @@ def parse():
     ap.add_argument("--codebook", type=int, default=None, help="codebook size (default: the config's)")
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-comm-diag", action="store_true",
+                    help="skip the untimed communication diagnostics of a distributed run (both gradient-exchange arms, 4 extra steps each)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra passes (single-stream rates, all-kernel table, with-LPIPS figure)")
     ap.add_argument("--gan", action="store_true",
@@ -451,6 +453,46 @@ def main():
         dt = max(float(v.item()) for v in allt)
     loss = float(out["loss_g"].reshape(-1)[0])
 
+    # ---- communication diagnostics (untimed; every rank; world > 1 or FAVAE_FORCE_DIST=1): BOTH arms of the gradient exchange on
+    # this object -- collectives queued behind backward (FAVAE_COMM_DEFER=1) and started where backward finishes each segment (=0) --
+    # with the per-segment overlap table of TrainStep.comm_report() and the two codebook all-reduces of the quantizer forward
+    # (models/l2_quantize.py:419,427; favae_scripts/train_favae.py:344-347).  Nobody on the builder's side sees the first N > 1 run:
+    # its line has to say where the communication time went and which arm is faster.
+    comm = None
+    if use_dist and ts.exchange is not None and not args.no_comm_diag:
+        cb = ts.model.quantizer._codebook
+        was_defer, was_timing = ts.exchange.defer, ts.exchange.timing
+        comm = {"default_arm": "defer" if was_defer else "eager", "steps_per_arm": 3, "arms": {}}
+        for arm, defer in (("defer", True), ("eager", False)):
+            ts.exchange.defer = defer
+            ts.exchange.set_timing(True)
+            ts.step(xs[0])                                  # warm-up of the arm
+            cb.comm_timing = []
+            sync()
+            t0 = time.perf_counter()
+            for i in range(3):
+                cb.comm_timing = []
+                ts.step(xs[i % 2])
+            sync()
+            t_arm = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_arm, op=dist.ReduceOp.MAX)
+            rep = ts.comm_report() or {"backward_ms": None, "segments": []}
+            comm["arms"][arm] = {
+                "ms_per_step": rnd(1e3 * float(t_arm.item()) / 3),
+                "backward_ms": rnd(rep["backward_ms"]) if rep["backward_ms"] is not None else None,
+                # per segment: [MB, start_ms, end_ms, overlapped_ms, exposed_ms] relative to the start of backward (rank 0, last step)
+                "segments": [[rnd(r["MB"], 4), rnd(r["start_ms"], 4), rnd(r["end_ms"], 4), rnd(r["overlapped_ms"], 4), rnd(r["exposed_ms"], 4)]
+                             for r in rep["segments"]],
+                "exposed_ms": rnd(sum(r["exposed_ms"] for r in rep["segments"]), 4),
+                # the two SUM all-reduces inside the quantizer forward: [MB, ms] each (cluster-size bins, embedding sums)
+                "codebook_allreduce": [[rnd(nb / 1e6, 4), rnd(e0.elapsed_time(e1), 4)] for nb, e0, e1 in (cb.comm_timing or [])[:2]],
+            }
+        cb.comm_timing = None
+        ts.exchange.defer = was_defer
+        ts.exchange.set_timing(was_timing)
+        a = comm["arms"]
+        comm["faster_arm"] = min(a, key=lambda k: a[k]["ms_per_step"])
+
     # ---- untimed extras (every rank: the steps contain collectives) ------------------------------------------------
     extras = {}
     if not args.no_extras:
@@ -539,6 +581,8 @@ def main():
             res["ms_per_step_single_stream"] = rnd(1e3 * extras["t_excl"] / 2)
         if "with_lpips" in extras:
             res["with_lpips"] = extras["with_lpips"]
+        if comm is not None:
+            res["comm"] = comm
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             print("[bench] GPU part done: %.2f images/s; timing the CPU baseline sample..." % res["value"], file=sys.stderr, flush=True)
             res["cpu_baseline"] = cpu_baseline(args, torch)

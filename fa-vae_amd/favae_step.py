@@ -97,6 +97,12 @@ class GradExchange:
         self.marks = []                         # (segment, start event, end event, bytes)
         self.watch = [torch.cuda.Stream() for _ in self.segments] if self.timing else None
 
+    def set_timing(self, on):
+        """switch the per-segment events on / off after construction (bench.py's comm diagnostics run both arms on one object)"""
+        self.timing = bool(on) and self.cuda
+        if self.timing and self.watch is None:
+            self.watch = [torch.cuda.Stream() for _ in self.segments]
+
     def reset(self):
         self.fired = [False] * len(self.segments)
         self.works = []

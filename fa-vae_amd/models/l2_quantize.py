@@ -45,9 +45,21 @@ class CosineSimCodebook(nn.Module):
         self.register_buffer("cluster_size", torch.zeros(num_codebooks, codebook_size))
         self.register_buffer("embed", l2norm(uniform_init(num_codebooks, codebook_size, dim)))
 
+    # comm_timing: when a list, every codebook all-reduce appends (bytes, start event, end event) -- bench.py's `comm` object and
+    # tests/dist_probe.py read them after a synchronize (what the first real multi-GPU run has to show: models/l2_quantize.py:419,427)
+    comm_timing = None
+
     def _all_reduce(self, t):
         if self.use_ddp:
-            distributed.all_reduce(t)
+            rec = self.comm_timing
+            if rec is not None and t.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                distributed.all_reduce(t)
+                e1.record()
+                rec.append((t.numel() * t.element_size(), e0, e1))
+            else:
+                distributed.all_reduce(t)
 
     @torch.no_grad()
     def forward(self, x):

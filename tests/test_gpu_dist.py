@@ -24,6 +24,20 @@ def test_bench_under_torchrun_rccl():
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["parallelism"] == "dp1"
     assert res["config"]["loss_g_last"] == res["config"]["loss_g_last"]          # not NaN
+    # a distributed bench line diagnoses itself -- both arms of the gradient exchange (collectives queued behind
+    # backward / started where backward finishes a segment) with the per-segment overlap table and the two codebook all-reduces
+    c = res["comm"]
+    assert c["default_arm"] in ("defer", "eager") and c["faster_arm"] in ("defer", "eager") and set(c["arms"]) == {"defer", "eager"}
+    for arm, a in c["arms"].items():
+        assert a["ms_per_step"] > 0 and a["backward_ms"] > 0, arm
+        assert len(a["segments"]) == 4 and all(len(r) == 5 for r in a["segments"]), a["segments"]
+        assert abs(sum(r[0] for r in a["segments"]) - 4e-6 * 82.7e6) < 0.05 * 4e-6 * 82.7e6, "the segments tile the 82.7 M-float gradient buffer"
+        assert len(a["codebook_allreduce"]) == 2 and all(len(r) == 2 and r[1] >= 0 for r in a["codebook_allreduce"])
+        assert abs(a["codebook_allreduce"][1][0] - 1024 * 256 * 4e-6) < 1e-3          # embedding sums: codebook 1024 x 256 floats
+        for mb, t0, t1, ov, ex in a["segments"]:
+            assert t1 >= t0 and ov >= 0 and ex >= -1e-3 and abs((t1 - t0) - (ov + ex)) < 1e-2
+    for mb, t0, t1, ov, ex in c["arms"]["defer"]["segments"]:
+        assert ov < 0.05, "deferred arm: nothing starts before backward has ended"
 
 
 def test_model_under_torch_ddp():
