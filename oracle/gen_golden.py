@@ -753,6 +753,35 @@ def gen_gan(tag="gan_128"):
     check(f"{tag}/bn_running_var", tr.P["discriminator.features.3.running_var"], model.discriminator.features[3].running_var,
           tol=bars["side"])
     out[p + "x_recon_d"] = npy(x_recon_d)
+    if tag == "cfg5_256":
+        # BASELINE configs[4] names bf16.  What the REFERENCE does in that mode (favae_scripts/train_favae.py:239-240: accelerate wraps the
+        # model forward in autocast and hands fp32 outputs to the losses), run here as torch.autocast("cpu", bfloat16) around encode /
+        # decode of an identically filled model: how many codebook indices flip against its own fp32 run, how far loss_l1 / loss_q / the
+        # reconstruction move.  The bar for the HIP bf16 mode: deviate no more than the reference itself does.
+        def enc_dec(auto):
+            m = VQGANFCM(**mk)
+            fill_module(m, "")
+            m.train()
+            with torch.no_grad():
+                if auto:
+                    with torch.autocast("cpu", dtype=torch.bfloat16):
+                        zq, lq, ind, _ = m.encode(x)
+                        xr, _ = m.decode(zq)
+                else:
+                    zq, lq, ind, _ = m.encode(x)
+                    xr, _ = m.decode(zq)
+            return ind, xr.float(), lq.float().reshape(-1)
+        i32, x32, q32 = enc_dec(False)
+        i16, x16, q16 = enc_dec(True)
+        assert torch.equal(i32.reshape(-1), ro["out"]["indices"].reshape(-1)), "fp32 encode() of the reference = the golden indices"
+        l32, l16 = (x - x32).abs().mean(), (x - x16).abs().mean()
+        out[p + "bf16ref.indices"] = npy(i16)
+        out[p + "bf16ref.flips"] = np.int64(int((i32 != i16).sum()))
+        out[p + "bf16ref.loss_l1_delta"] = np.float64(abs(float(l16 - l32)) / float(l32))
+        out[p + "bf16ref.loss_q_delta"] = np.float64(abs(float(q16[0] - q32[0])) / float(q32[0]))
+        out[p + "bf16ref.x_recon_rms_rel"] = np.float64(float(((x16 - x32).pow(2).mean() / x32.pow(2).mean()).sqrt()))
+        report.append((f"{tag}/reference bf16 autocast: index flips vs its fp32 run (count)", float(out[p + "bf16ref.flips"])))
+        report.append((f"{tag}/reference bf16 autocast: loss_l1 delta", float(out[p + "bf16ref.loss_l1_delta"])))
     for k, g in d_grads.items():
         if g.numel() <= 4096:
             out[p + "dgfull." + k] = npy(g)

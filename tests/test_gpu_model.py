@@ -595,6 +595,20 @@ def test_cfg5_256_b1_index_flips_and_loss_deltas(golden_dir):
     print("\ncfg5_256 closed-form codebook: index flips vs reference h3 %d / %d, b1 %d / %d (%.1f %%); b1 loss deltas vs reference %s"
           % (flips_h3, n, flips_b1, n, 100.0 * flips_b1 / n, {k: "%.2e" % v for k, v in d.items()}))
     assert flips_h3 == 0
+    # The reference-derived bar: the REFERENCE under torch.autocast("cpu", bfloat16) -- what its accelerate
+    # mixed-precision mode does to encode / decode (favae_scripts/train_favae.py:239-240), captured by oracle/gen_golden.py cfg5 --
+    # flips ref_flips of the 512 indices against its own fp32 run and moves loss_l1 / loss_q by the stored fractions.  The HIP bf16 mode
+    # (bf16 conv operands, fp32 activations and accumulation) must not deviate from the fp32 reference by more than that.
+    ref_flips = int(g[tag + ".bf16ref.flips"])
+    ref_dl1, ref_dq = float(g[tag + ".bf16ref.loss_l1_delta"]), float(g[tag + ".bf16ref.loss_q_delta"])
+    xr32 = a["x_recon"].float()
+    rms_b1 = float(((b["x_recon"] - xr32).pow(2).mean() / xr32.pow(2).mean()).sqrt())
+    print("reference under bf16 autocast: %d / %d flips, loss_l1 %.2e, loss_q %.2e, x_recon rms-rel %.2e | HIP b1: %d flips, loss_l1 %.2e, "
+          "loss_q %.2e, x_recon rms-rel %.2e" % (ref_flips, n, ref_dl1, ref_dq, float(g[tag + ".bf16ref.x_recon_rms_rel"]), flips_b1,
+                                                d["loss_l1"], d["loss_q"], rms_b1))
+    assert flips_b1 <= ref_flips, "b1 flips more codebook indices than the reference's own bf16 autocast run"
+    assert d["loss_l1"] <= max(ref_dl1, 1e-3) and d["loss_q"] <= max(2 * ref_dq, 1e-3)
+    assert rms_b1 <= float(g[tag + ".bf16ref.x_recon_rms_rel"])
     # trained-like codebook: l2-normalised encoder outputs (fp32-grade) of other images, one per code
     codes = []
     with torch.no_grad():
