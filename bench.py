@@ -46,7 +46,7 @@ MFMA_WALL_RANDOM_TFLOPS = 1400.0      # measured: register-resident v_mfma_f32_3
                                       # over 3 ms .. 1.5 s runs (tools/experiments/mfma_power.hip; 1.84-1.92 on zeros): what the matrix
                                       # pipe sustains on real data
 SPLIT_PRODUCTS = {0: None, 1: 1, 2: 3, 3: 6, 4: 1}   # 16-bit MFMA products per multiply-add by scheme id (conv_split.h): h1, h3, b6, b1
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")
 MAX_LINE_BYTES = 4096                 # the driver keeps an 8 KB tail of stdout: the JSON line must stay far below it
 NOTES = {
     "roofline": "dominant kernel of the timed region by total time among all matrix-bound launches (conv forward, data-gradient and "
@@ -56,8 +56,8 @@ NOTES = {
                 "on (MI355X_MICROARCH.md: 2500 TFLOP/s dense for v_mfma_f32_32x32x16_f16/bf16, 157.3 for the fp32 MFMA) and frac = "
                 "achieved / peak. The split-precision kernels spend `products_per_fma` 16-bit MFMA products per fp32 multiply-add "
                 "(planes=2: two scaled fp16 planes, 3 products; planes=3: 6; one plane: 1) and conv3x3_wino_sp_kernel (Winograd "
-                "F(2x2,3x3), csrc/conv_wino.h) executes 4/9 of the direct conv's multiplies: executed_gflop_per_launch = algorithmic x "
-                "products x (4/9 for Winograd) is the MFMA work really issued, frac_of_pipe_peak = executed / time / 2500. "
+                "F(2x2,3x3), csrc/conv_wino.h) executes 4/9 of the direct conv's multiplies, conv3x3_wino4_sp_kernel (F(4x4,3x3), "
+                "csrc/conv_wino4.h) 1/4: executed_gflop_per_launch = algorithmic x products x (4/9 | 1/4) is the MFMA work really issued, frac_of_pipe_peak = executed / time / 2500. "
                 "peak_fp32_equivalent = 2500 / products (833 for h3) and frac_fp32_equivalent = achieved / that: the fraction of what "
                 "a direct 3-product kernel could reach at best (a Winograd kernel may exceed its own share of it).",
     "single_stream": "*_single_stream: the same launches in 2 untimed steps with the weight-gradient stream off (exclusive durations)",
@@ -273,18 +273,20 @@ def kernel_planes(name):
             return int(args[1])
         if name.startswith("conv_fwd_sp_kernel") or name.startswith("conv_wgrad_sp_kernel"):
             return int(args[-1])
-        if name.startswith(("conv3x3_wino_sp_kernel", "conv3x3_winow_sp_kernel")):   # h3 only; priced on the direct conv's FLOPs (it executes 4/9 of the products)
-            return 2
+        if name.startswith(("conv3x3_wino_sp_kernel", "conv3x3_winow_sp_kernel", "conv3x3_wino4_sp_kernel")):
+            return 2          # h3 only; priced on the direct conv's FLOPs (F(2x2) executes 4/9 of the products, F(4x4) 1/4)
     except ValueError:
         pass
     return None
 
 
 def executed_factor(name, planes):
-    """MFMA FLOPs issued per algorithmic FLOP: 16-bit products per fp32 multiply-add x 4/9 for the Winograd F(2x2,3x3) kernels"""
+    """MFMA FLOPs issued per algorithmic FLOP: 16-bit products per fp32 multiply-add x 4/9 for the Winograd F(2x2,3x3) kernels, x 1/4 for F(4x4,3x3)"""
     f = float(SPLIT_PRODUCTS[planes]) if planes else 1.0
     if name.startswith(("conv3x3_wino_sp_kernel", "conv3x3_winow_sp_kernel")):
         f *= 4.0 / 9.0
+    if name.startswith("conv3x3_wino4_sp_kernel"):       # F(4x4, 3x3): 36 products per 16 outputs instead of 144
+        f *= 1.0 / 4.0
     return f
 
 
@@ -557,6 +559,10 @@ def main():
             full = roofline_entry(ranked[0][0], ranked[0][1], step_us, traffic, excl)
             full["profiled_steps"] = PROF_STEPS
             res["roofline"] = compact_roofline(full)
+            # where `traffic` comes from: NOT measured in this run (PMC passes cannot share a run with the timing) but read from the
+            # committed passes of the same build -- or null when that file belongs to another build of csrc/ 
+            res["roofline"]["traffic_source"] = ("%s (own --pmc passes, build %s)" % (traffic_meta["file"], traffic_meta["build"])
+                                                 if traffic_meta["status"] == "ok" else "none: %s is %s" % (traffic_meta["file"], traffic_meta["status"]))
             detail["roofline"] = full
             detail["roofline_others"] = [roofline_entry(kn, c, step_us, traffic, excl) for kn, c in ranked[1:]]
         if work is not None and not args.gan and not args.lpips:

@@ -177,7 +177,10 @@ __global__ __launch_bounds__(256) void thin_out_kernel(ThinArgs a) {
 #pragma unroll
     for (int co = 0; co < CT; ++co) bias[co] = (!WGRAD && a.bias) ? a.bias[co] : 0.f;
 
-    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    // Items = image rows (x blocks of a row): a row's neighbours y - 1, y + 1 are read again by the items above and below.  Consecutive
+    // block ids go to different XCDs (private L2s), so with item = blockIdx the 128-channel tensor came from HBM three times (traffic
+    // 3.1 x); with the XCD-contiguous remap the three readers of a row share one L2 at nearly the same time.
+    for (int item = xcd_remap(blockIdx.x, gridDim.x); item < items; item += gridDim.x) {
     int b = item;
     const int xs = (b % xblocks) * a.xb + pl * seg; b /= xblocks;
     const int y = b % a.H;

@@ -41,6 +41,15 @@ def test_winograd_kernel_is_priced_on_executed_flops():
     assert abs(e["frac_of_pipe_peak"] - 0.150) < 1e-3 and abs(e["frac_fp32_equivalent"] - 0.337) < 1e-3
 
 
+def test_f44_winograd_kernel_is_priced_on_executed_flops():
+    """round 5: the F(4x4, 3x3) kernel executes 36 of the direct conv's 144 products per 16 outputs, x 3 split products: executed =
+    algorithmic x 3 / 4, against the same 2.5 PFLOP/s pipe (it once showed up at frac 1.64 of the fp32-MFMA peak: no planes matched)."""
+    name = "conv3x3_wino4_sp_kernel<0, true, false>"
+    e = bench.compact_roofline(bench.roofline_entry(name, _rec(42, 1018.0, 618.5, 2.7), 2 * 135000.0, {}, None))
+    assert e["peak"] == 2500.0 and abs(e["frac"] - 618.5e9 / 1018e-6 * 1e-12 / 2500.0) < 1e-4 and e["frac"] < 0.5
+    assert abs(e["executed_gflop_per_launch"] - 618.5 * 3 / 4) < 0.01 and abs(e["frac_of_pipe_peak"] - 0.75 * e["frac"]) < 1e-4
+
+
 def test_no_matrix_kernel_is_priced_above_its_pipe():
     """The h3 kernels without a scheme template argument (codebook scores, SDPA batched GEMM) run on the 16-bit pipe with 3 products per
     multiply-add: priced against 2500, not against the fp32-MFMA 157.3 (the round-4 table once showed the VQ product at frac 1.52)."""

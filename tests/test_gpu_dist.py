@@ -152,7 +152,7 @@ def test_bench_line_schema():
     assert "workload" in res["config"] and "model" not in res["config"]
     assert abs(res["value"] - 2 * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]
     r = res["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "algorithmic_bytes_per_launch"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "avg_launch_us", "algorithmic_bytes_per_launch"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 * r["frac"]
     # checkable against the guide: peak is the hardware peak of the pipe, the executed MFMA work is priced next to the algorithmic one
