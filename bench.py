@@ -382,6 +382,10 @@ def main():
     # FAVAE_FORCE_DIST=1 exercises the multi-GPU code path (RCCL process group, codebook + gradient all-reduce) at any
     # world size, including 1 (used by tests/test_gpu_dist.py on the single-GPU box)
     use_dist = world > 1 or os.environ.get("FAVAE_FORCE_DIST") == "1"
+    # before the first HIP call of the process: 8 hardware queues instead of 4 (streams sharing a queue serialise; with the RCCL process
+    # group's streams in the process the weight-gradient stream otherwise lands on the compute stream's queue: +8.6 % step time at every
+    # N >= 2, measured at world 1 -- fa-vae_amd/favae_hip/ops.py _side_stream, profiles/r05_dist_overhead.txt)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -405,15 +409,20 @@ def main():
     torch.manual_seed(0)                           # favae_scripts/train_favae.py:235 (ranks are synchronised by TrainStep's broadcast)
     desc, _, n_embed, mk, _, _, work = CONFIGS[args.config]
 
+    # FAVAE_DIST_DEBUG (experiments only): "pg_only" = process group initialised, model / TrainStep as without one; "no_codebook" =
+    # distributed TrainStep without the quantizer's codebook all-reduces
+    dbg = os.environ.get("FAVAE_DIST_DEBUG", "")
+
     def build(with_lpips):
-        model = VQGANFCM(args.codebook, n_embed, use_cosine_sim=True, use_l2_quantizer=True, sync_codebook=use_dist,
+        model = VQGANFCM(args.codebook, n_embed, use_cosine_sim=True, use_l2_quantizer=True,
+                         sync_codebook=use_dist and dbg not in ("pg_only", "no_codebook"),
                          commitment_weight=1.0, kernel_size=9, dsl_init_sigma=3.0, device=dev, **mk).to(dev)
         lpips = None
         if with_lpips:
             from losses.lpips import LPIPS
             lpips = LPIPS(pretrained=False).to(dev).eval()        # random-init VGG16 / lin weights; .eval(): train_favae.py:308
         lr = 4.5e-6 * args.batch * world               # train_favae.py:250-251
-        return TrainStep(model, lr=lr, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, distributed=use_dist,
+        return TrainStep(model, lr=lr, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, distributed=use_dist and dbg != "pg_only",
                          train_disc=args.gan, lpips=lpips, perceptual_weight=1.0)
     ts = build(args.lpips)
     exchange_desc = (("RCCL all-reduce, %d segments " % len(ts.exchange.segments)) +

@@ -12,6 +12,13 @@ from ctypes import POINTER, Structure, byref, c_float, c_int, c_int32, c_int64, 
 
 import torch
 
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order; streams that share a queue serialise.  This
+# package runs the weight gradients on a second stream, and with an RCCL process group in the process (more streams) that stream ended up
+# on the compute stream's queue: 8.6 % of the step at world 1 (ops._side_stream).  Ask for 8 queues while the runtime has not read the
+# variable yet; ops._side_stream() additionally probes for a stream that really overlaps.
+if "GPU_MAX_HW_QUEUES" not in os.environ and not torch.cuda.is_initialized():
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FAVAE_HIP_LIB") or os.path.join(_HERE, "libfavae_hip.so")     # FAVAE_HIP_LIB: same-box A/B of two builds
 ABI_VERSION = 18

@@ -493,10 +493,39 @@ _FLUSH_EVERY = int(os.environ.get("FAVAE_FLUSH_EVERY", "12"))
 _SERIALIZE_MFMA = os.environ.get("FAVAE_SERIALIZE_MFMA", "0") == "1"
 
 
+def streams_overlap(a, b, cycles=4_000_000):
+    """diagnostic: do two HIP streams run a spin kernel each concurrently (torch.cuda._sleep, timed against one alone)?  NOT a test for
+    the queue oversubscription described at _side_stream(): there every pair of streams still passes this probe."""
+    ea0, ea1, eb0, eb1 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        ea0.record(a)
+        torch.cuda._sleep(cycles)
+        ea1.record(a)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        eb0.record(a)
+        torch.cuda._sleep(cycles)
+    with torch.cuda.stream(b):
+        torch.cuda._sleep(cycles)
+    a.wait_stream(b)
+    with torch.cuda.stream(a):
+        eb1.record(a)
+    torch.cuda.synchronize()
+    return eb0.elapsed_time(eb1) < 1.5 * ea0.elapsed_time(ea1)
+
+
 def _side_stream():
     if _SIDE["stream"] is None:
         # FAVAE_SIDE_PRIORITY (A/B switch): HIP priority of the weight-gradient stream (torch: lower number = higher priority, clamped
-        # to the device's range); default = the normal priority the main stream has
+        # to the device's range); default = the normal priority the main stream has.
+        # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default).  With an RCCL process group in the process
+        # (its internal streams + the communication stream) the step's two compute streams lost ALL of their overlap -- the in-step
+        # kernel times equal the single-stream ones, 134.2 -> 145.8 ms per step at world 1, i.e. at every N >= 2 -- although any two
+        # streams still run a pair of spin kernels concurrently (streams_overlap above: the cross-stream event waits of every
+        # weight-gradient launch are what serialises on an oversubscribed queue).  8 queues remove it (134.7 ms with the full
+        # distributed path): favae_hip/__init__.py and bench.py ask for them before HIP is initialised; a process that initialised HIP
+        # earlier with the default gets a warning from TrainStep (profiles/r05_dist_overhead.txt, tools/experiments/r05/dist_overhead*.sh).
         _SIDE["stream"] = torch.cuda.Stream(priority=int(os.environ.get("FAVAE_SIDE_PRIORITY", "0")))
     return _SIDE["stream"]
 

@@ -140,3 +140,19 @@ def test_cout64_wants_split_weights_exactly_when_the_winograd_kernel_takes_it():
             else:
                 assert wants == 0, line                 # 1024 input channels with a fused affine: beyond the LDS staging of (scale, shift)
     assert seen_on == 3 and seen_off == 8
+
+
+def test_package_asks_for_eight_hardware_queues_before_hip_is_initialised():
+    """Round 5 finding (profiles/r05_dist_overhead.txt): with HIP's default of 4 hardware queues an initialised RCCL process group takes
+    the overlap of the weight-gradient stream away (+8.6 % step time at every N >= 2).  Importing favae_hip before the first HIP call
+    exports GPU_MAX_HW_QUEUES=8 (an explicit setting of the user is kept); bench.py does the same at the top of main()."""
+    import subprocess
+    import sys
+    code = "import os, sys; sys.path.insert(0, %r); import favae_hip; print(os.environ.get('GPU_MAX_HW_QUEUES'))" % os.path.join(ROOT, "fa-vae_amd")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "8", out.stdout + out.stderr[-1000:]
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="16"), capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip() == "16"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index('os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")') < src.index('dist.init_process_group("nccl"')
