@@ -488,6 +488,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
 
     double gs1 = 0.0, gs2 = 0.0;
     float se_amax = 0.f;
+    const bool gb_pm = GB && (a.gb_act & FAVAE_GB_PREMUL) != 0;
     const float* tr = Ts + lane * TPITCH + wid * 8;
     float tv[2][4][8];                              // [i][b][tile of the row]
 #pragma unroll
@@ -513,11 +514,15 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float y = fmaf(v[i][j], un, bv);
-                if constexpr (!GB) y += pre[q][i][j];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), ry, vcol, pix_off(q, i, j), 0);
+                if constexpr (!GB) {
+                    y += pre[q][i][j];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), ry, vcol, pix_off(q, i, j), 0);
+                }
                 if constexpr (GB) {
                     const float xh = (pre[q][i][j] - g_mu) * g_rs;
-                    const float dyv = y * favae_act_grad(fmaf(xh, g_ga, g_be), a.gb_act);
+                    const float dyv = y * favae_act_grad(fmaf(xh, g_ga, g_be), a.gb_act & 0xff);
+                    // FAVAE_GB_PREMUL: the tensor written is da * act'(y) -- what the GroupNorm-backward apply pass would recompute
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gb_pm ? dyv : y), ry, vcol, pix_off(q, i, j), 0);
                     f1 += dyv;
                     f2 = fmaf(dyv, xh, f2);
                 }

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
             const float ga = gamma[c], be = beta[c];
             const float xh = (xv[e] - mu) * rs;
             const float y = fmaf(xh, ga, be);
-            const float dy = dv[e] * act_grad(y, act);
+            const float dy = (act & FAVAE_GB_PREMUL) ? dv[e] : dv[e] * act_grad(y, act);
             float o = rs * (dy * ga - k1[n * G + g] - xh * k2[n * G + g]);
             if (dx_add) o += av[e];
             ov[e] = o;
@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 // CS: the pass also emits, for the tensor dx it writes, the per-block column sums cs_part[block][C] (block = blockIdx.y * gridDim.x
 // + blockIdx.x) and max |dx| -- dx is the `dy` of the conv in front of this GroupNorm, whose bias gradient and fp16 operand
 // range are exactly these two (favae_colsum read the tensor once more for them).
-template <bool SKIP, bool CS>
+// PM: `da` already is dy = da * act'(y) (FAVAE_GB_PREMUL: written by the data-gradient conv's epilogue, which needs it for the sums anyway)
+template <bool SKIP, bool CS, bool PM = false>
 __global__ __launch_bounds__(256, 5) void gn_bwd_apply_rows_kernel(const float* __restrict__ da, const float* __restrict__ x,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -360,8 +361,8 @@ __global__ __launch_bounds__(256, 5) void gn_bwd_apply_rows_kernel(const float* 
             // explicit fused multiply-adds: every instantiation rounds the same way (left to the compiler, the contraction of
             // rs (dy ga - k1 - xh k2) changed with the code around it)
             const float xh = (xv[e] - mu[e]) * rs[e];
-            const float y = fmaf(xh, ga[e], be[e]);
-            const float dy = dv[e] * act_grad(y, act);
+            float dy = dv[e];
+            if constexpr (!PM) dy = dv[e] * act_grad(fmaf(xh, ga[e], be[e]), act);
             const float t = fmaf(-xh, rk2[e], fmaf(dy, ga[e], -rk1[e]));
             ov[e] = SKIP ? fmaf(rs[e], t, av[e]) : rs[e] * t;
         }
@@ -566,6 +567,8 @@ static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, 
                            favae_stream_t stream, float* cs_part, float* cs_amax) {
     FAVAE_REQUIRE(da && x && gamma && beta && mean && rstd && dx && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
     FAVAE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr));
+    const bool pm = (act & FAVAE_GB_PREMUL) != 0;     // `da` is dy = da * act'(y): only the conv epilogue that made the sums can have written it
+    FAVAE_REQUIRE(!pm || tile_partials > 0);
     if (ws_bytes < (tile_partials ? favae_gn_bwd_tiles_workspace(N, tile_partials, C) : favae_gn_workspace(N, HW, C)))
         return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     hipStream_t s = (hipStream_t)stream;
@@ -593,8 +596,12 @@ static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, 
         const long rpb = (HW + S - 1) / S;
         const dim3 grid((unsigned)S, N);
 #define FAVAE_LAUNCH_APPLY(SK, CS)                                                                                             \
-    FAVAE_KLAUNCH((gn_bwd_apply_rows_kernel<SK, CS>), grid, dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2, dx_add, dx, \
-                  (long)HW, C, G, act, rpb, cs_part, (unsigned*)cs_amax)
+    do {                                                                                                                       \
+        if (pm) FAVAE_KLAUNCH((gn_bwd_apply_rows_kernel<SK, CS, true>), grid, dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2, \
+                              dx_add, dx, (long)HW, C, G, act & 0xff, rpb, cs_part, (unsigned*)cs_amax);                       \
+        else FAVAE_KLAUNCH((gn_bwd_apply_rows_kernel<SK, CS>), grid, dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2, dx_add, \
+                           dx, (long)HW, C, G, act, rpb, cs_part, (unsigned*)cs_amax);                                         \
+    } while (0)
         if (dx_add && cs_part) FAVAE_LAUNCH_APPLY(true, true);
         else if (dx_add) FAVAE_LAUNCH_APPLY(true, false);
         else if (cs_part) FAVAE_LAUNCH_APPLY(false, true);

@@ -391,6 +391,13 @@ _WREC = {1: 8, 2: 16, 3: 24, 4: 8}    # bytes of one pre-split record (4 weights
 _WINO_FLIP_FWD = os.environ.get("FAVAE_WINO_FLIP_FWD", "1") != "0"
 PLANES_WINO = 0x100                   # include/favae_hip.h FAVAE_PLANES_WINO: the records are Winograd records (favae_wino_weights)
 PLANES_WINO4 = 0x200                  # ... F(4x4, 3x3) records (flip | 2): conv3x3_wino4_sp_kernel
+GB_PREMUL = 0x100                     # include/favae_hip.h FAVAE_GB_PREMUL (flag on `act` of favae_conv_dgrad_gnbwd / favae_gn_act_bwd_*)
+# FAVAE_GB_PREMUL=1 (A/B arm, bit-identical results; default off): the apply pass gets 25 % lighter -- 14.4 -> 13.6 ms exclusive, the
+# single-stream step 155.5 -> 154.4 ms -- and the two-stream step 0.4-0.9 ms SLOWER (134.3 / 134.5 / 134.8 / 135.4 against 135.3 / 135.3 /
+# 135.3 / 135.8, four same-box pairs): the main queue reaches the next data gradient sooner, which then shares the CUs with the weight
+# gradient still running on the second stream for longer (in-step data gradient 42.8 -> 45.0 ms, weight gradient 36.8 -> 37.9).  The
+# HBM-bound pass was hiding in the shadow of the matrix kernels; making it faster moves matrix work into matrix work.
+_GB_PREMUL = os.environ.get("FAVAE_GB_PREMUL", "0") == "1"
 CONV_MODES = {"fp32": 0, "h1": 1, "h3": 2, "b6": 3, "b1": 4}
 
 
@@ -1026,7 +1033,7 @@ class FusedConvFn(torch.autograd.Function):
             else:
                 raise RuntimeError("unsupported conv geometry for the data gradient")
             dys = None
-            gn_tiles, gn_ws = 0, None
+            gn_tiles, gn_ws, act_gn = 0, None, act
             if not phased:
                 da = new_cl(N, Cin, Hv, Wv, dev)
                 d2 = make_conv_desc(N, Ho, Wo, Cout, Hv, Wv, Cin, cfg.kh, cfg.kw, 1, pad2, g2, ACT_NONE, 1)
@@ -1038,7 +1045,10 @@ class FusedConvFn(torch.autograd.Function):
                     gn_tiles = query("favae_conv_gnbwd_tiles", byref(d2))
                     if gn_tiles:
                         gn_ws = workspace(query("favae_gn_bwd_tiles_workspace", N, gn_tiles, Cin), dev)
-                        gnb = (x, mean, rstd, gn_w, gn_b, cfg.groups, act, gn_ws)
+                        # FAVAE_GB_PREMUL: the epilogue writes dy = da * act'(y) (it has it in registers for the sums) and the apply
+                        # pass below takes it as such -- no second transcendental per element in the HBM-bound pass
+                        act_gn = act | GB_PREMUL if _GB_PREMUL else act
+                        gnb = (x, mean, rstd, gn_w, gn_b, cfg.groups, act_gn, gn_ws)
                 if _SERIALIZE_MFMA and gn_tiles and _SIDE["used"]:
                     # experiment: the dense data gradient starts only after the weight gradient of the layer behind it has retired
                     torch.cuda.current_stream().wait_stream(_SIDE["stream"])
@@ -1065,16 +1075,17 @@ class FusedConvFn(torch.autograd.Function):
                 cs_blocks = query("favae_gn_bwd_colsum_blocks", gN, gHW, Cin) if _DYCS_FUSE else 0
                 if not gn_tiles:
                     gn_ws = workspace(query("favae_gn_workspace", gN, gHW, Cin), dev)
+                act_ap = act_gn if gn_tiles else act          # flagged only when the epilogue really wrote the pre-multiplied tensor
                 if cs_blocks:                                 # the apply pass also leaves colsum / max|dx| for the conv in front
                     cs_part = torch.empty((cs_blocks * Cin,), dtype=torch.float32, device=dev)
                     cs_amax = torch.empty((1,), dtype=torch.float32, device=dev)
-                    call("favae_gn_act_bwd_colsum", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin, gG, act,
+                    call("favae_gn_act_bwd_colsum", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin, gG, act_ap,
                          ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0, gn_tiles,
                          ptr(gn_ws), gn_ws.numel(), ptr(cs_part), ptr(cs_amax))
                     dx._favae_dycs = (cs_part, cs_blocks, cs_amax, dx._version, _ARENA["epoch"])
                 elif gn_tiles:                                # pass 1 came out of the data-gradient conv's epilogue
                     call("favae_gn_act_bwd_tiles", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin,
-                         gG, act, ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,
+                         gG, act_ap, ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,
                          gn_tiles, ptr(gn_ws), gn_ws.numel())
                 else:
                     call("favae_gn_act_bwd", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin,
