@@ -22,10 +22,18 @@ d2 = H.make_conv_desc(B, hw, hw, cout, hw, hw, cin, k, k, 1, k // 2, 0, 0, 1)
 dx = K.new_cl(B, cin, hw, hw, dev)
 dw = torch.empty(cout, k, k, cin, device=dev)
 ws = H.workspace(H.query("favae_conv_wgrad_workspace", byref(d)), dev)
+# CONV_ONE_F44=1: the forward and the data gradient (launched as a forward conv on the flipped weights) on the F(4x4, 3x3) kernel too
+f44 = os.environ.get("CONV_ONE_F44") == "1"
 K._conv_launch(d, x, w, b, None, scale, shift, y, xb)
 yb = K.absmax(y)
 for _ in range(3):
     K._conv_launch(d, x, w, b, None, scale, shift, y, xb)
     K._conv_launch(d2, y, wt, None, None, None, None, dx, yb)
+    if f44:
+        prev = K.set_wino4("2")
+        with K.wino4_forward(True):
+            K._conv_launch(d, x, w, b, None, scale, shift, y, xb)
+            K._conv_launch(d2, y, wt, None, None, None, None, dx, yb)
+        K.set_wino4(prev)
     H.call("favae_conv_wgrad", byref(d), H.ptr(x), H.ptr(y), H.ptr(scale), H.ptr(shift), H.ptr(xb), H.ptr(yb), H.ptr(dw), 0, H.ptr(ws), ws.numel())
 torch.cuda.synchronize()

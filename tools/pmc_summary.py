@@ -9,7 +9,7 @@ import re
 import sys
 
 csv.field_size_limit(1 << 30)
-KEEP = ("conv3x3_halo_sp_kernel", "conv3x3_wino_sp_kernel", "conv3x3_winow_sp_kernel", "conv_wgrad_nine_sp_kernel", "conv_wgrad_row3_sp_kernel", "conv_fwd_sp_kernel", "conv_wgrad_sp_kernel")
+KEEP = ("conv3x3_halo_sp_kernel", "conv3x3_wino_sp_kernel", "conv3x3_wino4_sp_kernel", "conv3x3_winow_sp_kernel", "conv_wgrad_nine_sp_kernel", "conv_wgrad_row3_sp_kernel", "conv_fwd_sp_kernel", "conv_wgrad_sp_kernel")
 
 
 def short(name):
