@@ -455,6 +455,21 @@ def zero_arena_off():
     query("favae_set_zero_arena", None, 0)
 
 
+def _in_arena(t):
+    """does tensor t (a float32[1] operand range) live in the zero arena?"""
+    b = _ARENA["buf"]
+    return t is not None and b is not None and b.data_ptr() <= t.data_ptr() < b.data_ptr() + b.numel() * 4
+
+
+def _check_arena_epoch(ctx, *ranges):
+    """an operand range saved for backward may be an arena slot, which TrainStep.step() / zero_arena_reset() zeroes and hands
+    out again.  A graph built before such a reset and back-propagated after it (retained graph, a forward outside step(), two TrainSteps
+    interleaved) would scale its fp16 planes with max|x| = 0 or a stranger's value, silently.  Fail loudly instead."""
+    if getattr(ctx, "arena_epoch", None) != _ARENA["epoch"] and any(_in_arena(r) for r in ranges):
+        raise RuntimeError("favae_hip: this graph was built before the last zero_arena_reset() (TrainStep.step() starts with one); "
+                           "operand ranges it saved in the zero arena are gone -- run forward and backward inside the same step")
+
+
 def _max_target(dev):
     """a float32[1] that is zero in stream order when the kernel that atomicMax'es into it runs: the next arena slot, else a fresh tensor
     (which the library memsets)"""
@@ -923,6 +938,7 @@ class FusedConvFn(torch.autograd.Function):
                     rec = _wino_records(wk, Cout, Cin, key, w_amax)
                 ctx.wflip = (rec, f43)
         ctx.cfg = cfg
+        ctx.arena_epoch = _ARENA["epoch"]
         ctx.has_b = b is not None
         ctx.has_gn = gn_w is not None
         ctx.has_xform = scale is not None
@@ -938,6 +954,7 @@ class FusedConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dskip=None):
         x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb, w_amax, xs = ctx.saved_tensors
+        _check_arena_epoch(ctx, xb)
         if dskip is not None:
             dskip = to_cl(dskip)
         cfg = ctx.cfg

@@ -875,3 +875,23 @@ def test_train_step_with_fixed_sigma_spectrum_loss():
             continue
         worst = max(worst, rel(named[k].grad, go))
     assert worst < 2e-3, f"gradients with the SL term: worst per-tensor max-rel {worst:.3e}"
+
+
+def test_backward_across_an_arena_reset_fails_loudly():
+    """a graph built before TrainStep.step() / zero_arena_reset() and back-propagated after it would read recycled
+    operand-range slots (max|x| = 0 or another tensor's) without any error: it must raise instead."""
+    from favae_hip import ops as K
+    from favae_step import TrainStep
+    model, _, _ = build("cfg1_k3")
+    ts = TrainStep(model, lr=1e-4)
+    x = O.det_input(1, 64, 64, 3).to(DEV)
+    ts.step(x)                                            # arms the arena
+    model.train()
+    out = ts.losses(x)                                    # graph built in epoch e
+    K.zero_arena_reset(DEV)                               # what the next step() would do first
+    with pytest.raises(RuntimeError, match="zero_arena_reset"):
+        out["loss_g"].sum().backward()
+    torch.cuda.synchronize()
+    K.reset_side_state()
+    ts.step(x)                                            # and the object still trains afterwards
+    torch.cuda.synchronize()
