@@ -476,17 +476,23 @@ def main():
         comm = {"default_arm": "defer" if was_defer else "eager", "steps_per_arm": 3, "arms": {}}
         for arm, defer in (("defer", True), ("eager", False)):
             ts.exchange.defer = defer
-            ts.exchange.set_timing(True)
-            ts.step(xs[0])                                  # warm-up of the arm
-            cb.comm_timing = []
+            # (i) the arm's step time WITHOUT any instrumentation: 1 warm-up + 3 steps between barrier + synchronize pairs, max over ranks
+            ts.exchange.set_timing(False)
+            cb.comm_timing = None
+            ts.step(xs[0])
             sync()
             t0 = time.perf_counter()
             for i in range(3):
-                cb.comm_timing = []
                 ts.step(xs[i % 2])
             sync()
             t_arm = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
             dist.all_reduce(t_arm, op=dist.ReduceOp.MAX)
+            # (ii) two more steps with the events on: the table of the last one (rank 0)
+            ts.exchange.set_timing(True)
+            for i in range(2):
+                cb.comm_timing = []
+                ts.step(xs[i % 2])
+            sync()
             rep = ts.comm_report() or {"backward_ms": None, "segments": []}
             comm["arms"][arm] = {
                 "ms_per_step": rnd(1e3 * float(t_arm.item()) / 3),

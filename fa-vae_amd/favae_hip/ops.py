@@ -464,7 +464,9 @@ def _in_arena(t):
 def _check_arena_epoch(ctx, *ranges):
     """an operand range saved for backward may be an arena slot, which TrainStep.step() / zero_arena_reset() zeroes and hands
     out again.  A graph built before such a reset and back-propagated after it (retained graph, a forward outside step(), two TrainSteps
-    interleaved) would scale its fp16 planes with max|x| = 0 or a stranger's value, silently.  Fail loudly instead."""
+    interleaved) would scale its fp16 planes with max|x| = 0 or a stranger's value, silently.  Fail loudly instead.  (Slots that went
+    through ctx.save_for_backward are also caught by autograd itself: they are views of the arena buffer, whose in-place zero_() bumps
+    the version counter -- "modified by an inplace operation"; tests/test_gpu_model.py::test_backward_across_an_arena_reset_fails_loudly.)"""
     if getattr(ctx, "arena_epoch", None) != _ARENA["epoch"] and any(_in_arena(r) for r in ranges):
         raise RuntimeError("favae_hip: this graph was built before the last zero_arena_reset() (TrainStep.step() starts with one); "
                            "operand ranges it saved in the zero arena are gone -- run forward and backward inside the same step")

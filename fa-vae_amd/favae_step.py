@@ -95,13 +95,11 @@ class GradExchange:
         self.fired = [False] * len(self.segments)
         self.works = []
         self.marks = []                         # (segment, start event, end event, bytes)
-        self.watch = [torch.cuda.Stream() for _ in self.segments] if self.timing else None
+        self.watch = None                       # (round 4: one watcher stream per segment; see _launch)
 
     def set_timing(self, on):
         """switch the per-segment events on / off after construction (bench.py's comm diagnostics run both arms on one object)"""
         self.timing = bool(on) and self.cuda
-        if self.timing and self.watch is None:
-            self.watch = [torch.cuda.Stream() for _ in self.segments]
 
     def reset(self):
         self.fired = [False] * len(self.segments)
@@ -123,14 +121,16 @@ class GradExchange:
                     ev0 = torch.cuda.Event(enable_timing=True)
                     ev0.record(self.comm)
                 ws = [dist.all_reduce(self.gflat[a:b], async_op=True) for a, b in self.segments[i]]
-            self.works += ws
-            if self.timing:
-                with torch.cuda.stream(self.watch[i]):
+                if self.timing:
+                    # end of the segment: the COMMUNICATION stream waits for the collective (it would only queue the next segment's
+                    # collective behind it anyway) and takes the time stamp.  Round 4 waited on a watcher stream per segment: that
+                    # block alone cost 30 ms per step (132 -> 165, bisected in tools/experiments/r05/comm_timing_cost2.sh)
                     for w in ws:
-                        w.wait()                      # this stream (only) waits for the collective
+                        w.wait()
                     ev1 = torch.cuda.Event(enable_timing=True)
-                    ev1.record(self.watch[i])
-                self.marks.append((i, ev0, ev1, nbytes))
+                    ev1.record(self.comm)
+                    self.marks.append((i, ev0, ev1, nbytes))
+            self.works += ws
         else:
             for a, b in self.segments[i]:
                 self.works.append(dist.all_reduce(self.gflat[a:b], async_op=True))
