@@ -16,5 +16,5 @@ FAVAE_BENCH_DETAIL=$O/bench_detail.json timeout 900 python bench.py --steps 20 -
 FAVAE_BENCH_DETAIL=$O/bench_default_detail.json timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-300 $O/bench_default.json
 bash tools/r05_run.sh $TAG configs
 timeout 600 python bench.py --no-cpu-baseline --no-extras --precision bf16 > $O/bench_bf16.json 2>/dev/null; cut -c1-160 $O/bench_bf16.json
-FAVAE_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline --no-extras --steps 4 > $O/bench_dist_world1.json 2>/dev/null; python -c "import json;print(json.dumps(json.load(open('$O/bench_dist_world1.json'))['comm']))"
+FAVAE_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline --no-extras --steps 4 > $O/bench_dist_world1.json 2>/dev/null; python -c "import json;print(json.dumps(json.loads(open('$O/bench_dist_world1.json').read().splitlines()[0])['comm']))"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
