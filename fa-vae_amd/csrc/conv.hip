@@ -1019,6 +1019,23 @@ static bool wino_ok(const favae_conv_desc* d, bool has_affine) {
            (size_t)d->Cout * d->Cin * 64 < (1u << 31) && (!has_affine || d->Cin <= wino::AFF_C);
 }
 
+// 16 x 8-pixel x 128-channel tiling of the same kernel (conv_wino.h, WIDE): every F(2x2) launch whose output channels tile by 128.
+// FAVAE_WINO_WIDE=0 / favae_set_wino_wide(0): the 16 x 16 x 64 tiling everywhere (A/B; the results are bit-identical, the per-tile
+// partial sums of the statistics epilogues are on a finer grid).
+int g_wino_wide = -1;
+static bool use_wino_wide() {
+    if (g_wino_wide < 0) { const char* e = getenv("FAVAE_WINO_WIDE"); g_wino_wide = (e && e[0] == '0') ? 0 : 1; }
+    return g_wino_wide == 1;
+}
+static bool wino_wide_ok(const favae_conv_desc* d, bool has_affine) {
+    return use_wino_wide() && wino_ok(d, has_affine) && d->Cout % 128 == 0;
+}
+extern "C" int favae_set_wino_wide(int on) {
+    const int prev = use_wino_wide() ? 1 : 0;
+    g_wino_wide = on ? 1 : 0;
+    return prev;
+}
+
 // F(4x4, 3x3) variant (conv_wino4.h): 32 x 16-pixel tiles, K loop unrolled by four chunks, records of 144 bytes per (co, ci) pair.  The
 // geometry check only: WHERE it is used (data gradients; decoder layers) is the caller's policy (ops.py, FAVAE_WINO4) because the
 // accuracy bar depends on what consumes the result.  FAVAE_WINO4=0 in the environment: never.
@@ -1139,18 +1156,24 @@ extern "C" int favae_conv_fwd_split_planes(const favae_conv_desc* d, const float
 // Data gradient of a conv whose INPUT was act(GroupNorm(x)): da = conv(dy, flipped w) as favae_conv_fwd_split, plus, from the
 // epilogue, the per-tile partial sums of the GroupNorm backward (norm.hip: S1 = sum dy, S2 = sum dy xhat with dy = da act'(y))
 // into part[N][tiles][C][2] (double; tiles = (H/8) (W/16) per image) -- favae_gn_act_bwd_tiles consumes them.
-extern "C" int favae_conv_gnbwd_tiles(const favae_conv_desc* d) {
+// `planes`: the planes word the conv call will be given -- only FAVAE_PLANES_WINO4 is looked at (F(4x4) records: that kernel's grid)
+static int wino_part_tiles(const favae_conv_desc* d, bool has_affine, int planes) {
+    if ((planes & FAVAE_PLANES_WINO4) && wino4_ok(d, has_affine)) return (d->Hout / 16) * (d->Wout / 16);
+    if (wino_wide_ok(d, has_affine)) return (d->Hout / 8) * (d->Wout / 16);
+    return (d->Hout / 16) * (d->Wout / 16);
+}
+extern "C" int favae_conv_gnbwd_tiles(const favae_conv_desc* d, int planes) {
     if (!desc_ok(d) || !halo3_fp16_ok(d, false)) return 0;
-    if (wino_ok(d, false)) return (d->Hout / 16) * (d->Wout / 16);
+    if (wino_ok(d, false)) return wino_part_tiles(d, false, planes);
     return (d->Hout / 8) * (d->Wout / 16);
 }
 
 // Forward conv that also emits pass 1 of the GroupNorm consuming its output: per-tile (sum y, sum y^2) per channel into
 // part[N][tiles][Cout][2] (double); favae_gn_stats_tiles turns them into the statistics (norm.hip).
-extern "C" int favae_conv_stats_tiles(const favae_conv_desc* d, int has_affine) {
+extern "C" int favae_conv_stats_tiles(const favae_conv_desc* d, int has_affine, int planes) {
     if (!desc_ok(d) || !halo3_fp16_ok(d, has_affine != 0)) return 0;
     if (has_affine && d->act != FAVAE_ACT_SILU) return 0;
-    if (wino_ok(d, has_affine != 0)) return (d->Hout / 16) * (d->Wout / 16);
+    if (wino_ok(d, has_affine != 0)) return wino_part_tiles(d, has_affine != 0, planes);
     return (d->Hout / 8) * (d->Wout / 16);
 }
 
@@ -1159,7 +1182,7 @@ extern "C" int favae_conv_fwd_split_stats(const favae_conv_desc* d, const float*
                                           const float* shift, float* y, void* part, size_t part_bytes, float* y_absmax,
                                           favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && wsplit && (x_absmax || planes == 4) && part);
-    const int tiles = favae_conv_stats_tiles(d, scale != nullptr);
+    const int tiles = favae_conv_stats_tiles(d, scale != nullptr, planes);
     // the tile grid of the partial sums is the kernel's: Winograd records go with the Winograd kernel's 16 x 16 tiles and nothing else
     if (((planes & FAVAE_PLANES_WINO) != 0) != wino_ok(d, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (planes & FAVAE_PLANES_WINO) planes = wino_planes_ok(d, planes, scale != nullptr) ? planes : 0;
@@ -1175,7 +1198,7 @@ extern "C" int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy,
                                       const float* gamma, const float* beta, int groups, int act, void* part, size_t part_bytes,
                                       favae_stream_t stream) {
     FAVAE_REQUIRE(desc_ok(d) && dy && wsplit && (dy_absmax || planes == 4) && da && x && mean && rstd && gamma && beta && part && groups > 0);
-    const int tiles = favae_conv_gnbwd_tiles(d);
+    const int tiles = favae_conv_gnbwd_tiles(d, planes);
     if (((planes & FAVAE_PLANES_WINO) != 0) != wino_ok(d, false)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (planes & FAVAE_PLANES_WINO) planes = wino_planes_ok(d, planes, false) ? planes : 0;
     if (!tiles || ((planes & 0xff) != 2 && planes != 1 && planes != 4) || d->Cout % groups != 0) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
@@ -1345,20 +1368,27 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
             FAVAE_CHECK_LAUNCH();
             return FAVAE_OK;
         }
-        a.tiles_n = d->Cout / 64;
+        const bool wide = wino_wide_ok(d, scale != nullptr);      // 16 x 8 pixels x 128 channels per workgroup
+        const int wth = wide ? 8 : 16;
+        a.tiles_n = d->Cout / (wide ? 128 : 64);
         a.w_bytes = (unsigned)((size_t)d->Cout * d->Cin * 64);
         auto rcp32 = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };   // 0: divisor 1
-        a.wino_rcp_n = rcp32(a.tiles_n); a.wino_rcp_w = rcp32(d->Win / 16); a.wino_rcp_h = rcp32(d->Hin / 16);
-        const dim3 wgrid((unsigned)(d->N * (d->Hin / 16) * (d->Win / 16) * a.tiles_n));
-#define FAVAE_LAUNCH_WINO(X, GBV, SEV)                                                                                      \
+        a.wino_rcp_n = rcp32(a.tiles_n); a.wino_rcp_w = rcp32(d->Win / 16); a.wino_rcp_h = rcp32(d->Hin / wth);
+        const dim3 wgrid((unsigned)(d->N * (d->Hin / wth) * (d->Win / 16) * a.tiles_n));
+#define FAVAE_LAUNCH_WINO_T(X, GBV, SEV, WD)                                                                                \
     do {                                                                                                                    \
         static bool attr_set = false;                                                                                       \
         if (!attr_set) {                                                                                                    \
-            (void)hipFuncSetAttribute((const void*)conv3x3_wino_sp_kernel<X, GBV, SEV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)conv3x3_wino_sp_kernel<X, GBV, SEV, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       wino::LDS_B);                                                                         \
             attr_set = true;                                                                                                \
         }                                                                                                                   \
-        FAVAE_KLAUNCH((conv3x3_wino_sp_kernel<X, GBV, SEV>), wgrid, dim3(512), wino::LDS_B, s, a);                          \
+        FAVAE_KLAUNCH((conv3x3_wino_sp_kernel<X, GBV, SEV, WD>), wgrid, dim3(512), wino::LDS_B, s, a);                      \
+    } while (0)
+#define FAVAE_LAUNCH_WINO(X, GBV, SEV)                                                                                      \
+    do {                                                                                                                    \
+        if (wide) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true);                                                                   \
+        else FAVAE_LAUNCH_WINO_T(X, GBV, SEV, false);                                                                       \
     } while (0)
         if (gb) FAVAE_LAUNCH_WINO(0, true, false);
         else if (stats_part && xf == 0) FAVAE_LAUNCH_WINO(0, false, true);
@@ -1368,6 +1398,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         else if (xf == 2) FAVAE_LAUNCH_WINO(2, false, false);
         else FAVAE_LAUNCH_WINO(3, false, false);
 #undef FAVAE_LAUNCH_WINO
+#undef FAVAE_LAUNCH_WINO_T
     } else if (halo_ok || halo2_ok) {
         a.tiles_n = cdiv(d->Cout, 128);
         const dim3 hgrid((unsigned)(d->N * (d->Hin / 8) * (d->Win / 16) * a.tiles_n));

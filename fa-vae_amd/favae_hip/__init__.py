@@ -21,7 +21,7 @@ if "GPU_MAX_HW_QUEUES" not in os.environ and not torch.cuda.is_initialized():
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FAVAE_HIP_LIB") or os.path.join(_HERE, "libfavae_hip.so")     # FAVAE_HIP_LIB: same-box A/B of two builds
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02, ACT_RELU = 0, 1, 2, 3
@@ -117,10 +117,10 @@ SIGNATURES = {
     "favae_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     "favae_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     "favae_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _S]),
-    "favae_conv_stats_tiles": (c_int, [POINTER(ConvDesc), c_int]),
+    "favae_conv_stats_tiles": (c_int, [POINTER(ConvDesc), c_int, c_int]),
     "favae_conv_fwd_split_stats": (c_int, [POINTER(ConvDesc), _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, _S]),
     "favae_gn_stats_tiles": (c_int, [_P, c_int, _P, _P, c_int, c_int64, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _S]),
-    "favae_conv_gnbwd_tiles": (c_int, [POINTER(ConvDesc)]),
+    "favae_conv_gnbwd_tiles": (c_int, [POINTER(ConvDesc), c_int]),
     "favae_gn_bwd_tiles_workspace": (c_size_t, [c_int, c_int, c_int]),
     "favae_conv_dgrad_gnbwd": (c_int, [POINTER(ConvDesc), _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _S]),
     "favae_gn_act_bwd_tiles": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P,
@@ -141,6 +141,7 @@ SIGNATURES = {
     "favae_get_wino": (c_int, []),
     "favae_conv_wino4_ok": (c_int, [_P, c_int]),
     "favae_set_wino4": (c_int, [c_int]),
+    "favae_set_wino_wide": (c_int, [c_int]),
     "favae_wino4_weights_bytes": (c_size_t, [c_int, c_int]),
     "favae_set_zero_arena": (c_int, [c_void_p, c_size_t]),
     "favae_wino_weights_grouped": (c_int, [_P, _P, c_int, _S]),

@@ -368,6 +368,12 @@ def set_wino4(mode):
     return prev
 
 
+def set_wino_wide(on):
+    """16 x 8-pixel x 128-channel tiling of the F(2x2) Winograd kernel on / off (FAVAE_WINO_WIDE; bit-identical results); returns the
+    previous setting"""
+    return query("favae_set_wino_wide", 1 if on else 0)
+
+
 _WINO4_FWD_MINPIX = int(os.environ.get("FAVAE_WINO4_FWD_MINPIX", "65536"))   # forward: only where it measured faster (128 -> 128 @256^2: 1.12 x)
 
 
@@ -918,7 +924,9 @@ class FusedConvFn(torch.autograd.Function):
         st_tiles = 0
         st_part = None
         if _GNSTATS_FUSE and xs is None:
-            st_tiles = query("favae_conv_stats_tiles", byref(d), 0 if scale is None else 1)
+            # the tile grid is the kernel's: F(4x4) records (decoder forward under FAVAE_WINO4=2) have their own
+            st_tiles = query("favae_conv_stats_tiles", byref(d), 0 if scale is None else 1,
+                             PLANES_WINO4 if _wino4_wanted(d, scale is not None, False) else 0)
             if st_tiles:
                 st_part = torch.empty((N * st_tiles * Cout * 2,), dtype=torch.float64, device=dev)
         y_amax = _max_target(dev) if st_part is not None else None
@@ -1061,7 +1069,7 @@ class FusedConvFn(torch.autograd.Function):
                 gnb = None
                 if (_GNBWD_FUSE and has_gn and cfg.norm == "group" and not cfg.upsample and dys is None and mean is not None
                         and (dyb is not None or not _fp16_planes())):
-                    gn_tiles = query("favae_conv_gnbwd_tiles", byref(d2))
+                    gn_tiles = query("favae_conv_gnbwd_tiles", byref(d2), PLANES_WINO4 if _wino4_wanted(d2, False, True) else 0)
                     if gn_tiles:
                         gn_ws = workspace(query("favae_gn_bwd_tiles_workspace", N, gn_tiles, Cin), dev)
                         # FAVAE_GB_PREMUL: the epilogue writes dy = da * act'(y) (it has it in registers for the sums) and the apply

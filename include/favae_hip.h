@@ -114,12 +114,16 @@ int favae_segment_absmax(const float* x, const int64_t* seg_off, int nseg, const
  * of the direct kernel; transforms in fp32, products on two scaled fp16 planes, fp32 accumulation and output transform.
  * favae_conv_wino_ok(d, has_affine) = 1 when favae_conv_fwd_split / _stats / favae_conv_dgrad_gnbwd run d on that kernel: the caller
  * then passes records made by favae_wino_weights (favae_wino_weights_bytes(Cout, Cin) bytes) and planes = 2 | FAVAE_PLANES_WINO; the
- * tile counts of favae_conv_stats_tiles / favae_conv_gnbwd_tiles are that kernel's (16 x 16 pixels).  favae_wino_weights: w = OHWI fp32
+ * tile counts of favae_conv_stats_tiles / favae_conv_gnbwd_tiles are that kernel's (16 x 16 pixels; 16 x 8 where the output channels
+ * tile by 128: the kernel then runs 16 x 8 pixels x 128 channels per workgroup -- each tile's GroupNorm / SiLU staging, input transform
+ * and operand split are done once for 128 output channels instead of once per 64 -- same result bits, same records;
+ * FAVAE_WINO_WIDE=0 / favae_set_wino_wide(0) keeps the 16 x 16 x 64 tiling everywhere).  favae_wino_weights: w = OHWI fp32
  * [Cout][3][3][Cin]; flip = 0 -> records of the forward conv, flip = 1 -> of its data gradient (Cin outputs, taps flipped);
  * amax = device float max|w| or NULL (computed).  FAVAE_WINO=0 in the environment keeps every conv on the direct kernels. */
 #define FAVAE_PLANES_WINO 0x100
 int favae_conv_wino_ok(const favae_conv_desc* d, int has_affine);
 int favae_set_wino(int on);            /* run-time override of FAVAE_WINO; returns the previous setting */
+int favae_set_wino_wide(int on);       /* run-time override of FAVAE_WINO_WIDE; returns the previous setting */
 int favae_get_wino(void);              /* the current setting, no side effect */
 /* Winograd F(4x4, 3x3) (csrc/conv_wino4.h, ABI 18): 36 instead of 64 multiplies per 16 outputs -- 0.56 x the matrix work and operand
  * splitting of the F(2x2) kernel, at 2.3e-6 rms (F(2x2): 3.6e-7) of the output range per conv.  Meant for results no codebook index
@@ -434,9 +438,10 @@ int favae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
  * needs per (image, group) the mean and variance of its input, which is the output of the previous conv: the dense 3x3 forward
  * kernel sums y and y^2 per channel over its 8x16-pixel tile in the epilogue (fp64 from the first product, fixed order:
  * deterministic) into part[N][tiles][Cout][2], and favae_gn_stats_tiles finishes the statistics without reading the tensor.
- *   favae_conv_stats_tiles(d, has_affine)   tiles per image when favae_conv_fwd_split(d, ...) runs that kernel, else 0
+ *   favae_conv_stats_tiles(d, has_affine, planes)   tiles per image when favae_conv_fwd_split(d, ...) runs that kernel, else 0;
+ *     planes = the planes word the conv call will be given (only FAVAE_PLANES_WINO4 is looked at: the Winograd kernels' grids differ)
  * ---------------------------------------------------------------------------------------------------------- */
-int favae_conv_stats_tiles(const favae_conv_desc* d, int has_affine);
+int favae_conv_stats_tiles(const favae_conv_desc* d, int has_affine, int planes);
 /* y_absmax (optional device float): max |y| of the output as a further by-product -- the fp16 operand range of a conv that consumes y
  * WITHOUT a normalisation in front (Downsample, Upsample, nin_shortcut: models/codec.py:17,26-29,50), which otherwise costs one
  * favae_absmax pass over y. */
@@ -453,7 +458,7 @@ int favae_gn_stats_tiles(const void* part, int tiles, const float* gamma, const 
  * kernel has da in its accumulators: favae_conv_dgrad_gnbwd = favae_conv_fwd_split(d, dy, flipped weights) -> da, whose epilogue
  * also reads the matching tile of x and writes per-tile partial sums part[N][tiles][C][2] (double, fixed summation order:
  * deterministic); favae_gn_act_bwd_tiles = favae_gn_act_bwd without its streaming pass 1 (two tensor reads less per GroupNorm).
- *   favae_conv_gnbwd_tiles(d)       tiles per image ((H/8)(W/16)) when the data gradient `d` runs that kernel, else 0
+ *   favae_conv_gnbwd_tiles(d, planes)   tiles per image when the data gradient `d` runs that kernel, else 0 (planes: as above)
  *   favae_gn_bwd_tiles_workspace    bytes of the workspace shared by the two calls: it STARTS with `part`
  *   act | FAVAE_GB_PREMUL (round 5): the epilogue has dy = da * act'(y) in registers for the sums -- with the flag it WRITES that
  *     tensor instead of da, and favae_gn_act_bwd_tiles / favae_gn_act_bwd_colsum called with the same flagged `act` (and tiles > 0)
@@ -462,7 +467,7 @@ int favae_gn_stats_tiles(const void* part, int tiles, const float* gamma, const 
  * Reference: autograd of GroupNorm + SiLU in ResnetBlock / NonResnetBlock / final (models/codec.py:38-46,65-73,170-175).
  * ---------------------------------------------------------------------------------------------------------- */
 #define FAVAE_GB_PREMUL 0x100
-int favae_conv_gnbwd_tiles(const favae_conv_desc* d);
+int favae_conv_gnbwd_tiles(const favae_conv_desc* d, int planes);
 size_t favae_gn_bwd_tiles_workspace(int N, int tiles, int C);
 int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy, const void* wsplit, int planes, const float* dy_absmax,
                            float* da, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,

@@ -484,6 +484,60 @@ def test_winograd_f44_against_f22_kernel(K, N, cin, cout, H, W):
             i, float((u - v).abs().max()) / scale)
 
 
+@pytest.mark.parametrize("N,cin,cout,H,W", [(2, 128, 128, 32, 32), (1, 16, 128, 16, 48), (3, 192, 256, 48, 32), (1, 512, 384, 16, 16),
+                                            (2, 32, 128, 64, 16)])
+def test_winograd_wide_tiling_is_bit_identical(K, N, cin, cout, H, W):
+    """The 16 x 8-pixel x 128-channel workgroups of the F(2x2, 3x3) kernel (conv_wino.h WIDE: staging, transform and split once per 128
+    output channels) against its 16 x 16 x 64 tiling: same arithmetic in the same order, so forward (bias + residual; fused GroupNorm +
+    SiLU) and data gradient are BIT-identical; what flows through the per-tile partial sums of the statistics epilogues (a finer tile
+    grid, summed in fp64) agrees to fp32 rounding.  One, two, twelve, 32 K chunks; one to three channel tiles; non-square images."""
+    import favae_hip as H_
+    from ctypes import byref
+    desc = H_.make_conv_desc(N, H, W, cin, H, W, cout, 3, 3, 1, 1, 0, 0, 1)
+    if not H_.query("favae_conv_wino_ok", byref(desc), 0):
+        pytest.skip("Winograd path switched off")
+    torch.manual_seed(N * 100 + cout)
+    d = dev()
+    x = torch.randn(N, cin, H, W, device=d)
+    w = torch.randn(cout, cin, 3, 3, device=d) * math.sqrt(1.0 / (9 * cin))
+    w2 = torch.randn(128, cout, 3, 3, device=d) * math.sqrt(1.0 / (9 * cout))
+    b = torch.randn(cout, device=d) * 0.1
+    res = torch.randn(N, cout, H, W, device=d)
+    gw, gb = 1 + 0.2 * torch.randn(cin, device=d), 0.2 * torch.randn(cin, device=d)
+    gw2, gb2 = 1 + 0.2 * torch.randn(cout, device=d), 0.2 * torch.randn(cout, device=d)
+    gy = torch.randn(N, 128, H, W, device=d)
+    cfg_gn = K.ConvCfg(3, 3, 1, 1, groups=16)
+    cfg = K.ConvCfg(3, 3, 1, 1)
+
+    def run(wide):
+        prev = K.set_wino_wide(wide)
+        try:
+            assert H_.query("favae_conv_stats_tiles", byref(desc), 0, 0) == (H // (8 if wide else 16)) * (W // 16)
+            outs = []
+            with torch.no_grad():                     # no by-products: the conv results themselves
+                outs.append(K.fused_conv(x, w, b, None, None, res, cfg))
+                outs.append(K.fused_conv(x, w, b, gw, gb, None, cfg_gn))
+            for gn in (False, True):
+                xg, wg, wg2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+                g1 = [t.clone().requires_grad_(True) for t in (gw, gb, gw2, gb2)]
+                y = K.fused_conv(xg, wg, b, g1[0] if gn else None, g1[1] if gn else None, res, cfg_gn if gn else cfg)
+                z = K.fused_conv(y, wg2, None, g1[2], g1[3], None, cfg_gn)        # its GroupNorm runs on y's statistics epilogue
+                grads = torch.autograd.grad(z, [xg, wg, wg2] + (g1 if gn else g1[2:]), gy)
+                K.sync_side_stream()
+                torch.cuda.synchronize()
+                outs += [y.detach(), z.detach()] + list(grads)
+            return outs
+        finally:
+            K.set_wino_wide(prev)
+    a1 = _wino4_run(K, lambda: run(1), "0")
+    a0 = _wino4_run(K, lambda: run(0), "0")
+    for i in (0, 1, 2, 9):                            # plain forwards, and y of both stacked runs (computed before any by-product is used)
+        assert torch.equal(a1[i], a0[i]), "output %d differs between the two tilings" % i
+    for i, (u, v) in enumerate(zip(a1, a0)):
+        scale = float(v.abs().max())
+        assert float((u - v).abs().max()) <= 2e-6 * scale, "output %d: %.2e of the maximum" % (i, float((u - v).abs().max()) / scale)
+
+
 @pytest.mark.parametrize("switch", ["FAVAE_CONV_HALO", "FAVAE_WINO"])
 def test_cout64_conv_without_the_winograd_kernel(switch):
     """with the A/B switch that takes the Winograd kernel away a 64 -> 64 3x3 conv (the VGG16 convs of LPIPS) must

@@ -47,14 +47,14 @@ for cin, cout, hw in SHAPES:
         K.set_wino4(mode)
         with K.wino4_forward(True):
             y = K.new_cl(B, cout, hw, hw, dev)
-            tiles = H.query("favae_conv_stats_tiles", byref(d), 1)
+            tiles = H.query("favae_conv_stats_tiles", byref(d), 1, K.PLANES_WINO4 if mode == "2" else 0)
             st = torch.empty((B * tiles * cout * 2,), dtype=torch.float64, device=dev)
             ya = torch.zeros(1, device=dev)
             t_f = timeit(lambda: K._conv_launch(d, x, w, b, None, scale, shift, y, xb, stats_out=st, y_amax=ya))
             dy = torch.randn(B, cout, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
             dyb = K.absmax(dy)
             dx = K.new_cl(B, cin, hw, hw, dev)
-            gt = H.query("favae_conv_gnbwd_tiles", byref(d2))
+            gt = H.query("favae_conv_gnbwd_tiles", byref(d2), K.PLANES_WINO4 if mode == "2" else 0)
             gws = H.workspace(H.query("favae_gn_bwd_tiles_workspace", B, gt, cin), dev)
             torch.manual_seed(1)
             dy.copy_(torch.randn(B, cout, hw, hw, device=dev))

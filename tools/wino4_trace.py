@@ -79,7 +79,7 @@ dy = torch.randn(B, cout, hw, hw, device=dev).contiguous(memory_format=torch.cha
 dyb = K.absmax(dy)
 d2 = H.make_conv_desc(B, hw, hw, cout, hw, hw, cin, 3, 3, 1, 1, 0, 0, 1)
 dx = K.new_cl(B, cin, hw, hw, dev)
-gt = H.query("favae_conv_gnbwd_tiles", byref(d2))
+gt = H.query("favae_conv_gnbwd_tiles", byref(d2), K.PLANES_WINO4)
 gws = H.workspace(H.query("favae_gn_bwd_tiles_workspace", B, gt, cin), dev)
 gnb = (x, mean, rstd, gw, gb, 32, H.ACT_SILU, gws)
 wmax = K.absmax(w)
