@@ -42,6 +42,9 @@ constexpr int LDS_B = 2 * V_B + RAW_B + 2 * AFF_C * 4;   // 161088 of the 160 KB
 constexpr int UCH = 16 * 1024;                // weight bytes per (co tile of 64, K chunk, column b): [a][co block][plane][lane][16 B]
 constexpr float HEAD = 0.25f;                 // |B^T d B| <= 4 max|d|, |G g G^T| <= 2.25 max|g|: two more bits of fp16 head room
 
+// (Round 5 tried v_fma_mixlo_f16 / v_fma_mixhi_f16 -- the residual, and in the direct kernels also the scaled hi, rounded straight into
+// the halves of the packed pair: 6 / 8 instead of 8 / 12 instructions per four values, same bits -- and the step got 0.8 ms SLOWER, the
+// weight-gradient kernel 3 %: profiles/r05_split_ab.txt.  The partial-register writes serialise.)
 // (hi, lo) fp16 planes of four values (already scaled), stored VPL apart.  hi = rne(t) as a packed pair; the residual t - hi comes from
 // one mixed-precision FMA per value (v_fma_mix_f32: the f16 half of the pair x -1 + the fp32 value, exact) -- 8 vector instructions
 // per four values (the compiler's own lowering of the same expression converts every hi twice: 16).
@@ -415,13 +418,18 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
         }
         __syncthreads();                            // (scale, shift) staged
     }
+    WTRACE(0, 2);
     store_raw(0);
+    WTRACE(0, 3);
     load_raw(KL < 2 ? KL : 2);
     if constexpr (WIDE) {                           // chunk 1 goes into the other tile: no barrier between the two
         if (KL >= 1) store_raw_from(rg1, 1);
+        WTRACE(0, 4);
         __syncthreads();
+        WTRACE(0, 5);
         read_patch(0);
         transform(0);
+        WTRACE(0, 6);
         __syncthreads();
     } else {
         __syncthreads();

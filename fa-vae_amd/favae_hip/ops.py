@@ -339,9 +339,11 @@ def _wino_cached(w, flip):
 
 
 # Winograd F(4x4, 3x3) (csrc/conv_wino4.h): 0.56 x the matrix work of the F(2x2) kernel at ~6 x its rounding error (2.3e-6 rms of the output
-# range per conv).  FAVAE_WINO4: "0" never; "1" (default) data gradients only -- no codebook index depends on them and their parity bar is
+# range per conv).  FAVAE_WINO4: "0" (default) never; "1" data gradients only -- no codebook index depends on them and their parity bar is
 # 5e-3; "2" also the forward convs of modules that opted in (`wino4_forward(True)` around the call: the decoder, behind the quantizer).
-_WINO4 = os.environ.get("FAVAE_WINO4", "1")
+# "1" was the default until the F(2x2) kernel got its 16 x 8 x 128 tiling (conv_wino.h WIDE): that one is as fast at 256^2 and faster
+# below with F(2x2)'s rounding, and the step is 0.4 ms shorter without F(4x4) (profiles/r05_wide_step_ab.txt, r05_wide_bench.txt).
+_WINO4 = os.environ.get("FAVAE_WINO4", "0")
 _WINO4_FWD = [False]
 
 

@@ -39,6 +39,13 @@ def report(name, t, KC):
     print("  workgroup (wave) lifetime %.0f cycles: prologue %.0f, K loop %.0f, epilogue %.0f (exchange stores %.0f, barrier %.0f, finish+stores %.0f, stats %.0f)"
           % (total.mean(), pro.mean(), (tt[:, 47, 0] - tt[:, 0, 1]).mean(), epi.mean(), (tt[:, 47, 1] - tt[:, 47, 0]).mean(),
              (tt[:, 47, 2] - tt[:, 47, 1]).mean(), (tt[:, 47, 3] - tt[:, 47, 2]).mean(), (tt[:, 47, 4] - tt[:, 47, 3]).mean()))
+    if (tt[:, 0, 2] > 0).all():                  # finer prologue stamps (WIDE build)
+        names = ["start", "end", "loads issued, (scale, shift) staged", "halo 0 arrived + staged", "halo 1 staged", "barrier", "patch + transform 0"]
+        order = [0, 2, 3, 4, 5, 6, 1]
+        prev = tt[:, 0, 0]
+        for k in order[1:]:
+            print("     prologue: -> %-40s %6.0f cycles" % (names[k] if k != 1 else "last barrier", (tt[:, 0, k] - prev).mean()))
+            prev = tt[:, 0, k]
     rows = [r for r in range(3, KC)]             # steady-state periods (generic copies of the loop body): chunk index r - 1
     if not rows:
         rows = [1]
