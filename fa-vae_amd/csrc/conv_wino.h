@@ -616,13 +616,13 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
                     f1 += dyv;
                     f2 = fmaf(dyv, xh, f2);
                 }
-                if constexpr (SE) {
-                    gs1 += (double)y;
-                    gs2 += (double)y * (double)y;
+                if constexpr (SE) {                 // four outputs in fp32, then fp64 -- as the GB sums: fp64 vector instructions run at
+                    f1 += y;                        // half rate, 5 per output were 2000 of a forward workgroup's 45000 cycles
+                    f2 = fmaf(y, y, f2);
                     se_amax = fmaxf(se_amax, fabsf(y));
                 }
             }
-        if constexpr (GB) { gs1 += (double)f1; gs2 += (double)f2; }
+        if constexpr (GB || SE) { gs1 += (double)f1; gs2 += (double)f2; }
     }
     WTRACE(47, 3);
     if constexpr (GB || SE) {

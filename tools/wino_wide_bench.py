@@ -16,8 +16,10 @@ dev = torch.device("cuda:0")
 SHAPES = [(128, 128, 256), (128, 128, 128), (256, 128, 128), (128, 256, 128), (256, 256, 64), (256, 256, 32), (512, 512, 16), (256, 512, 32)]
 
 
-def timeit(fn, n=6):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, n=10):
+    for _ in range(4):               # warm-up: the first loop over a fresh shape measured 10-20 % slow (round 5: clocks / caches), which
+        fn()                         # favoured whatever was timed second
+    torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(n):
