@@ -66,7 +66,10 @@ __global__ __launch_bounds__(512) void fft_lines_kernel(FftArgs a) {
     const size_t base_out = (size_t)o * a.Lout * a.inner + i0 + ic;
     // U independent loads in flight per thread before the first LDS store (the loop bounds are run-time values, so the
     // compiler would otherwise serialise load -> store pairs: this pass is latency-bound with 8 waves per 64 KB tile)
-    constexpr int U = 8;
+#ifndef FAVAE_FFT_U
+#define FAVAE_FFT_U 16
+#endif
+    constexpr int U = FAVAE_FFT_U;
     for (int l0 = bl; l0 < L; l0 += BL * U) {
         float2 v[U];
         float t[U];
@@ -102,6 +105,8 @@ __global__ __launch_bounds__(512) void fft_lines_kernel(FftArgs a) {
     // ---- butterflies ------------------------------------------------------------------------------------------
     // Two radix-2 stages (s, s+1) are applied per pass on groups of four points held in registers -- the same butterflies in
     // the same order as stage-by-stage radix-2 (bit-identical results), with half the LDS traffic and half the barriers.
+    // (Round 5 tried four stages per pass on sixteen points: the forward W-axis pass -13 %, the inverse one +8 %, the loss 3.42 -> 3.32 ms
+    // on the 128-channel pair, and different gradient bits -- the compiler contracts the unrolled butterflies differently.  Not kept.)
     auto bfly = [](const float2 w, float2& x0, float2& x1) {
         const float2 t = make_float2(w.x * x1.x - w.y * x1.y, w.x * x1.y + w.y * x1.x);
         x1 = make_float2(x0.x - t.x, x0.y - t.y);
@@ -141,10 +146,10 @@ __global__ __launch_bounds__(512) void fft_lines_kernel(FftArgs a) {
         __syncthreads();
     }
     // ---- store ------------------------------------------------------------------------------------------------
-    if (!ic_ok) return;
+    if (OUT != OUT_COMPLEX_MAX && !ic_ok) return;
     float mx = 0.f;
     const float gs = (OUT == OUT_REAL) ? a.gscale[0] * a.scale : a.scale;
-    for (int l = bl; l < (OUT == OUT_REAL ? L : a.Lout); l += BL) {
+    for (int l = bl; ic_ok && l < (OUT == OUT_REAL ? L : a.Lout); l += BL) {
         float2 v;
         if (a.generic) {
             // any length (FA-VAE at resolutions that are not powers of two, e.g. 192 -> 12 x 12 latents): bin l of the line is
@@ -175,34 +180,51 @@ __global__ __launch_bounds__(512) void fft_lines_kernel(FftArgs a) {
         }
     }
     if (OUT == OUT_COMPLEX_MAX) {
-        const long n = o / a.plane_outer_div;
-        const int c = (int)((i0 + ic) % a.C);
-        atomicMax(&a.planemax[n * a.C + c], __float_as_uint(mx));       // d >= 0: uint order == float order
+        // one atomic per column of the tile, and only where it can raise the plane's maximum (round 5: one per THREAD were 8.4 M atomics
+        // on 4096 addresses for the 128-channel feature pair -- 2000 per address; the maximum does not depend on the order)
+        __syncthreads();                                   // every thread is here (no early return above): data[] is free
+        float* red = reinterpret_cast<float*>(data);       // [BL][IC]
+        red[bl * IC + ic] = mx;
+        __syncthreads();
+        if (bl == 0 && ic_ok) {
+            for (int b = 1; b < BL; ++b) mx = fmaxf(mx, red[b * IC + ic]);
+            const long n = o / a.plane_outer_div;
+            const int c = (int)((i0 + ic) % a.C);
+            unsigned* pm = &a.planemax[n * a.C + c];
+            if (__float_as_uint(mx) > *reinterpret_cast<volatile unsigned*>(pm))       // a stale read only costs an atomic
+                atomicMax(pm, __float_as_uint(mx));                                       // d >= 0: uint order == float order
+        }
     }
 }
 
 // spec <- coef * w * F (in place), per-block partial of sum(w*d) in double
 // half spectrum [N][H][Wh][C]: bins 0 < k < W/2 stand for two bins of the full spectrum
-__global__ __launch_bounds__(256) void ffl_weight_kernel(float* spec, const unsigned* planemax, double* part, long per_img,
-                                                         int C, long total, float coef, int Wh, int W) {
+// grid (blocks per image, N); j = (h Wh + k) C + c inside the image.  Round 5: 32-bit indices and divisions by multiply-high with host-made
+// reciprocals (rcp = floor(2^32 / d) + 1, 0 for d = 1; exact while j d < 2^32) -- the three 64-bit divisions per element of rounds 1-4
+// made this streaming pass instruction-bound (0.41 of the HBM roofline on the 128-channel feature pair).
+__global__ __launch_bounds__(256) void ffl_weight_kernel(float* spec, const unsigned* planemax, double* part, unsigned per_img,
+                                                         int C, float coef, int Wh, int W, unsigned rcp_c, unsigned rcp_wh) {
     __shared__ double red[4];
     double acc = 0.0;
-    float2* s2 = reinterpret_cast<float2*>(spec);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long n = i / per_img;
-        const int c = (int)(i % C);
-        float2 f = s2[i];
+    const int n = blockIdx.y;
+    float2* s2 = reinterpret_cast<float2*>(spec) + (size_t)n * per_img;
+    const unsigned* pm = planemax + (size_t)n * C;
+    for (unsigned j = blockIdx.x * 256u + threadIdx.x; j < per_img; j += gridDim.x * 256u) {
+        const unsigned q = rcp_c ? __umulhi(j, rcp_c) : j;           // j / C
+        const int c = (int)(j - q * (unsigned)C);
+        const unsigned r = rcp_wh ? __umulhi(q, rcp_wh) : q;         // q / Wh
+        const int k = (int)(q - r * (unsigned)Wh);
+        float2 f = s2[j];
         const float d = f.x * f.x + f.y * f.y;
-        const float mx = sqrtf(__uint_as_float(planemax[n * C + c]));
+        const float mx = sqrtf(__uint_as_float(pm[c]));
         float w = (mx > 0.f) ? sqrtf(d) / mx : 0.f;                   // 0/0 -> NaN -> 0 upstream
         w = fminf(fmaxf(w, 0.f), 1.f);
-        const int k = (int)((i / C) % Wh);
         acc += (double)(w * d) * ((Wh == W || k == 0 || 2 * k == W) ? 1.0 : 2.0);
         const float g = coef * w;
-        s2[i] = make_float2(g * f.x, g * f.y);
+        s2[j] = make_float2(g * f.x, g * f.y);
     }
     const double tot = block_sum_d256(acc, red);
-    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+    if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = tot;
 }
 
 __global__ __launch_bounds__(256) void ffl_finish_kernel(const double* part, int nparts, double scale, float* loss) {
@@ -304,13 +326,17 @@ extern "C" int favae_ffl_fwd(const float* pred, const float* target, int N, int 
     a.outer = N; a.inner = (long)Wh * C; a.L = H; a.Lin = H; a.Lout = H; a.plane_outer_div = 1;
     rc = launch_fft<IN_COMPLEX, OUT_COMPLEX_MAX>(a, s);
     if (rc) return rc;
-    const long total = (long)N * H * Wh * C;                 // stored bins
+    const size_t per_img = (size_t)H * Wh * C;               // stored bins of one image
     const double M = (double)N * H * W * C;                  // elements of the mean (full spectrum)
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > WEIGHT_BLOCKS) blocks = WEIGHT_BLOCKS;
-    FAVAE_KLAUNCH(ffl_weight_kernel, dim3(blocks), dim3(256), 0, s, spec, (const unsigned*)planemax, part, (long)H * Wh * C,
-                       C, total, (float)(2.0 * (double)loss_weight / M), Wh, W);
+    if (per_img * (size_t)(C > Wh ? C : Wh) >= ((size_t)1 << 32) || N > WEIGHT_BLOCKS) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    int bx = (int)((per_img + 255) / 256);
+    if (bx > WEIGHT_BLOCKS / N) bx = WEIGHT_BLOCKS / N;
+    if (bx < 1) bx = 1;
+    auto rcp32 = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };
+    FAVAE_KLAUNCH(ffl_weight_kernel, dim3(bx, N), dim3(256), 0, s, spec, (const unsigned*)planemax, part, (unsigned)per_img,
+                       C, (float)(2.0 * (double)loss_weight / M), Wh, W, rcp32(C), rcp32(Wh));
     FAVAE_CHECK_LAUNCH();
+    const int blocks = bx * N;
     FAVAE_KLAUNCH(ffl_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)part, blocks, (double)loss_weight / M, loss);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
