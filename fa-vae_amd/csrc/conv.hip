@@ -1738,11 +1738,37 @@ struct ReduceTable {
     unsigned first_block[FAVAE_REDUCE_JOBS_MAX + 1];
     int njobs;
 };
+// VEC: four consecutive outputs per thread, the slabs read as float4 (every job: n % 4 == 0, part 16-byte aligned) -- the same sums per
+// output in the same order, a quarter of the load instructions and four times the bytes in flight per thread (round 5: the scalar
+// kernel ran ~2 workgroups per CU through 8-16 dependent round trips: 195 us per flush of 12 jobs, 2.7 ms of the weight-gradient stream
+// per step)
+template <bool VEC>
 __global__ __launch_bounds__(256) void reduce_slabs_grouped_kernel(ReduceTable t) {
     int j = 0;
     while (j + 1 < t.njobs && blockIdx.x >= t.first_block[j + 1]) ++j;
     const favae_reduce_job jb = t.job[j];
     const size_t n = (size_t)jb.n;
+    if constexpr (VEC) {
+        const size_t i = ((size_t)(blockIdx.x - t.first_block[j]) * 256 + threadIdx.x) * 4;
+        if (i >= n) return;
+        const float* part = jb.part + i;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+        auto ld = [&](int z) { return *reinterpret_cast<const float4*>(part + (size_t)z * n); };
+        auto acc = [](float4& s, const float4 v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; };
+        int z = 0;
+        for (; z + 7 < jb.slabs; z += 8) {
+            const float4 v0 = ld(z), v1 = ld(z + 1), v2 = ld(z + 2), v3 = ld(z + 3), v4 = ld(z + 4), v5 = ld(z + 5), v6 = ld(z + 6), v7 = ld(z + 7);
+            acc(s0, v0); acc(s1, v1); acc(s2, v2); acc(s3, v3);
+            acc(s0, v4); acc(s1, v5); acc(s2, v6); acc(s3, v7);
+        }
+        for (; z + 3 < jb.slabs; z += 4) { acc(s0, ld(z)); acc(s1, ld(z + 1)); acc(s2, ld(z + 2)); acc(s3, ld(z + 3)); }
+        for (; z < jb.slabs; ++z) acc(s0, ld(z));
+        const float sum[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                              (s0.w + s1.w) + (s2.w + s3.w)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) jb.out[i + e] = jb.accumulate ? jb.out[i + e] + sum[e] : sum[e];     // out: any 4-byte alignment
+        return;
+    }
     const size_t i = (size_t)(blockIdx.x - t.first_block[j]) * 256 + threadIdx.x;
     if (i >= n) return;
     const float* part = jb.part;
@@ -1776,17 +1802,23 @@ extern "C" int favae_reduce_slabs_grouped(const favae_reduce_job* jobs, int njob
         t.njobs = njobs - base < FAVAE_REDUCE_JOBS_MAX ? njobs - base : FAVAE_REDUCE_JOBS_MAX;
         unsigned blocks = 0;
         double bytes = 0.0;
+        bool vec = true;
         for (int j = 0; j < t.njobs; ++j) {
             const favae_reduce_job& jb = jobs[base + j];
             FAVAE_REQUIRE(jb.part && jb.out && jb.n > 0 && jb.slabs > 0);
+            vec = vec && jb.n % 4 == 0 && (reinterpret_cast<uintptr_t>(jb.part) & 15) == 0;
+        }
+        for (int j = 0; j < t.njobs; ++j) {
+            const favae_reduce_job& jb = jobs[base + j];
             t.job[j] = jb;
             t.first_block[j] = blocks;
-            blocks += (unsigned)cdiv(jb.n, 256);
+            blocks += (unsigned)cdiv(vec ? jb.n / 4 : jb.n, 256);
             bytes += 4.0 * jb.n * (jb.slabs + (jb.accumulate ? 2 : 1));
         }
         t.first_block[t.njobs] = blocks;
         FAVAE_PROF_NOTE(0, bytes);
-        FAVAE_KLAUNCH(reduce_slabs_grouped_kernel, dim3(blocks), dim3(256), 0, s, t);
+        if (vec) FAVAE_KLAUNCH(reduce_slabs_grouped_kernel<true>, dim3(blocks), dim3(256), 0, s, t);
+        else FAVAE_KLAUNCH(reduce_slabs_grouped_kernel<false>, dim3(blocks), dim3(256), 0, s, t);
         FAVAE_CHECK_LAUNCH();
     }
     return FAVAE_OK;
