@@ -262,7 +262,7 @@ def test_split_precision_is_fp32_grade_against_fp64(K):
             for mode in ("h3", "h3+f44dgrad", "fp32", "b6"):
                 K.set_conv_mode(mode.split("+")[0])
                 # "h3": every 3x3 conv on the F(2x2, 3x3) Winograd kernel (the forward path of the product); "h3+f44dgrad": the product
-                # default since round 5 -- the DATA GRADIENT of layers that tile into it runs F(4x4, 3x3) (csrc/conv_wino4.h)
+                # optional since the wide F(2x2) tiling (FAVAE_WINO4=1) -- the DATA GRADIENT of layers that tile into it runs F(4x4, 3x3) (csrc/conv_wino4.h)
                 prev4 = K.set_wino4("1" if mode == "h3+f44dgrad" else "0")
                 xg, wg = x.to(d).requires_grad_(True), w.to(d).requires_grad_(True)
                 y_gn = K.fused_conv(xg, wg, b.to(d), gw.to(d), gb.to(d), None, cfg)
