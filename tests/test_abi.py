@@ -142,6 +142,48 @@ def test_cout64_wants_split_weights_exactly_when_the_winograd_kernel_takes_it():
     assert seen_on == 3 and seen_off == 8
 
 
+def test_partial_sum_tile_counts_follow_the_kernel_that_will_run():
+    """The per-tile partial sums of the statistics / GroupNorm-backward epilogues are on the grid of the kernel that writes them: the
+    F(2x2) Winograd kernel in its 16 x 8 x 128 tiling where Cout % 128 == 0, in its 16 x 16 x 64 tiling otherwise or under
+    FAVAE_WINO_WIDE=0 / favae_set_wino_wide(0), the F(4x4) kernel (16 x 16 partials) when the call will pass F(4x4) records -- the
+    queries take the planes word of that call (ABI 19).  A count for the wrong kernel under- or over-sizes the buffer the consumer
+    then sums.  Host logic only."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from ctypes import byref\n"
+        "from favae_hip import query\n"
+        "from favae_hip.ops import make_conv_desc, GATHER_PLAIN, ACT_NONE, ACT_SILU, PLANES_WINO4\n"
+        "H, W = 64, 96\n"
+        "for cin, cout in ((128, 128), (64, 64), (128, 192), (256, 256)):\n"
+        "    d = make_conv_desc(2, H, W, cin, H, W, cout, 3, 3, 1, 1, GATHER_PLAIN, ACT_SILU, 1)\n"
+        "    d2 = make_conv_desc(2, H, W, cin, H, W, cout, 3, 3, 1, 1, GATHER_PLAIN, ACT_NONE, 1)\n"
+        "    row = [query('favae_conv_stats_tiles', byref(d), 1, 0), query('favae_conv_gnbwd_tiles', byref(d2), 0),\n"
+        "           query('favae_conv_stats_tiles', byref(d), 1, PLANES_WINO4), query('favae_conv_gnbwd_tiles', byref(d2), PLANES_WINO4),\n"
+        "           query('favae_conv_wino4_ok', byref(d2), 0)]\n"
+        "    prev = query('favae_set_wino_wide', 0)\n"
+        "    row += [query('favae_conv_stats_tiles', byref(d), 1, 0), query('favae_conv_gnbwd_tiles', byref(d2), 0), prev]\n"
+        "    query('favae_set_wino_wide', prev)\n"
+        "    print(cin, cout, *row)\n"
+    ) % os.path.join(ROOT, "fa-vae_amd")
+    fine, coarse = (64 // 8) * (96 // 16), (64 // 16) * (96 // 16)
+    for env_extra, wide_default in (({}, 1), ({"FAVAE_WINO_WIDE": "0"}, 0)):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rows = [[int(v) for v in line.split()] for line in out.stdout.strip().splitlines()]
+        assert len(rows) == 4
+        for cin, cout, st, gb, st4, gb4, f44_ok, st_off, gb_off, prev in rows:
+            wide = wide_default and cout % 128 == 0
+            assert prev == wide_default
+            assert st == gb == (fine if wide else coarse), (env_extra, cin, cout, st, gb)
+            assert st_off == gb_off == coarse, (env_extra, cin, cout)
+            if f44_ok:                                       # F(4x4) records: that kernel's 16 x 16 partials whatever the F(2x2) tiling
+                assert st4 == gb4 == coarse, (env_extra, cin, cout, st4, gb4)
+            else:
+                assert st4 == st and gb4 == gb
+
+
 def test_package_asks_for_eight_hardware_queues_before_hip_is_initialised():
     """Round 5 finding (profiles/r05_dist_overhead.txt): with HIP's default of 4 hardware queues an initialised RCCL process group takes
     the overlap of the weight-gradient stream away (+8.6 % step time at every N >= 2).  Importing favae_hip before the first HIP call

@@ -213,6 +213,52 @@ def test_train_step_cfg1_256_against_reference_golden(golden_dir):
         close(got, g[f"cfg1_256.adam.{k}.head"], 1e-6, "adam." + k)
 
 
+def test_train_step_cfg1_256_with_f44_data_gradients_against_reference_golden(golden_dir):
+    """The same reference step with the optional F(4x4, 3x3) kernel on every data gradient that tiles into it (FAVAE_WINO4=1: the
+    default of round 5's first half, off since the wide F(2x2) tiling): losses, x_recon and every gradient hold the SAME bars."""
+    from favae_hip import ops as K
+    prev = K.set_wino4("1")
+    try:
+        g = np.load(os.path.join(golden_dir, "cfg1_256.npz"))
+        _golden_step(g, "cfg1_256", "cfg1")
+    finally:
+        K.set_wino4(prev)
+
+
+def test_winograd_tilings_agree_on_the_whole_model():
+    """16 x 8 x 128 against 16 x 16 x 64 workgroups of the F(2x2) kernel (FAVAE_WINO_WIDE=1 / 0) on a whole training step at 128 x 128:
+    the conv results are bit-identical per layer (tests/test_gpu_ops.py); through the model the per-tile partial sums of the statistics
+    epilogues (a finer tile grid, fp64) may move a GroupNorm statistic by an fp32 ulp -- indices identical, reconstruction, losses and
+    gradients equal to 1e-5 of their maxima."""
+    from favae_hip import ops as K
+    from favae_step import TrainStep
+    x = O.det_input(2, 128, 128, 77).to(DEV)
+
+    def run(wide):
+        model, _, _ = build("cfg1")
+        prev = K.set_wino_wide(wide)
+        try:
+            ts = TrainStep(model, lr=1e-4)
+            model.eval()
+            with torch.no_grad():
+                _, _, ind, _ = model.encode(x)
+            model.train()
+            ts.gflat.zero_()
+            out = ts.losses(x)
+            ts.backward(out)
+            K.sync_side_stream()
+            torch.cuda.synchronize()
+            return ind.clone(), out["x_recon"].detach().clone(), float(out["loss_g"]), ts.gflat.clone()
+        finally:
+            K.set_wino_wide(prev)
+    i1, x1, l1, g1 = run(1)
+    i0, x0, l0, g0 = run(0)
+    assert torch.equal(i1, i0), "codebook indices differ between the two tilings"
+    assert float((x1 - x0).abs().max()) <= 1e-5 * float(x0.abs().max())
+    assert abs(l1 - l0) <= 1e-5 * abs(l0)
+    assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max()), float((g1 - g0).abs().max()) / float(g0.abs().max())
+
+
 @pytest.mark.parametrize("gtag,mtag", [("cfg2_256", "cfg2"), ("f4_256", "f4_full")])
 def test_train_step_at_baseline_sizes_against_reference_golden(golden_dir, gtag, mtag):
     """The sizes that distinguish the BASELINE configs, one full reference step each (forward, every loss, backward, Adam):
