@@ -784,8 +784,20 @@ static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // geometry of conv3x3_wino_sp_kernel (conv_wino.h): dense 3x3, stride 1, pad 1, 16 x 16-pixel tiles x 64 output channels, h3 scheme.  Its
 // 64-channel tile also takes Cout == 64 (the direct split kernels need more than 64: their tiles are 128 wide) and, through XFORM = 3,
 // any fused activation (LeakyReLU / ReLU on load: the VGG16 convs of LPIPS, losses/lpips.py:74-96).
+// Conv modes that have a Winograd kernel for this conv: h3 always; the one-plane 16-bit modes h1 / b1 (round 5) where the wide tiling
+// applies (Cout % 128 == 0) -- FAVAE_WINO1=0 keeps those modes on the direct kernels (A/B).
+static bool use_wino1() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FAVAE_WINO1"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+static bool use_wino_wide();
+static bool wino_mode(const favae_conv_desc* d) {
+    const int m = conv_mode();
+    return m == 2 || ((m == 1 || m == 4) && use_wino1() && use_wino_wide() && d->Cout % 128 == 0);
+}
 static bool wino_geometry(const favae_conv_desc* d) {
-    return use_wino() && conv_mode() == 2 && !desc_special(d) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
+    return use_wino() && wino_mode(d) && !desc_special(d) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
            d->gather == FAVAE_GATHER_PLAIN && d->Hout == d->Hin && d->Wout == d->Win && d->Hin % 16 == 0 && d->Win % 16 == 0 &&
            d->Cout % 64 == 0 && d->Cin % 16 == 0;
 }
@@ -972,7 +984,7 @@ static bool wino_ok(const favae_conv_desc* d, bool has_affine);
 static bool wino4_ok(const favae_conv_desc* d, bool has_affine);
 // planes word of a call that passes Winograd records: F(2x2) records go with wino_ok, F(4x4) records (FAVAE_PLANES_WINO4 on top) with wino4_ok
 static bool wino_planes_ok(const favae_conv_desc* d, int planes, bool has_affine) {
-    if (planes == (2 | FAVAE_PLANES_WINO)) return wino_ok(d, has_affine);
+    if (planes == (conv_mode() | FAVAE_PLANES_WINO)) return wino_ok(d, has_affine);          // 2 (h3), 1 (h1) or 4 (b1) | the flag
     if (planes == (2 | FAVAE_PLANES_WINO | FAVAE_PLANES_WINO4)) return wino4_ok(d, has_affine);
     return false;
 }
@@ -982,7 +994,7 @@ extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, co
     if (!sp_fwd_eligible(d, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (planes & FAVAE_PLANES_WINO) {
         if (!wino_planes_ok(d, planes, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-        FAVAE_REQUIRE(wsplit && x_absmax);
+        FAVAE_REQUIRE(wsplit && (x_absmax || (planes & 0xff) == 4));
     } else {
         FAVAE_REQUIRE(wsplit && (planes == 3 || planes == 4 || ((planes == 2 || planes == 1) && x_absmax)));
     }
@@ -1015,7 +1027,7 @@ static bool halo3_fp16_ok(const favae_conv_desc* d, bool has_affine) {
 // Dense 3x3 convs of the h3 scheme whose shape tiles into 16 x 16 pixels x 64 output channels run conv3x3_wino_sp_kernel
 // (conv_wino.h): the caller then passes Winograd weight records (favae_wino_weights) and planes = 2 | FAVAE_PLANES_WINO.
 static bool wino_ok(const favae_conv_desc* d, bool has_affine) {
-    return use_wino() && conv_mode() == 2 && halo3_fp16_ok(d, has_affine) && d->Hin % 16 == 0 && d->Win % 16 == 0 && d->Cout % 64 == 0 &&
+    return use_wino() && wino_mode(d) && halo3_fp16_ok(d, has_affine) && d->Hin % 16 == 0 && d->Win % 16 == 0 && d->Cout % 64 == 0 &&
            (size_t)d->Cout * d->Cin * 64 < (1u << 31) && (!has_affine || d->Cin <= wino::AFF_C);
 }
 
@@ -1045,7 +1057,7 @@ static bool use_wino4() {
     return g_wino4 == 1;
 }
 static bool wino4_ok(const favae_conv_desc* d, bool has_affine) {
-    return use_wino4() && wino_ok(d, has_affine) && d->Win % 32 == 0 && d->Cin % 64 == 0 && d->Cin <= 736 &&
+    return use_wino4() && conv_mode() == 2 && wino_ok(d, has_affine) && d->Win % 32 == 0 && d->Cin % 64 == 0 && d->Cin <= 736 &&
            (size_t)d->Cout * d->Cin * 144 < (1u << 31);
 }
 extern "C" int favae_conv_wino4_ok(const favae_conv_desc* d, int has_affine) { return desc_ok(d) && wino4_ok(d, has_affine != 0) ? 1 : 0; }
@@ -1100,9 +1112,10 @@ extern "C" size_t favae_wino_weights_bytes(int Cout, int Cin) {
 // planes, in MFMA fragment order.  flip = 0: the forward conv (Cout outputs); flip = 1: its data gradient (Cin outputs, taps
 // flipped).  amax: device float max|w| (nullptr: computed here).  The header (float[0]) holds max|w|.
 extern "C" int favae_wino_weights(const float* w, void* out, int Cout, int Cin, int flip, const float* amax, favae_stream_t stream) {
-    FAVAE_REQUIRE(w && out && favae_wino_weights_bytes(Cout, Cin) && (((uintptr_t)out) & 15) == 0 && flip >= 0 && flip <= 3);
+    FAVAE_REQUIRE(w && out && favae_wino_weights_bytes(Cout, Cin) && (((uintptr_t)out) & 15) == 0 && flip >= 0 && flip <= 5);
     const int vec = (((uintptr_t)w) & 15) == 0 ? 1 : 0;
     const bool f43 = (flip & 2) != 0;            // bit 1: F(4x4, 3x3) records (favae_wino4_weights_bytes) for conv3x3_wino4_sp_kernel
+    const bool bf = (flip & 4) != 0;             // bit 2: F(2x2) records with a bf16 head plane (the one-plane bf16 mode b1)
     flip &= 1;
     FAVAE_REQUIRE(flip ? (Cin % 64 == 0 && Cout % 16 == 0) : (Cout % 64 == 0 && Cin % 16 == 0));
     hipStream_t s = (hipStream_t)stream;
@@ -1122,7 +1135,9 @@ extern "C" int favae_wino_weights(const float* w, void* out, int Cout, int Cin, 
         FAVAE_CHECK_LAUNCH();
         return FAVAE_OK;
     }
-    if (flip) FAVAE_KLAUNCH((wino_weights_kernel<true>), dim3(blocks), dim3(256), 0, s, w, (unsigned char*)out + sp::WHDR, Cout, Cin, amax, hdr, vec);
+    if (bf && flip) FAVAE_KLAUNCH((wino_weights_kernel<true, true>), dim3(blocks), dim3(256), 0, s, w, (unsigned char*)out + sp::WHDR, Cout, Cin, amax, hdr, vec);
+    else if (bf) FAVAE_KLAUNCH((wino_weights_kernel<false, true>), dim3(blocks), dim3(256), 0, s, w, (unsigned char*)out + sp::WHDR, Cout, Cin, amax, hdr, vec);
+    else if (flip) FAVAE_KLAUNCH((wino_weights_kernel<true>), dim3(blocks), dim3(256), 0, s, w, (unsigned char*)out + sp::WHDR, Cout, Cin, amax, hdr, vec);
     else FAVAE_KLAUNCH((wino_weights_kernel<false>), dim3(blocks), dim3(256), 0, s, w, (unsigned char*)out + sp::WHDR, Cout, Cin, amax, hdr, vec);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;
@@ -1181,12 +1196,14 @@ extern "C" int favae_conv_fwd_split_stats(const favae_conv_desc* d, const float*
                                           const float* x_absmax, const float* bias, const float* resid, const float* scale,
                                           const float* shift, float* y, void* part, size_t part_bytes, float* y_absmax,
                                           favae_stream_t stream) {
-    FAVAE_REQUIRE(desc_ok(d) && wsplit && (x_absmax || planes == 4) && part);
+    FAVAE_REQUIRE(desc_ok(d) && wsplit && (x_absmax || (planes & 0xff) == 4) && part);
     const int tiles = favae_conv_stats_tiles(d, scale != nullptr, planes);
-    // the tile grid of the partial sums is the kernel's: Winograd records go with the Winograd kernel's 16 x 16 tiles and nothing else
-    if (((planes & FAVAE_PLANES_WINO) != 0) != wino_ok(d, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    // the tile grid of the partial sums is the kernel's: Winograd records go with the Winograd kernel's tiles and nothing else.  In the
+    // one-plane modes the caller chooses between the Winograd and the direct kernel per call (both have the 16 x 8 grid there)
+    if (((planes & FAVAE_PLANES_WINO) != 0) != wino_ok(d, scale != nullptr) && !(conv_mode() != 2 && !(planes & FAVAE_PLANES_WINO)))
+        return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (planes & FAVAE_PLANES_WINO) planes = wino_planes_ok(d, planes, scale != nullptr) ? planes : 0;
-    if (!tiles || ((planes & 0xff) != 2 && planes != 1 && planes != 4)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (!tiles || ((planes & 0xff) != 2 && (planes & 0xff) != 1 && (planes & 0xff) != 4)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     if (y_absmax && favae_zero_target(y_absmax, sizeof(float), (hipStream_t)stream) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
     return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr, nullptr,
@@ -1197,11 +1214,12 @@ extern "C" int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy,
                                       const float* dy_absmax, float* da, const float* x, const float* mean, const float* rstd,
                                       const float* gamma, const float* beta, int groups, int act, void* part, size_t part_bytes,
                                       favae_stream_t stream) {
-    FAVAE_REQUIRE(desc_ok(d) && dy && wsplit && (dy_absmax || planes == 4) && da && x && mean && rstd && gamma && beta && part && groups > 0);
+    FAVAE_REQUIRE(desc_ok(d) && dy && wsplit && (dy_absmax || (planes & 0xff) == 4) && da && x && mean && rstd && gamma && beta && part && groups > 0);
     const int tiles = favae_conv_gnbwd_tiles(d, planes);
-    if (((planes & FAVAE_PLANES_WINO) != 0) != wino_ok(d, false)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (((planes & FAVAE_PLANES_WINO) != 0) != wino_ok(d, false) && !(conv_mode() != 2 && !(planes & FAVAE_PLANES_WINO)))
+        return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (planes & FAVAE_PLANES_WINO) planes = wino_planes_ok(d, planes, false) ? planes : 0;
-    if (!tiles || ((planes & 0xff) != 2 && planes != 1 && planes != 4) || d->Cout % groups != 0) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (!tiles || ((planes & 0xff) != 2 && (planes & 0xff) != 1 && (planes & 0xff) != 4) || d->Cout % groups != 0) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     GnBwdEpi gb{x, mean, rstd, gamma, beta, (double*)part, groups, act};
     return conv_fwd_impl(d, dy, (const float*)wsplit, nullptr, nullptr, nullptr, nullptr, da, planes, dy_absmax, stream, nullptr, &gb);
@@ -1337,7 +1355,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     // that would read them as fp32 weights
     if (w6 && !wino && bn != 128) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (wino) {
-        if (!(!special && buf_ok && use_b6() && w6 && wino_geometry(d) && wplanes == 2 && !planes_out && d->w_rec_offset == 0))
+        if (!(!special && buf_ok && use_b6() && w6 && wino_geometry(d) && wplanes == conv_mode() && !planes_out && d->w_rec_offset == 0))
             return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (gb && (xf != 0 || bias || resid)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (stats_part && !(xf == 0 || xf == 2)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
@@ -1369,26 +1387,29 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
             return FAVAE_OK;
         }
         const bool wide = wino_wide_ok(d, scale != nullptr);      // 16 x 8 pixels x 128 channels per workgroup
+        if (wplanes != 2 && !wide) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         const int wth = wide ? 8 : 16;
         a.tiles_n = d->Cout / (wide ? 128 : 64);
         a.w_bytes = (unsigned)((size_t)d->Cout * d->Cin * 64);
         auto rcp32 = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };   // 0: divisor 1
         a.wino_rcp_n = rcp32(a.tiles_n); a.wino_rcp_w = rcp32(d->Win / 16); a.wino_rcp_h = rcp32(d->Hin / wth);
         const dim3 wgrid((unsigned)(d->N * (d->Hin / wth) * (d->Win / 16) * a.tiles_n));
-#define FAVAE_LAUNCH_WINO_T(X, GBV, SEV, WD)                                                                                \
+#define FAVAE_LAUNCH_WINO_T(X, GBV, SEV, WD, PL)                                                                            \
     do {                                                                                                                    \
         static bool attr_set = false;                                                                                       \
         if (!attr_set) {                                                                                                    \
-            (void)hipFuncSetAttribute((const void*)conv3x3_wino_sp_kernel<X, GBV, SEV, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)conv3x3_wino_sp_kernel<X, GBV, SEV, WD, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       wino::LDS_B);                                                                         \
             attr_set = true;                                                                                                \
         }                                                                                                                   \
-        FAVAE_KLAUNCH((conv3x3_wino_sp_kernel<X, GBV, SEV, WD>), wgrid, dim3(512), wino::LDS_B, s, a);                      \
+        FAVAE_KLAUNCH((conv3x3_wino_sp_kernel<X, GBV, SEV, WD, PL>), wgrid, dim3(512), wino::LDS_B, s, a);                  \
     } while (0)
 #define FAVAE_LAUNCH_WINO(X, GBV, SEV)                                                                                      \
     do {                                                                                                                    \
-        if (wide) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true);                                                                   \
-        else FAVAE_LAUNCH_WINO_T(X, GBV, SEV, false);                                                                       \
+        if (wplanes == 1) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 1);        /* one fp16 plane (h1): wide tiling only */     \
+        else if (wplanes == 4) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 4);   /* one bf16 plane (b1) */                        \
+        else if (wide) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 2);                                                           \
+        else FAVAE_LAUNCH_WINO_T(X, GBV, SEV, false, 2);                                                                    \
     } while (0)
         if (gb) FAVAE_LAUNCH_WINO(0, true, false);
         else if (stats_part && xf == 0) FAVAE_LAUNCH_WINO(0, false, true);

@@ -63,8 +63,23 @@ __device__ __forceinline__ float minus_hi_half(unsigned h, float v) {      // v 
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
     return r;
 }
-template <int PLB = VPL>
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {     // gfx950: packed fp32 -> bf16, round to nearest even
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// PLN = operand scheme of the conv mode: 2 = (hi, lo) fp16 planes (h3); 1 = ONE fp16 plane (h1); 4 = ONE bf16 plane (b1) -- the
+// one-plane modes store the head plane only (the second plane's slot stays unused)
+template <int PLB = VPL, int PLN = 2>
 __device__ __forceinline__ void split_store(unsigned char* dst, const float4 t) {
+    if constexpr (PLN == 1) {
+        *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pk_f16(t.x, t.y), cvt_pk_f16(t.z, t.w));
+        return;
+    }
+    if constexpr (PLN == 4) {
+        *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pk_bf16(t.x, t.y), cvt_pk_bf16(t.z, t.w));
+        return;
+    }
     const unsigned h01 = cvt_pk_f16(t.x, t.y), h23 = cvt_pk_f16(t.z, t.w);
     const unsigned l01 = cvt_pk_f16(minus_lo_half(h01, t.x), minus_hi_half(h01, t.y));
     const unsigned l23 = cvt_pk_f16(minus_lo_half(h23, t.z), minus_hi_half(h23, t.w));
@@ -80,7 +95,9 @@ __device__ __forceinline__ float4 add4(const float4 p, const float4 q) { return 
 //   FLIP = true : O = Cin,  I = Cout, g[o][kh][kw][i] = w[i][2 - kh][2 - kw][o]    (data gradient)
 // out (behind the header): U = G g G^T scaled by S_U = HEAD * 2^(14 - floor(log2 max|w|)), split into (hi, lo) fp16 planes, in MFMA
 // B-fragment order: [o / 64][i / 16][b][a][(o / 32) & 1][plane][lane = (o & 31) + 32 ((i / 8) & 1)][8 k].  One thread per (o, 8 i).
-template <bool FLIP>
+// BF (flip bit 2, round 5): the head plane holds bf16(U) instead of fp16(U) and the second plane zeros -- the records of the one-plane
+// bf16 mode (b1); the one-plane fp16 mode (h1) reads the head plane of the ordinary records.
+template <bool FLIP, bool BF = false>
 __device__ __forceinline__ void wino_weights_body(const float* __restrict__ w, unsigned char* __restrict__ out, int Cout, int Cin,
                                                   const float* __restrict__ amax, float* __restrict__ hdr_out, int vec, int idx) {
     const int O = FLIP ? Cin : Cout, I = FLIP ? Cout : Cin;
@@ -89,7 +106,7 @@ __device__ __forceinline__ void wino_weights_body(const float* __restrict__ w, u
     if (idx >= O * I8) return;
     // FLIP: consecutive threads -> consecutive o (= ci, contiguous in w); else consecutive 8-channel groups of i
     const int o = FLIP ? idx % O : idx / I8, i8 = FLIP ? idx / O : idx % I8;
-    const float S = sp::pow2_scale(amax) * wino::HEAD;
+    const float S = BF ? 1.f : sp::pow2_scale(amax) * wino::HEAD;
     float g[3][3][8];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
@@ -128,8 +145,14 @@ __device__ __forceinline__ void wino_weights_body(const float* __restrict__ w, u
             for (int e = 0; e < 8; ++e) {
                 const float u = b == 0 ? t[0][e] : b == 3 ? t[2][e]
                               : b == 1 ? 0.5f * (t[0][e] + t[1][e] + t[2][e]) : 0.5f * (t[0][e] - t[1][e] + t[2][e]);
-                hi[e] = (_Float16)u;
-                lo[e] = (_Float16)(u - (float)hi[e]);
+                if constexpr (BF) {
+                    const unsigned short hb = (unsigned short)(sp::Scheme<4>::rne_hi(u) >> 16);
+                    hi[e] = __builtin_bit_cast(_Float16, hb);
+                    lo[e] = (_Float16)0.f;
+                } else {
+                    hi[e] = (_Float16)u;
+                    lo[e] = (_Float16)(u - (float)hi[e]);
+                }
             }
             unsigned char* d = base + (size_t)b * wino::UCH + a * 4096;
             *reinterpret_cast<half8_t*>(d) = half8_t{hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
@@ -138,10 +161,10 @@ __device__ __forceinline__ void wino_weights_body(const float* __restrict__ w, u
     }
 }
 
-template <bool FLIP>
+template <bool FLIP, bool BF = false>
 __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, int Cout, int Cin,
                                                            const float* __restrict__ amax, float* __restrict__ hdr_out, int vec) {
-    wino_weights_body<FLIP>(w, out, Cout, Cin, amax, hdr_out, vec, blockIdx.x * 256 + threadIdx.x);
+    wino_weights_body<FLIP, BF>(w, out, Cout, Cin, amax, hdr_out, vec, blockIdx.x * 256 + threadIdx.x);
 }
 
 template <bool FLIP>
@@ -163,6 +186,11 @@ __global__ __launch_bounds__(256) void wino_weights_grouped_kernel(const WinoJob
     if (j.flip & 2) {                               // bit 1: F(4x4, 3x3) records (conv_wino4.h)
         if (j.flip & 1) wino4_weights_body<true>(j.w, j.out + sp::WHDR, j.Cout, j.Cin, j.amax, reinterpret_cast<float*>(j.out), vec, idx);
         else wino4_weights_body<false>(j.w, j.out + sp::WHDR, j.Cout, j.Cin, j.amax, reinterpret_cast<float*>(j.out), vec, idx);
+        return;
+    }
+    if (j.flip & 4) {                               // bit 2: bf16 head plane (one-plane bf16 mode)
+        if (j.flip & 1) wino_weights_body<true, true>(j.w, j.out + sp::WHDR, j.Cout, j.Cin, j.amax, reinterpret_cast<float*>(j.out), vec, idx);
+        else wino_weights_body<false, true>(j.w, j.out + sp::WHDR, j.Cout, j.Cin, j.amax, reinterpret_cast<float*>(j.out), vec, idx);
         return;
     }
     if (j.flip) wino_weights_body<true>(j.w, j.out + sp::WHDR, j.Cout, j.Cin, j.amax, reinterpret_cast<float*>(j.out), vec, idx);
@@ -191,8 +219,13 @@ __device__ unsigned long long g_wino_trace[64 * 8 * 48 * 8];
 // 64-channel workgroup: the vector work per output is 0.5-0.56 x, the price is twice the weight fragments streamed from L2 per wave
 // (each wave reads both 32-channel blocks of its 64).  Transform item = (tile, channel quad, row r of B^T d B): two patch rows per
 // thread instead of three.  Arithmetic, summation order and therefore the result bits are those of the 64-channel tiling.
-template <int XFORM, bool GB, bool SE, bool WIDE = false>
+//
+// PLN (round 5): operand scheme -- 2 = two scaled fp16 planes, three products (h3, fp32-grade); 1 / 4 = ONE fp16 / bf16 plane, one product
+// (the 16-bit mixed-precision modes h1 / b1, WIDE only): a third of the MFMAs, a quarter of the split instructions, half the fragments.
+template <int XFORM, bool GB, bool SE, bool WIDE = false, int PLN = 2>
 __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
+    static_assert(PLN == 2 || ((PLN == 1 || PLN == 4) && WIDE), "one-plane modes: the wide tiling only");
+    constexpr int NP = PLN == 2 ? 2 : 1;           // operand planes
     static_assert(!GB || XFORM == 0, "GroupNorm-backward sums: plain data gradient");
     static_assert(!(GB && SE), "one statistics epilogue at a time");
     using namespace wino;
@@ -225,7 +258,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     const int n = (int)sp3;
     const int n0 = tn * NCO;
     const int q4 = tid & 3;
-    const float Sa = sp::pow2_scale(a.x_amax) * HEAD;
+    // the bf16 plane of the b1 mode has fp32's exponent range: no operand scaling (and no range bound asked of the caller)
+    const float Sa = PLN == 4 ? 1.f : sp::pow2_scale(a.x_amax) * HEAD;
 
     const auto rx = make_rsrc(a.x, a.x_bytes);
     const auto rw = make_rsrc(a.w, a.w_bytes);
@@ -321,10 +355,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
                 for (int c = 0; c < 4; ++c) X[c] = sub4(pr[0][c], pr[1][c]);
             }
             unsigned char* vx = vbase + buf * VB + th * 4 * 2 * PLB;
-            split_store<PLB>(vx + 0 * 2 * PLB, sub4(X[0], X[2]));
-            split_store<PLB>(vx + 1 * 2 * PLB, add4(X[1], X[2]));
-            split_store<PLB>(vx + 2 * 2 * PLB, sub4(X[2], X[1]));
-            split_store<PLB>(vx + 3 * 2 * PLB, sub4(X[1], X[3]));
+            split_store<PLB, PLN>(vx + 0 * 2 * PLB, sub4(X[0], X[2]));
+            split_store<PLB, PLN>(vx + 1 * 2 * PLB, add4(X[1], X[2]));
+            split_store<PLB, PLN>(vx + 2 * 2 * PLB, sub4(X[2], X[1]));
+            split_store<PLB, PLN>(vx + 3 * 2 * PLB, sub4(X[1], X[3]));
         } else {
             float4 O[4];
 #pragma unroll
@@ -338,14 +372,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
             }
             unsigned char* vx = vbase + buf * VB + (th ? 3 : 0) * 4 * 2 * PLB;
             unsigned char* vo = vbase + buf * VB + (th ? 2 : 1) * 4 * 2 * PLB;
-            split_store<PLB>(vx + 0 * 2 * PLB, sub4(X[0], X[2]));
-            split_store<PLB>(vx + 1 * 2 * PLB, add4(X[1], X[2]));
-            split_store<PLB>(vx + 2 * 2 * PLB, sub4(X[2], X[1]));
-            split_store<PLB>(vx + 3 * 2 * PLB, sub4(X[1], X[3]));
-            split_store<PLB>(vo + 0 * 2 * PLB, sub4(O[0], O[2]));
-            split_store<PLB>(vo + 1 * 2 * PLB, add4(O[1], O[2]));
-            split_store<PLB>(vo + 2 * 2 * PLB, sub4(O[2], O[1]));
-            split_store<PLB>(vo + 3 * 2 * PLB, sub4(O[1], O[3]));
+            split_store<PLB, PLN>(vx + 0 * 2 * PLB, sub4(X[0], X[2]));
+            split_store<PLB, PLN>(vx + 1 * 2 * PLB, add4(X[1], X[2]));
+            split_store<PLB, PLN>(vx + 2 * 2 * PLB, sub4(X[2], X[1]));
+            split_store<PLB, PLN>(vx + 3 * 2 * PLB, sub4(X[1], X[3]));
+            split_store<PLB, PLN>(vo + 0 * 2 * PLB, sub4(O[0], O[2]));
+            split_store<PLB, PLN>(vo + 1 * 2 * PLB, add4(O[1], O[2]));
+            split_store<PLB, PLN>(vo + 2 * 2 * PLB, sub4(O[2], O[1]));
+            split_store<PLB, PLN>(vo + 3 * 2 * PLB, sub4(O[1], O[3]));
         }
     };
 
@@ -358,14 +392,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     const int KC = a.Cin / 16, KL = KC - 1;
     // WIDE: the wave's 64 output channels are the 64-channel record tile 2 tn + wc, both 32-channel blocks
     constexpr int NCB = WIDE ? 2 : 1;
-    half8_t bfr[4][NCB][2];
+    half8_t bfr[4][NCB][NP];
     auto load_b = [&](int kc, int ar) {
         const unsigned so = WIDE ? (unsigned)((((tn * 2 + wc) * KC + kc) * 4 + wb) * UCH + ar * 4096)
                                  : (unsigned)(((tn * KC + kc) * 4 + wb) * UCH + ar * 4096 + wc * 2048);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 bfr[ar][cb][pl] = __builtin_bit_cast(half8_t, bload(rw, vw, so + (unsigned)(cb * 2048 + pl * 1024)));
     };
     f32x16 acc[4][2];
@@ -374,12 +408,27 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     auto mma = [&](int buf, int ar, auto first_c) { // smallest terms first; the two row blocks alternate between dependent MFMAs
         constexpr bool FIRST = decltype(first_c)::value != 0;
         constexpr int NRB = WIDE ? 1 : 2;           // row blocks of 32 tiles; acc[ar][x]: x = row block, WIDE: x = channel block
-        half8_t af[NRB][2];
+        half8_t af[NRB][NP];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 af[rb][pl] = *reinterpret_cast<const half8_t*>(Afr + buf * VB + (ar * 4 * 2 + pl) * PLB + rb * 1024);
+        if constexpr (NP == 1) {                    // one product per block
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                f32x16 c;
+                if constexpr (FIRST) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+                } else c = acc[ar][rb];
+                if constexpr (PLN == 4)
+                    acc[ar][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[0][0]),
+                                                                          __builtin_bit_cast(bf16x8_t, bfr[ar][rb][0]), c, 0, 0, 0);
+                else acc[ar][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bfr[ar][rb][0], c, 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int p3 = 0; p3 < 3; ++p3) {
             const int pa = p3 == 0 ? 1 : 0, pb = p3 == 1 ? 1 : 0;
@@ -392,7 +441,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
                         for (int r = 0; r < 16; ++r) c[r] = 0.f;
                     } else c = acc[ar][rb];
                 } else c = acc[ar][rb];
-                acc[ar][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[WIDE ? 0 : rb][pa], bfr[ar][WIDE ? rb : 0][pb], c, 0, 0, 0);
+                acc[ar][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[WIDE ? 0 : rb][NP == 2 ? pa : 0], bfr[ar][WIDE ? rb : 0][NP == 2 ? pb : 0], c, 0, 0, 0);
             }
         }
     };
@@ -408,7 +457,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
 #ifndef FAVAE_WIDE_AHEAD
 #define FAVAE_WIDE_AHEAD 3
 #endif
-    constexpr int NB_AHEAD = WIDE ? FAVAE_WIDE_AHEAD : 4;
+    constexpr int NB_AHEAD = (WIDE && PLN == 2) ? FAVAE_WIDE_AHEAD : 4;
 #pragma unroll
     for (int ar = 0; ar < NB_AHEAD; ++ar) load_b(0, ar);
     if (XFORM) {
@@ -508,7 +557,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     // ---- epilogue: t[i][wb] = sum_a A^T[i][a] M[a][wb] in registers (A^T = [[1,1,1,0],[0,1,-1,-1]]), exchanged through LDS.
     // Thread (co = lane, tile group wid) then finishes 8 tiles x 2 x 2 outputs; a wave stores 64 consecutive channels of one pixel
     // (256 bytes).  Offsets are scalar per pixel (buffer soffset) + one constant voffset: no 64-bit address arithmetic.
-    const float un = sp::pow2_inv(Sa) * sp::pow2_inv(sp::pow2_scale(a.w_amax) * HEAD);
+    const float un = PLN == 4 ? 1.f : sp::pow2_inv(Sa) * sp::pow2_inv(sp::pow2_scale(a.w_amax) * HEAD);
     const int fco = WIDE ? (wid & 1) * 64 + lane : lane;                 // finishing role: channel of the tile, tile row
     const int frow = WIDE ? wid >> 1 : wid;
     const int col = n0 + fco;

@@ -290,7 +290,16 @@ class WinoRecords:
         """record store + device job table, on the first refresh that needs them (64 bytes per (Cout, Cin) pair and direction, 144 for the
         F(4x4) records: ~1 GB for the f=16 model -- not spent when the conv mode is not h3 or the Winograd path is off)"""
         from . import WinoJob
-        sizes = [int(query("favae_wino4_weights_bytes" if key & 2 else "favae_wino_weights_bytes", co, ci)) for (p, key, co, ci) in self._jobs]
+        # the records a mode reads: h3 / h1 the fp16 ones (h1: their head plane), b1 those with a bf16 head plane (key | 4, asked for by the
+        # conv launches through want())
+        bf = 4 if get_conv_mode() == "b1" else 0
+        self._mode_bf = bf
+        jobs = [j for j in self._jobs if (j[1] & 4) == bf]
+        self._njobs = len(jobs)
+        if not jobs:
+            self.store, self.bufs, self._dirty = None, {}, False
+            return
+        sizes = [int(query("favae_wino4_weights_bytes" if key & 2 else "favae_wino_weights_bytes", co, ci)) for (p, key, co, ci) in jobs]
         offs, nbytes = [], 0
         for sz in sizes:
             offs.append(nbytes)
@@ -298,9 +307,9 @@ class WinoRecords:
         self.nbytes = nbytes
         self.store = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
         self.bufs = {}
-        arr = (WinoJob * self.n)()
+        arr = (WinoJob * len(jobs))()
         block_job, b0 = [], 0
-        for k, (p, key, co, ci) in enumerate(self._jobs):
+        for k, (p, key, co, ci) in enumerate(jobs):
             wm, i = p._favae_wmax
             nb = (co * ci // 8 + 255) // 256
             arr[k].w, arr[k].out, arr[k].amax = p.data_ptr(), self.store.data_ptr() + offs[k], wm.out[i:i + 1].data_ptr()
@@ -315,11 +324,15 @@ class WinoRecords:
 
     def refresh(self):
         on = bool(query("favae_get_wino"))
-        if not self.n or not on or get_conv_mode() != "h3":
+        mode = get_conv_mode()
+        if not self.n or not on or mode not in ("h3", "h1", "b1"):
             self.versions = {}
             return
-        if self.store is None or self._dirty:
+        if self.store is None or self._dirty or getattr(self, "_mode_bf", None) != (4 if mode == "b1" else 0):
             self._materialize()
+        if not getattr(self, "_njobs", 0):
+            self.versions = {}
+            return
         call("favae_wino_weights_grouped", ptr(self.jobs), ptr(self.block_job), self.nblocks)
         self.versions = {id(p): _weights_key(p) for p in self.params}
 
@@ -333,7 +346,7 @@ def _wino_cached(w, flip):
     wr = getattr(w, "_favae_wino", None)
     if wr is None:
         return None
-    if flip & 2:
+    if flip & 6:
         wr.want(w, flip)
     return wr.get(w, flip)
 
@@ -377,6 +390,17 @@ def set_wino_wide(on):
 
 
 _WINO4_FWD_MINPIX = int(os.environ.get("FAVAE_WINO4_FWD_MINPIX", "65536"))   # forward: only where it measured faster (128 -> 128 @256^2: 1.12 x)
+
+
+# One-plane Winograd (csrc/conv_wino.h PLN = 1 / 4) in the 16-bit mixed-precision modes: h1 (one fp16 plane) everywhere the kernel applies;
+# b1 (one bf16 plane) on the DATA GRADIENTS only -- B^T d B in bf16 costs 1.65 x the direct bf16 conv's error, and with the forward convs on
+# it the step leaves what the REFERENCE does under bf16 autocast (cfg5_256: 14 index flips / loss_l1 7.0e-3 against 12 / 2.4e-3; the direct
+# kernels: 6 / 7.8e-4).  FAVAE_WINO1_FWD=1 forces the forward convs too (experiments).
+_WINO1_FWD = os.environ.get("FAVAE_WINO1_FWD", "0") == "1"
+
+
+def _wino1_wanted(planes, dgrad):
+    return planes != 4 or dgrad or _WINO1_FWD
 
 
 def _wino4_wanted(d, has_affine, dgrad):
@@ -802,8 +826,10 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
     Returns the device float holding max|w| when pre-split records were made (fp16 scheme), else None."""
     planes = query("favae_conv_wants_split_weights", byref(d), 0 if scale is None else 1)
     w_amax = None
-    if planes == 2 and planes_out is None and query("favae_conv_wino_ok", byref(d), 0 if scale is None else 1):
-        # dense 3x3 conv of the h3 scheme: Winograd F(2x2, 3x3) kernel, records = G g G^T in fragment order (csrc/conv_wino.h)
+    if (planes in (1, 2, 4) and planes_out is None and _wino1_wanted(planes, flip_of is not None or gnbwd is not None)
+            and query("favae_conv_wino_ok", byref(d), 0 if scale is None else 1)):
+        # dense 3x3 conv of the h3 scheme (and, where Cout % 128 == 0, of the one-plane 16-bit modes h1 / b1): Winograd F(2x2, 3x3) kernel,
+        # records = G g G^T in fragment order (csrc/conv_wino.h); h1 reads the head plane of the h3 records, b1 has bf16 ones (flip | 4)
         if wino_rec is not None:                 # made by the forward pass (FusedConvFn.forward)
             wsp, f43 = wino_rec
         else:
@@ -812,9 +838,11 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
                 flip = 1
             else:
                 w, co, ci, flip = w_ohwi, d.Cout, d.Cin, 0        # OHWI memory, whatever the logical shape
-            f43 = _wino4_wanted(d, scale is not None, flip == 1)
+            f43 = planes == 2 and _wino4_wanted(d, scale is not None, flip == 1)
             if f43:
                 flip |= 2
+            if planes == 4:
+                flip |= 4
             wsp = _wino_cached(w, flip)              # made for the whole model after the optimizer step (WinoRecords)
             if wsp is None:
                 if w_amax is None:
@@ -942,9 +970,10 @@ class FusedConvFn(torch.autograd.Function):
         if (_WINO_FLIP_FWD and w_amax is not None and cfg.stride == 1 and not cfg.upsample and cfg.kh == 3
                 and any(ctx.needs_input_grad) and (ctx.needs_input_grad[0] or gn_w is not None)):   # no backward (no_grad, eval): no records
             d2 = make_conv_desc(N, Ho, Wo, Cout, Hin, Win, Cin, cfg.kh, cfg.kw, 1, cfg.kh - 1 - cfg.pad, GATHER_PLAIN, ACT_NONE, 1)
-            if query("favae_conv_wants_split_weights", byref(d2), 0) == 2 and query("favae_conv_wino_ok", byref(d2), 0):
-                f43 = _wino4_wanted(d2, False, True)
-                key = 3 if f43 else 1
+            pl2 = query("favae_conv_wants_split_weights", byref(d2), 0)
+            if pl2 in (1, 2, 4) and _wino1_wanted(pl2, True) and query("favae_conv_wino_ok", byref(d2), 0):
+                f43 = pl2 == 2 and _wino4_wanted(d2, False, True)
+                key = (3 if f43 else 1) | (4 if pl2 == 4 else 0)
                 rec = _wino_cached(wk, key)
                 if rec is None:
                     rec = _wino_records(wk, Cout, Cin, key, w_amax)

@@ -538,6 +538,59 @@ def test_winograd_wide_tiling_is_bit_identical(K, N, cin, cout, H, W):
         assert float((u - v).abs().max()) <= 2e-6 * scale, "output %d: %.2e of the maximum" % (i, float((u - v).abs().max()) / scale)
 
 
+@pytest.mark.parametrize("mode,bar", [("h1", 1.5e-3), ("b1", 1.2e-2)])
+def test_one_plane_winograd_against_the_direct_one_plane_kernel(K, mode, bar):
+    """The 16-bit mixed-precision modes on the Winograd kernel (conv_wino.h PLN = 1 / 4: ONE fp16 / bf16 plane, one product, wide tiling):
+    forward (GroupNorm + SiLU fused, statistics epilogue feeding a second block), data gradient (GroupNorm-backward epilogue) and what flows
+    through them, against the fp32-grade h3 result -- within `bar` of each tensor's maximum and within 2.5 x the error of the direct
+    one-plane kernel of the same mode (B^T d B before the rounding costs 1.5-1.7 x).  b1 forward convs take the Winograd kernel only
+    under FAVAE_WINO1_FWD (ops._WINO1_FWD, set here): the product keeps them on the direct kernel (tests/test_gpu_model.py, b1 bar)."""
+    import favae_hip as H_
+    from ctypes import byref
+    torch.manual_seed(11)
+    d = dev()
+    N, cin, cout, H, W = 2, 128, 256, 32, 48
+    x = torch.randn(N, cin, H, W, device=d)
+    w = torch.randn(cout, cin, 3, 3, device=d) * math.sqrt(1.0 / (9 * cin))
+    w2 = torch.randn(128, cout, 3, 3, device=d) * math.sqrt(1.0 / (9 * cout))
+    b = torch.randn(cout, device=d) * 0.1
+    gw, gb = 1 + 0.2 * torch.randn(cin, device=d), 0.2 * torch.randn(cin, device=d)
+    gw2, gb2 = 1 + 0.2 * torch.randn(cout, device=d), 0.2 * torch.randn(cout, device=d)
+    gy = torch.randn(N, 128, H, W, device=d)
+    cfg = K.ConvCfg(3, 3, 1, 1, groups=16)
+
+    def run():
+        xg, wg, wg2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+        y = K.fused_conv(xg, wg, b, gw, gb, None, cfg)
+        z = K.fused_conv(y, wg2, None, gw2, gb2, None, cfg)
+        grads = torch.autograd.grad(z, [xg, wg, wg2], gy)
+        K.sync_side_stream()
+        torch.cuda.synchronize()
+        return [t.detach().double() for t in (y, z) + tuple(grads)]
+    ref = run()
+    prev_mode, prev_fwd = K.get_conv_mode(), K._WINO1_FWD
+    K.set_conv_mode(mode)
+    K._WINO1_FWD = True
+    try:
+        desc = H_.make_conv_desc(N, H, W, cin, H, W, cout, 3, 3, 1, 1, 0, 0, 1)
+        if not H_.query("favae_conv_wino_ok", byref(desc), 0):
+            pytest.skip("one-plane Winograd path switched off")
+        wino = run()
+        prev = H_.query("favae_set_wino", 0)
+        try:
+            direct = run()
+        finally:
+            H_.query("favae_set_wino", prev)
+    finally:
+        K._WINO1_FWD = prev_fwd
+        K.set_conv_mode(prev_mode)
+    for i, (r, u, v) in enumerate(zip(ref, wino, direct)):
+        s = float(r.abs().max())
+        eu, ev = float((u - r).abs().max()) / s, float((v - r).abs().max()) / s
+        assert eu <= bar, "output %d: Winograd %s errs %.2e of the maximum" % (i, mode, eu)
+        assert eu <= 2.5 * ev + 1e-5, "output %d: Winograd %s %.2e against the direct kernel's %.2e" % (i, mode, eu, ev)
+
+
 @pytest.mark.parametrize("switch", ["FAVAE_CONV_HALO", "FAVAE_WINO"])
 def test_cout64_conv_without_the_winograd_kernel(switch):
     """with the A/B switch that takes the Winograd kernel away a 64 -> 64 3x3 conv (the VGG16 convs of LPIPS) must
