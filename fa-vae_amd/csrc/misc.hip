@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void u8_norm_kernel(const unsigned char* __res
 
 }  // namespace
 
-extern "C" int favae_abi_version(void) { return 19; }
+extern "C" int favae_abi_version(void) { return 20; }
 
 extern "C" int favae_u8_to_float_nhwc(const unsigned char* in, float* out, int64_t pixels, int C, const float* mean, const float* std,
                                       favae_stream_t stream) {

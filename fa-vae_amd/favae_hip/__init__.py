@@ -21,7 +21,7 @@ if "GPU_MAX_HW_QUEUES" not in os.environ and not torch.cuda.is_initialized():
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FAVAE_HIP_LIB") or os.path.join(_HERE, "libfavae_hip.so")     # FAVAE_HIP_LIB: same-box A/B of two builds
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02, ACT_RELU = 0, 1, 2, 3
