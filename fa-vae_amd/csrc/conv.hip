@@ -794,7 +794,9 @@ static bool use_wino1() {
 static bool use_wino_wide();
 static bool wino_mode(const favae_conv_desc* d) {
     const int m = conv_mode();
-    return m == 2 || ((m == 1 || m == 4) && use_wino1() && use_wino_wide() && d->Cout % 128 == 0);
+    // h1: wherever the kernel tiles (64-channel convs -- the first VGG16 layers of LPIPS -- otherwise fall to the fp32-MFMA kernel);
+    // b1: only where the caller can still choose the direct bf16 kernel per call (the 128-channel tiles), see include/favae_hip.h
+    return m == 2 || (m == 1 && use_wino1() && d->Cout % 64 == 0) || (m == 4 && use_wino1() && use_wino_wide() && d->Cout % 128 == 0);
 }
 static bool wino_geometry(const favae_conv_desc* d) {
     return use_wino() && wino_mode(d) && !desc_special(d) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
@@ -1387,7 +1389,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
             return FAVAE_OK;
         }
         const bool wide = wino_wide_ok(d, scale != nullptr);      // 16 x 8 pixels x 128 channels per workgroup
-        if (wplanes != 2 && !wide) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+        if (wplanes == 4 && !wide) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         const int wth = wide ? 8 : 16;
         a.tiles_n = d->Cout / (wide ? 128 : 64);
         a.w_bytes = (unsigned)((size_t)d->Cout * d->Cin * 64);
@@ -1406,8 +1408,9 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     } while (0)
 #define FAVAE_LAUNCH_WINO(X, GBV, SEV)                                                                                      \
     do {                                                                                                                    \
-        if (wplanes == 1) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 1);        /* one fp16 plane (h1): wide tiling only */     \
-        else if (wplanes == 4) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 4);   /* one bf16 plane (b1) */                        \
+        if (wplanes == 1 && wide) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 1);     /* one fp16 plane (h1) */                   \
+        else if (wplanes == 1) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, false, 1);                                                  \
+        else if (wplanes == 4) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 4);   /* one bf16 plane (b1): wide tiling only */     \
         else if (wide) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 2);                                                           \
         else FAVAE_LAUNCH_WINO_T(X, GBV, SEV, false, 2);                                                                    \
     } while (0)

@@ -221,10 +221,11 @@ __device__ unsigned long long g_wino_trace[64 * 8 * 48 * 8];
 // thread instead of three.  Arithmetic, summation order and therefore the result bits are those of the 64-channel tiling.
 //
 // PLN (round 5): operand scheme -- 2 = two scaled fp16 planes, three products (h3, fp32-grade); 1 / 4 = ONE fp16 / bf16 plane, one product
-// (the 16-bit mixed-precision modes h1 / b1, WIDE only): a third of the MFMAs, a quarter of the split instructions, half the fragments.
+// (the 16-bit mixed-precision modes h1 / b1; b1 in the wide tiling only): a third of the MFMAs, a quarter of the split instructions,
+// half the fragments.
 template <int XFORM, bool GB, bool SE, bool WIDE = false, int PLN = 2>
 __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
-    static_assert(PLN == 2 || ((PLN == 1 || PLN == 4) && WIDE), "one-plane modes: the wide tiling only");
+    static_assert(PLN == 2 || PLN == 1 || (PLN == 4 && WIDE), "the bf16 plane: the wide tiling only");
     constexpr int NP = PLN == 2 ? 2 : 1;           // operand planes
     static_assert(!GB || XFORM == 0, "GroupNorm-backward sums: plain data gradient");
     static_assert(!(GB && SE), "one statistics epilogue at a time");
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
                 if constexpr (PLN == 4)
                     acc[ar][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[0][0]),
                                                                           __builtin_bit_cast(bf16x8_t, bfr[ar][rb][0]), c, 0, 0, 0);
-                else acc[ar][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bfr[ar][rb][0], c, 0, 0, 0);
+                else acc[ar][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[WIDE ? 0 : rb][0], bfr[ar][WIDE ? rb : 0][0], c, 0, 0, 0);
             }
             return;
         }

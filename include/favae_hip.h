@@ -126,12 +126,13 @@ int favae_set_wino(int on);            /* run-time override of FAVAE_WINO; retur
 int favae_set_wino_wide(int on);       /* run-time override of FAVAE_WINO_WIDE; returns the previous setting */
 int favae_get_wino(void);              /* the current setting, no side effect */
 /* One-plane Winograd (ABI 20): in the 16-bit mixed-precision modes (favae_set_conv_mode 1 = h1: ONE scaled fp16 plane; 4 = b1: ONE bf16
- * plane; BASELINE configs[4], train_favae.py:239-240) favae_conv_wino_ok is 1 as well where the 16 x 8 x 128 tiling applies
- * (Cout % 128 == 0; FAVAE_WINO1=0: never) -- the same kernel with one plane and ONE product per block.  The caller then passes
+ * plane; BASELINE configs[4], train_favae.py:239-240) favae_conv_wino_ok is 1 as well -- h1: wherever the kernel tiles (Cout % 64 == 0),
+ * b1: where the 16 x 8 x 128 tiling applies (Cout % 128 == 0); FAVAE_WINO1=0: never -- the same kernel with one plane and ONE product
+ * per block.  The caller then passes
  * planes = 1 | FAVAE_PLANES_WINO with the ordinary records (their head plane is read), or 4 | FAVAE_PLANES_WINO with records made by
  * favae_wino_weights with bit 2 of `flip` set (4 forward, 5 data gradient: bf16 head plane, unscaled; no operand bound is asked for).
- * In these two modes the caller may ALSO keep such a conv on the direct one-plane kernel (planes = 1 or 4 without the flag) call by
- * call: B^T d B before the rounding costs 1.5-1.7 x the direct kernel's error, and the Python host keeps the b1 forward convs direct. */
+ * In these two modes the caller may ALSO keep a conv with more than 64 output channels on the direct one-plane kernel (planes = 1 or 4
+ * without the flag) call by call: B^T d B before the rounding costs 1.5-1.7 x the direct kernel's error, and the Python host keeps the b1 forward convs direct. */
 /* Winograd F(4x4, 3x3) (csrc/conv_wino4.h, ABI 18): 36 instead of 64 multiplies per 16 outputs -- 0.56 x the matrix work and operand
  * splitting of the F(2x2) kernel, at 2.3e-6 rms (F(2x2): 3.6e-7) of the output range per conv.  Meant for results no codebook index
  * depends on: the data gradients (autograd of models/codec.py:38-46) and, by the caller's choice, decoder layers.

@@ -538,18 +538,20 @@ def test_winograd_wide_tiling_is_bit_identical(K, N, cin, cout, H, W):
         assert float((u - v).abs().max()) <= 2e-6 * scale, "output %d: %.2e of the maximum" % (i, float((u - v).abs().max()) / scale)
 
 
-@pytest.mark.parametrize("mode,bar", [("h1", 1.5e-3), ("b1", 1.2e-2)])
-def test_one_plane_winograd_against_the_direct_one_plane_kernel(K, mode, bar):
+@pytest.mark.parametrize("mode,cout,bar", [("h1", 256, 1.5e-3), ("b1", 256, 1.2e-2), ("h1", 64, 1.5e-3), ("h1", 192, 1.5e-3)])
+def test_one_plane_winograd_against_the_direct_one_plane_kernel(K, mode, cout, bar):
     """The 16-bit mixed-precision modes on the Winograd kernel (conv_wino.h PLN = 1 / 4: ONE fp16 / bf16 plane, one product, wide tiling):
     forward (GroupNorm + SiLU fused, statistics epilogue feeding a second block), data gradient (GroupNorm-backward epilogue) and what flows
     through them, against the fp32-grade h3 result -- within `bar` of each tensor's maximum and within 2.5 x the error of the direct
     one-plane kernel of the same mode (B^T d B before the rounding costs 1.5-1.7 x).  b1 forward convs take the Winograd kernel only
-    under FAVAE_WINO1_FWD (ops._WINO1_FWD, set here): the product keeps them on the direct kernel (tests/test_gpu_model.py, b1 bar)."""
+    under FAVAE_WINO1_FWD (ops._WINO1_FWD, set here): the product keeps them on the direct kernel (tests/test_gpu_model.py, b1 bar).
+    h1 also takes the 16 x 16 x 64 tiling (64 / 192 output channels: the first VGG16 convs of LPIPS would otherwise run the fp32-MFMA
+    kernel, which is what the "direct" arm then is -- only the absolute bar applies there)."""
     import favae_hip as H_
     from ctypes import byref
     torch.manual_seed(11)
     d = dev()
-    N, cin, cout, H, W = 2, 128, 256, 32, 48
+    N, cin, H, W = 2, 128, 32, 48
     x = torch.randn(N, cin, H, W, device=d)
     w = torch.randn(cout, cin, 3, 3, device=d) * math.sqrt(1.0 / (9 * cin))
     w2 = torch.randn(128, cout, 3, 3, device=d) * math.sqrt(1.0 / (9 * cout))
@@ -588,7 +590,8 @@ def test_one_plane_winograd_against_the_direct_one_plane_kernel(K, mode, bar):
         s = float(r.abs().max())
         eu, ev = float((u - r).abs().max()) / s, float((v - r).abs().max()) / s
         assert eu <= bar, "output %d: Winograd %s errs %.2e of the maximum" % (i, mode, eu)
-        assert eu <= 2.5 * ev + 1e-5, "output %d: Winograd %s %.2e against the direct kernel's %.2e" % (i, mode, eu, ev)
+        if cout % 128 == 0:
+            assert eu <= 2.5 * ev + 1e-5, "output %d: Winograd %s %.2e against the direct kernel's %.2e" % (i, mode, eu, ev)
 
 
 @pytest.mark.parametrize("switch", ["FAVAE_CONV_HALO", "FAVAE_WINO"])
