@@ -395,12 +395,15 @@ _WINO4_FWD_MINPIX = int(os.environ.get("FAVAE_WINO4_FWD_MINPIX", "65536"))   # f
 # One-plane Winograd (csrc/conv_wino.h PLN = 1 / 4) in the 16-bit mixed-precision modes: h1 (one fp16 plane) everywhere the kernel applies;
 # b1 (one bf16 plane) on the DATA GRADIENTS only -- B^T d B in bf16 costs 1.65 x the direct bf16 conv's error, and with the forward convs on
 # it the step leaves what the REFERENCE does under bf16 autocast (cfg5_256: 14 index flips / loss_l1 7.0e-3 against 12 / 2.4e-3; the direct
-# kernels: 6 / 7.8e-4).  FAVAE_WINO1_FWD=1 forces the forward convs too (experiments).
+# kernels: 6 / 7.8e-4).  The forward convs of the LPIPS feature extractor are the exception (see _wino1_wanted).  FAVAE_WINO1_FWD=1 forces every
+# forward conv too (experiments).
 _WINO1_FWD = os.environ.get("FAVAE_WINO1_FWD", "0") == "1"
 
 
-def _wino1_wanted(planes, dgrad):
-    return planes != 4 or dgrad or _WINO1_FWD
+def _wino1_wanted(planes, dgrad, act=ACT_NONE):
+    # ReLU on load = the frozen VGG16 of LPIPS (losses/lpips.py: the only ReLU convs): behind the reconstruction, no index, x_recon or
+    # reconstruction loss depends on it -- its forward convs take the Winograd kernel in b1 as well
+    return planes != 4 or dgrad or _WINO1_FWD or act == ACT_RELU
 
 
 def _wino4_wanted(d, has_affine, dgrad):
@@ -826,7 +829,7 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
     Returns the device float holding max|w| when pre-split records were made (fp16 scheme), else None."""
     planes = query("favae_conv_wants_split_weights", byref(d), 0 if scale is None else 1)
     w_amax = None
-    if (planes in (1, 2, 4) and planes_out is None and _wino1_wanted(planes, flip_of is not None or gnbwd is not None)
+    if (planes in (1, 2, 4) and planes_out is None and _wino1_wanted(planes, flip_of is not None or gnbwd is not None, d.act)
             and query("favae_conv_wino_ok", byref(d), 0 if scale is None else 1)):
         # dense 3x3 conv of the h3 scheme (and, where Cout % 128 == 0, of the one-plane 16-bit modes h1 / b1): Winograd F(2x2, 3x3) kernel,
         # records = G g G^T in fragment order (csrc/conv_wino.h); h1 reads the head plane of the h3 records, b1 has bf16 ones (flip | 4)
