@@ -10,9 +10,9 @@ sites = collections.Counter()
 import favae_hip as H_
 orig_call = K.call
 def spy_call(name, *args):
-    if name == "favae_absmax":                   # real launches only (K.absmax returns a producer's by-product when there is one)
+    if name in ("favae_absmax", "favae_gn_stats"):
         fr = [f for f in traceback.extract_stack()[:-1] if "favae" in f.filename or "models" in f.filename][-4:]
-        sites[(int(args[1]), " < ".join("%s:%d" % (os.path.basename(f.filename), f.lineno) for f in reversed(fr)))] += 1
+        sites[(name[6:], int(args[1]) if name == "favae_absmax" else tuple(int(v) for v in args[3:7]), " < ".join("%s:%d" % (os.path.basename(f.filename), f.lineno) for f in reversed(fr)))] += 1
     return orig_call(name, *args)
 K.call = spy_call
 import favae_hip; favae_hip.load()
@@ -32,6 +32,6 @@ ts.step(x)
 sites.clear()
 ts.step(x)
 torch.cuda.synchronize()
-for (shape, where), n in sorted(sites.items(), key=lambda kv: -kv[1]):
-    print(n, shape, where)
+for key, n in sorted(sites.items(), key=lambda kv: -kv[1]):
+    print(n, *key)
 print("total", sum(sites.values()))
