@@ -1041,6 +1041,12 @@ static bool use_wino_wide() {
     if (g_wino_wide < 0) { const char* e = getenv("FAVAE_WINO_WIDE"); g_wino_wide = (e && e[0] == '0') ? 0 : 1; }
     return g_wino_wide == 1;
 }
+// FAVAE_WINO_SKEW=0: the lock-step K loop of round 5 (A/B arm; conv_wino.h SKEW)
+static bool use_wino_skew() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("FAVAE_WINO_SKEW"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
 static bool wino_wide_ok(const favae_conv_desc* d, bool has_affine) {
     return use_wino_wide() && wino_ok(d, has_affine) && d->Cout % 128 == 0;
 }
@@ -1179,6 +1185,13 @@ static int wino_part_tiles(const favae_conv_desc* d, bool has_affine, int planes
     if (wino_wide_ok(d, has_affine)) return (d->Hout / 8) * (d->Wout / 16);
     return (d->Hout / 16) * (d->Wout / 16);
 }
+// One-plane modes let the caller pick the DIRECT kernel for a shape the Winograd kernel also takes (planes without FAVAE_PLANES_WINO).
+// The tile counts above are the Winograd kernel's; the direct kernel's grid is 16 x 8 pixels, which is the Winograd grid only in the
+// wide tiling.  Where the two differ (Cout % 128 != 0, or FAVAE_WINO_WIDE=0) the direct kernel would write twice the tiles the caller
+// sized `part` for: such a call is refused (tests/test_gpu_ops.py::test_one_plane_direct_stats_call_is_refused_off_the_wide_grid).
+static bool direct_grid_mismatch(const favae_conv_desc* d, int planes, bool has_affine) {
+    return conv_mode() != 2 && !(planes & FAVAE_PLANES_WINO) && wino_ok(d, has_affine) && !wino_wide_ok(d, has_affine);
+}
 extern "C" int favae_conv_gnbwd_tiles(const favae_conv_desc* d, int planes) {
     if (!desc_ok(d) || !halo3_fp16_ok(d, false)) return 0;
     if (wino_ok(d, false)) return wino_part_tiles(d, false, planes);
@@ -1204,6 +1217,7 @@ extern "C" int favae_conv_fwd_split_stats(const favae_conv_desc* d, const float*
     // one-plane modes the caller chooses between the Winograd and the direct kernel per call (both have the 16 x 8 grid there)
     if (((planes & FAVAE_PLANES_WINO) != 0) != wino_ok(d, scale != nullptr) && !(conv_mode() != 2 && !(planes & FAVAE_PLANES_WINO)))
         return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (direct_grid_mismatch(d, planes, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (planes & FAVAE_PLANES_WINO) planes = wino_planes_ok(d, planes, scale != nullptr) ? planes : 0;
     if (!tiles || ((planes & 0xff) != 2 && (planes & 0xff) != 1 && (planes & 0xff) != 4)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
@@ -1220,6 +1234,7 @@ extern "C" int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy,
     const int tiles = favae_conv_gnbwd_tiles(d, planes);
     if (((planes & FAVAE_PLANES_WINO) != 0) != wino_ok(d, false) && !(conv_mode() != 2 && !(planes & FAVAE_PLANES_WINO)))
         return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (direct_grid_mismatch(d, planes, false)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (planes & FAVAE_PLANES_WINO) planes = wino_planes_ok(d, planes, false) ? planes : 0;
     if (!tiles || ((planes & 0xff) != 2 && (planes & 0xff) != 1 && (planes & 0xff) != 4) || d->Cout % groups != 0) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
@@ -1396,23 +1411,24 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         auto rcp32 = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };   // 0: divisor 1
         a.wino_rcp_n = rcp32(a.tiles_n); a.wino_rcp_w = rcp32(d->Win / 16); a.wino_rcp_h = rcp32(d->Hin / wth);
         const dim3 wgrid((unsigned)(d->N * (d->Hin / wth) * (d->Win / 16) * a.tiles_n));
-#define FAVAE_LAUNCH_WINO_T(X, GBV, SEV, WD, PL)                                                                            \
+#define FAVAE_LAUNCH_WINO_T(X, GBV, SEV, WD, PL, SK)                                                                        \
     do {                                                                                                                    \
         static bool attr_set = false;                                                                                       \
         if (!attr_set) {                                                                                                    \
-            (void)hipFuncSetAttribute((const void*)conv3x3_wino_sp_kernel<X, GBV, SEV, WD, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)conv3x3_wino_sp_kernel<X, GBV, SEV, WD, PL, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       wino::LDS_B);                                                                         \
             attr_set = true;                                                                                                \
         }                                                                                                                   \
-        FAVAE_KLAUNCH((conv3x3_wino_sp_kernel<X, GBV, SEV, WD, PL>), wgrid, dim3(512), wino::LDS_B, s, a);                  \
+        FAVAE_KLAUNCH((conv3x3_wino_sp_kernel<X, GBV, SEV, WD, PL, SK>), wgrid, dim3(512), wino::LDS_B, s, a);              \
     } while (0)
 #define FAVAE_LAUNCH_WINO(X, GBV, SEV)                                                                                      \
     do {                                                                                                                    \
-        if (wplanes == 1 && wide) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 1);     /* one fp16 plane (h1) */                   \
-        else if (wplanes == 1) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, false, 1);                                                  \
-        else if (wplanes == 4) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 4);   /* one bf16 plane (b1): wide tiling only */     \
-        else if (wide) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 2);                                                           \
-        else FAVAE_LAUNCH_WINO_T(X, GBV, SEV, false, 2);                                                                    \
+        if (wplanes == 1 && wide) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 1, false);     /* one fp16 plane (h1) */            \
+        else if (wplanes == 1) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, false, 1, false);                                           \
+        else if (wplanes == 4) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 4, false);   /* one bf16 plane (b1): wide tiling only */ \
+        else if (wide && use_wino_skew() && d->Cin >= 32) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 2, true);   /* out-of-phase wave groups */ \
+        else if (wide) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 2, false);                                                    \
+        else FAVAE_LAUNCH_WINO_T(X, GBV, SEV, false, 2, false);                                                             \
     } while (0)
         if (gb) FAVAE_LAUNCH_WINO(0, true, false);
         else if (stats_part && xf == 0) FAVAE_LAUNCH_WINO(0, false, true);

@@ -202,26 +202,38 @@ __global__ __launch_bounds__(512) void fft_lines_kernel(FftArgs a) {
 // grid (blocks per image, N); j = (h Wh + k) C + c inside the image.  Round 5: 32-bit indices and divisions by multiply-high with host-made
 // reciprocals (rcp = floor(2^32 / d) + 1, 0 for d = 1; exact while j d < 2^32) -- the three 64-bit divisions per element of rounds 1-4
 // made this streaming pass instruction-bound (0.41 of the HBM roofline on the 128-channel feature pair).
-__global__ __launch_bounds__(256) void ffl_weight_kernel(float* spec, const unsigned* planemax, double* part, unsigned per_img,
-                                                         int C, float coef, int Wh, int W, unsigned rcp_c, unsigned rcp_wh) {
+// MULHI = false: the same pass with ordinary divisions on IDX-wide indices, for the sizes the reciprocal trick is not exact
+// for (per_img * max(C, Wh) >= 2^32: e.g. the 128-channel feature pair at 512 x 512) -- slower per element, never refused.  Images
+// beyond the grid's y extent are taken by the same block in turn (n += gridDim.y): its partial is one sum in a fixed order.
+template <bool MULHI, typename IDX>
+__global__ __launch_bounds__(256) void ffl_weight_kernel(float* spec, const unsigned* planemax, double* part, IDX per_img,
+                                                         int C, float coef, int Wh, int W, unsigned rcp_c, unsigned rcp_wh, int N) {
     __shared__ double red[4];
     double acc = 0.0;
-    const int n = blockIdx.y;
-    float2* s2 = reinterpret_cast<float2*>(spec) + (size_t)n * per_img;
-    const unsigned* pm = planemax + (size_t)n * C;
-    for (unsigned j = blockIdx.x * 256u + threadIdx.x; j < per_img; j += gridDim.x * 256u) {
-        const unsigned q = rcp_c ? __umulhi(j, rcp_c) : j;           // j / C
-        const int c = (int)(j - q * (unsigned)C);
-        const unsigned r = rcp_wh ? __umulhi(q, rcp_wh) : q;         // q / Wh
-        const int k = (int)(q - r * (unsigned)Wh);
-        float2 f = s2[j];
-        const float d = f.x * f.x + f.y * f.y;
-        const float mx = sqrtf(__uint_as_float(pm[c]));
-        float w = (mx > 0.f) ? sqrtf(d) / mx : 0.f;                   // 0/0 -> NaN -> 0 upstream
-        w = fminf(fmaxf(w, 0.f), 1.f);
-        acc += (double)(w * d) * ((Wh == W || k == 0 || 2 * k == W) ? 1.0 : 2.0);
-        const float g = coef * w;
-        s2[j] = make_float2(g * f.x, g * f.y);
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        float2* s2 = reinterpret_cast<float2*>(spec) + (size_t)n * per_img;
+        const unsigned* pm = planemax + (size_t)n * C;
+        for (IDX j = (IDX)blockIdx.x * 256u + threadIdx.x; j < per_img; j += (IDX)gridDim.x * 256u) {
+            int c, k;
+            if constexpr (MULHI) {
+                const unsigned q = rcp_c ? __umulhi((unsigned)j, rcp_c) : (unsigned)j;           // j / C
+                c = (int)((unsigned)j - q * (unsigned)C);
+                const unsigned r = rcp_wh ? __umulhi(q, rcp_wh) : q;                             // q / Wh
+                k = (int)(q - r * (unsigned)Wh);
+            } else {
+                const IDX q = j / (IDX)C;
+                c = (int)(j - q * (IDX)C);
+                k = (int)(q % (IDX)Wh);
+            }
+            float2 f = s2[j];
+            const float d = f.x * f.x + f.y * f.y;
+            const float mx = sqrtf(__uint_as_float(pm[c]));
+            float w = (mx > 0.f) ? sqrtf(d) / mx : 0.f;                   // 0/0 -> NaN -> 0 upstream
+            w = fminf(fmaxf(w, 0.f), 1.f);
+            acc += (double)(w * d) * ((Wh == W || k == 0 || 2 * k == W) ? 1.0 : 2.0);
+            const float g = coef * w;
+            s2[j] = make_float2(g * f.x, g * f.y);
+        }
     }
     const double tot = block_sum_d256(acc, red);
     if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = tot;
@@ -328,15 +340,25 @@ extern "C" int favae_ffl_fwd(const float* pred, const float* target, int N, int 
     if (rc) return rc;
     const size_t per_img = (size_t)H * Wh * C;               // stored bins of one image
     const double M = (double)N * H * W * C;                  // elements of the mean (full spectrum)
-    if (per_img * (size_t)(C > Wh ? C : Wh) >= ((size_t)1 << 32) || N > WEIGHT_BLOCKS) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-    int bx = (int)((per_img + 255) / 256);
-    if (bx > WEIGHT_BLOCKS / N) bx = WEIGHT_BLOCKS / N;
+    const int ny = N > WEIGHT_BLOCKS ? WEIGHT_BLOCKS : N;     // images beyond the grid: the same blocks take them in turn
+    int bx = (int)((per_img + 255) / 256 < (size_t)(WEIGHT_BLOCKS / ny) ? (per_img + 255) / 256 : (size_t)(WEIGHT_BLOCKS / ny));
     if (bx < 1) bx = 1;
     auto rcp32 = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };
-    FAVAE_KLAUNCH(ffl_weight_kernel, dim3(bx, N), dim3(256), 0, s, spec, (const unsigned*)planemax, part, (unsigned)per_img,
-                       C, (float)(2.0 * (double)loss_weight / M), Wh, W, rcp32(C), rcp32(Wh));
+    const float coef = (float)(2.0 * (double)loss_weight / M);
+    // multiply-high by host-made reciprocals is exact while index * divisor < 2^32; beyond that ordinary divisions (32- or 64-bit indices)
+    const bool exact = per_img * (size_t)(C > Wh ? C : Wh) < ((size_t)1 << 32);
+    if (exact) {
+        FAVAE_KLAUNCH((ffl_weight_kernel<true, unsigned>), dim3(bx, ny), dim3(256), 0, s, spec, (const unsigned*)planemax, part,
+                      (unsigned)per_img, C, coef, Wh, W, rcp32(C), rcp32(Wh), N);
+    } else if (per_img < ((size_t)1 << 32) - (size_t)WEIGHT_BLOCKS * 256) {
+        FAVAE_KLAUNCH((ffl_weight_kernel<false, unsigned>), dim3(bx, ny), dim3(256), 0, s, spec, (const unsigned*)planemax, part,
+                      (unsigned)per_img, C, coef, Wh, W, 0u, 0u, N);
+    } else {
+        FAVAE_KLAUNCH((ffl_weight_kernel<false, unsigned long long>), dim3(bx, ny), dim3(256), 0, s, spec, (const unsigned*)planemax, part,
+                      (unsigned long long)per_img, C, coef, Wh, W, 0u, 0u, N);
+    }
     FAVAE_CHECK_LAUNCH();
-    const int blocks = bx * N;
+    const int blocks = bx * ny;
     FAVAE_KLAUNCH(ffl_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)part, blocks, (double)loss_weight / M, loss);
     FAVAE_CHECK_LAUNCH();
     return FAVAE_OK;

@@ -132,7 +132,11 @@ int favae_get_wino(void);              /* the current setting, no side effect */
  * planes = 1 | FAVAE_PLANES_WINO with the ordinary records (their head plane is read), or 4 | FAVAE_PLANES_WINO with records made by
  * favae_wino_weights with bit 2 of `flip` set (4 forward, 5 data gradient: bf16 head plane, unscaled; no operand bound is asked for).
  * In these two modes the caller may ALSO keep a conv with more than 64 output channels on the direct one-plane kernel (planes = 1 or 4
- * without the flag) call by call: B^T d B before the rounding costs 1.5-1.7 x the direct kernel's error, and the Python host keeps the b1 forward convs direct. */
+ * without the flag) call by call: B^T d B before the rounding costs 1.5-1.7 x the direct kernel's error, and the Python host keeps the b1 forward convs direct.
+ * The statistics / GroupNorm-backward variants (favae_conv_fwd_split_stats, favae_conv_dgrad_gnbwd) accept that direct call only where
+ * the direct kernel's 16 x 8 tile grid IS the grid favae_conv_stats_tiles / favae_conv_gnbwd_tiles report, i.e. where the wide Winograd
+ * tiling applies (Cout % 128 == 0 and FAVAE_WINO_WIDE on); elsewhere they return FAVAE_ERR_UNSUPPORTED instead of writing partial sums
+ * past the buffer the caller sized from the tile count. */
 /* Winograd F(4x4, 3x3) (csrc/conv_wino4.h, ABI 18): 36 instead of 64 multiplies per 16 outputs -- 0.56 x the matrix work and operand
  * splitting of the F(2x2) kernel, at 2.3e-6 rms (F(2x2): 3.6e-7) of the output range per conv.  Meant for results no codebook index
  * depends on: the data gradients (autograd of models/codec.py:38-46) and, by the caller's choice, decoder layers.

@@ -47,6 +47,9 @@ MODEL_KW = {
 }
 
 
+import margins  # noqa: E402  (achieved errors of every bar -> gpurun_out/parity_margins.txt)
+
+
 def build(tag):
     from models.vqgan_fcm import VQGANFCM
     mk, ok = MODEL_KW[tag]
@@ -65,6 +68,7 @@ def rel(a, b):
 
 def close(a, b, tol, name):
     e = rel(a, b)
+    margins.record(name, e, tol)
     assert e < tol, f"{name}: max-rel {e:.3e} >= {tol}"
 
 
@@ -152,13 +156,16 @@ def _golden_step(g, gtag, mtag, grad_tol=5e-3):
             tol = 2e-2 if k.endswith("sigmas") else grad_tol
             scale = float(np.abs(g[key]).max()) + 1e-30
             err = float(np.abs(gr.reshape(-1)[:16].numpy() - g[key]).max()) / scale
+            margins.record("grad head " + k, err, tol)
             assert err < tol, f"grad head {k}: {err:.3e}"
             ref_abs = float(g[p + "g." + k + ".abs"])
+            margins.record("grad abs-sum " + k, abs(float(gr.double().abs().sum()) - ref_abs) / ref_abs, tol)
             assert abs(float(gr.double().abs().sum()) - ref_abs) < tol * ref_abs, f"grad abs-sum {k}"
             # whole tensor (fixtures of the BASELINE sizes): every element of the small ones, hashed positions + channel sums of the large
             if p + "g." + k + ".full" in g.files:
                 ref = g[p + "g." + k + ".full"]
                 err = float(np.abs(gr.numpy().reshape(ref.shape) - ref).max()) / (float(np.abs(ref).max()) + 1e-30)
+                margins.record("grad (every element) " + k, err, tol)
                 assert err < tol, f"grad (every element) {k}: {err:.3e}"
                 n_full += 1
             elif p + "g." + k + ".at" in g.files:

@@ -377,6 +377,9 @@ def large_close(g, key, t, tol, what):
     amax = float(g[key + ".absmax"]) + 1e-30
     at = flat[O.sample_positions(flat.numel(), len(g[key + ".at"]))].numpy()
     err = float(np.abs(at - g[key + ".at"]).max()) / amax
+    if t.is_cuda or os.environ.get("PYTEST_CURRENT_TEST", "").find("test_gpu_") >= 0:
+        import margins
+        margins.record(what + " (hashed positions)", err, tol)
     assert err < tol, f"{what} at {len(at)} positions: {err:.3e}"
     d = t.double().transpose(0, 1).reshape(t.shape[1], -1)
     per = d.shape[1]
