@@ -132,7 +132,7 @@ def write_detail(detail):
 def fit_line(res):
     """the stdout JSON line, kept below MAX_LINE_BYTES by dropping optional keys (they stay in the side file) -- never by failing"""
     line = json.dumps(res)
-    for k in ("with_lpips", "per_rank_images_per_s", "roofline_step", "ms_per_step_profiler_off"):
+    for k in ("with_lpips", "per_rank_images_per_s", "roofline_step", "ms_per_step_profiler_off", "reference_loop"):
         if len(line) < MAX_LINE_BYTES:
             break
         res = {kk: v for kk, v in res.items() if kk != k}
@@ -428,7 +428,13 @@ def main():
     exchange_desc = (("RCCL all-reduce, %d segments " % len(ts.exchange.segments)) +
                      ("queued behind backward (FAVAE_COMM_DEFER=0: overlapped with it)" if ts.exchange.defer else "overlapped with backward")
                      if ts.exchange is not None else ("one RCCL all-reduce after backward" if use_dist else "none (1 GPU)"))
-    xs = [synthetic_batch(args.batch, args.res, args.res, 1234 + 17 * rank + i).to(dev) for i in range(2)]
+    # x = randn(B, 3, 256, 256, generator seed 1234 + rank).clamp(-1, 1), resident on the device; two batches drawn one after
+    # the other from that generator alternate over the steps (FAVAE_BENCH_INPUT=hash: the hash-noise batch of rounds 1-5, utils.synthetic_batch)
+    if os.environ.get("FAVAE_BENCH_INPUT") == "hash":
+        xs = [synthetic_batch(args.batch, args.res, args.res, 1234 + 17 * rank + i).to(dev) for i in range(2)]
+    else:
+        gen = torch.Generator().manual_seed(1234 + rank)
+        xs = [torch.randn(args.batch, 3, args.res, args.res, generator=gen).clamp_(-1.0, 1.0).to(dev) for i in range(2)]
     prof = Prof(favae_hip)
 
     def sync():
@@ -539,6 +545,35 @@ def main():
                 t_lp = float(t.item())
             extras["with_lpips"] = {"value": rnd(args.batch * world * n_lp / t_lp), "unit": "images/s",
                                     "ms_per_step": rnd(1e3 * t_lp / n_lp), "steps": n_lp}
+            del ts_lp
+        # (e) the loop a user of the drop-in boundary runs: train_favae.py:68-119 restated on the drop-in modules -- torch DDP
+        # (find_unused_parameters=True), torch.optim.Adam(betas=(0.5, 0.9)), the ten-scalar .item() read-back (tools/ref_loop_bench.py).
+        # Last of the extras: it needs a process group (RCCL, world 1 when bench.py runs without one), created and destroyed here.
+        if args.config == "celeba_f16" and not args.gan and not args.lpips and args.precision == "fp32":
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from ref_loop_bench import build_model, reference_loop
+            ts = None
+            torch.cuda.empty_cache()
+            own_pg = not use_dist
+            if own_pg:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29549")
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            torch.manual_seed(0)
+            ref_model = build_model(dev, args.codebook, n_embed, sync_codebook=use_dist, **mk)
+            n_ref = min(args.steps, 4)
+            r = reference_loop(ref_model, xs, n_ref, warmup=2, lr=4.5e-6 * args.batch * world, sync_fn=sync)
+            t = torch.tensor([r["ms_per_step"]], device=dev, dtype=torch.float64)
+            if use_dist:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms_ref = float(t.item())
+            extras["reference_loop"] = {"images_per_s": rnd(args.batch * world * 1e3 / ms_ref), "ms_per_step": rnd(ms_ref), "steps": n_ref,
+                                        "what": "train_favae.py:68-119 on the drop-in modules: DDP(find_unused_parameters), "
+                                                "torch.optim.Adam, 10 x .item() per step (tools/ref_loop_bench.py)"}
+            del ref_model
+            if own_pg:
+                dist.destroy_process_group()
 
     if rank == 0:
         step_us = 1e6 * dt * PROF_STEPS / args.steps           # wall time of the profiled steps (for share_of_step_time)
@@ -602,6 +637,9 @@ def main():
             res["ms_per_step_single_stream"] = rnd(1e3 * extras["t_excl"] / 2)
         if "with_lpips" in extras:
             res["with_lpips"] = extras["with_lpips"]
+        if "reference_loop" in extras:
+            res["reference_loop"] = extras["reference_loop"]
+            res["reference_loop"]["vs_trainstep"] = rnd(res["reference_loop"]["images_per_s"] / res["value"], 4)
         if comm is not None:
             res["comm"] = comm
         if world == 1 and not use_dist and not args.no_cpu_baseline:

@@ -1041,12 +1041,6 @@ static bool use_wino_wide() {
     if (g_wino_wide < 0) { const char* e = getenv("FAVAE_WINO_WIDE"); g_wino_wide = (e && e[0] == '0') ? 0 : 1; }
     return g_wino_wide == 1;
 }
-// FAVAE_WINO_SKEW=0: the lock-step K loop of round 5 (A/B arm; conv_wino.h SKEW)
-static bool use_wino_skew() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("FAVAE_WINO_SKEW"); on = (e && e[0] == '0') ? 0 : 1; }
-    return on != 0;
-}
 static bool wino_wide_ok(const favae_conv_desc* d, bool has_affine) {
     return use_wino_wide() && wino_ok(d, has_affine) && d->Cout % 128 == 0;
 }
@@ -1411,24 +1405,23 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         auto rcp32 = [](int dv) { return dv == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1); };   // 0: divisor 1
         a.wino_rcp_n = rcp32(a.tiles_n); a.wino_rcp_w = rcp32(d->Win / 16); a.wino_rcp_h = rcp32(d->Hin / wth);
         const dim3 wgrid((unsigned)(d->N * (d->Hin / wth) * (d->Win / 16) * a.tiles_n));
-#define FAVAE_LAUNCH_WINO_T(X, GBV, SEV, WD, PL, SK)                                                                        \
+#define FAVAE_LAUNCH_WINO_T(X, GBV, SEV, WD, PL)                                                                       \
     do {                                                                                                                    \
         static bool attr_set = false;                                                                                       \
         if (!attr_set) {                                                                                                    \
-            (void)hipFuncSetAttribute((const void*)conv3x3_wino_sp_kernel<X, GBV, SEV, WD, PL, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)conv3x3_wino_sp_kernel<X, GBV, SEV, WD, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       wino::LDS_B);                                                                         \
             attr_set = true;                                                                                                \
         }                                                                                                                   \
-        FAVAE_KLAUNCH((conv3x3_wino_sp_kernel<X, GBV, SEV, WD, PL, SK>), wgrid, dim3(512), wino::LDS_B, s, a);              \
+        FAVAE_KLAUNCH((conv3x3_wino_sp_kernel<X, GBV, SEV, WD, PL>), wgrid, dim3(512), wino::LDS_B, s, a);              \
     } while (0)
 #define FAVAE_LAUNCH_WINO(X, GBV, SEV)                                                                                      \
     do {                                                                                                                    \
-        if (wplanes == 1 && wide) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 1, false);     /* one fp16 plane (h1) */            \
-        else if (wplanes == 1) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, false, 1, false);                                           \
-        else if (wplanes == 4) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 4, false);   /* one bf16 plane (b1): wide tiling only */ \
-        else if (wide && use_wino_skew() && d->Cin >= 32) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 2, true);   /* out-of-phase wave groups */ \
-        else if (wide) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 2, false);                                                    \
-        else FAVAE_LAUNCH_WINO_T(X, GBV, SEV, false, 2, false);                                                             \
+        if (wplanes == 1 && wide) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 1);     /* one fp16 plane (h1) */            \
+        else if (wplanes == 1) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, false, 1);                                           \
+        else if (wplanes == 4) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 4);   /* one bf16 plane (b1): wide tiling only */ \
+        else if (wide) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 2);                                                   \
+        else FAVAE_LAUNCH_WINO_T(X, GBV, SEV, false, 2);                                                             \
     } while (0)
         if (gb) FAVAE_LAUNCH_WINO(0, true, false);
         else if (stats_part && xf == 0) FAVAE_LAUNCH_WINO(0, false, true);

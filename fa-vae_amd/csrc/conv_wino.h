@@ -223,25 +223,9 @@ __device__ unsigned long long g_wino_trace[64 * 8 * 48 * 8];
 // PLN (round 5): operand scheme -- 2 = two scaled fp16 planes, three products (h3, fp32-grade); 1 / 4 = ONE fp16 / bf16 plane, one product
 // (the 16-bit mixed-precision modes h1 / b1; b1 in the wide tiling only): a third of the MFMAs, a quarter of the split instructions,
 // half the fragments.
-//
-// SKEW (round 6; wide tiling only): the two waves of a SIMD run HALF A CHUNK OUT OF PHASE.  profiles/r06_mfma_valu_sweep.txt: a SIMD hides
-// up to five single-issue vector instructions (or one LDS store, two or three LDS reads) in the 32-cycle shadow of every
-// v_mfma_f32_32x32x16, whichever of its waves issues them -- the "times add" premise of rounds 3-5 came from a 12-fillers-per-MFMA test,
-// past the knee.  The K loop of this kernel issues 3.4 vector instructions per MFMA, well under the knee, but in lock step: both waves of
-// a SIMD transform (matrix pipe idle), then both multiply (vector ALU idle).  With SKEW the waves of channel half 0 (group A: waves 0-3,
-// one per SIMD) and of half 1 (group B: waves 4-7, the other wave of each SIMD) alternate:
-//     slot 2k    : A  M(k)   = the 24 MFMAs of chunk k          B  T(k+1) = patch, transform + split -> V[(k+1) & 1], staging of chunk k+2
-//     slot 2k + 1: A  T(k+1)                                    B  M(k)
-// one workgroup barrier per slot.  V[k+1] is complete after slot 2k+1 and first read in slot 2k+2; V[(k+1) & 1] = V[(k-1) & 1] was last
-// read in slot 2k-1 (B's M(k-1)): TWO V buffers still do.  Raw halo tile (k+2) & 1 = that of chunk k, last read (patch) in slot 2k-1 by A,
-// is overwritten in slots 2k (B's share) and 2k+1 (A's share) and first read in slot 2k+2: two tiles.  Both groups run ONE instruction
-// stream, loop { M(k); barrier; T(k + 1 + group); barrier } -- group B enters it behind a T(1) of its own, so its T is one chunk further
-// on; what a T computes past the last chunk lands in the V buffer / halo tile nobody reads any more (indices into memory are clamped).
-// Arithmetic and summation order are untouched: the result bits are those of the lock-step kernel.
-template <int XFORM, bool GB, bool SE, bool WIDE = false, int PLN = 2, bool SKEW = false>
+template <int XFORM, bool GB, bool SE, bool WIDE = false, int PLN = 2>
 __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     static_assert(PLN == 2 || PLN == 1 || (PLN == 4 && WIDE), "the bf16 plane: the wide tiling only");
-    static_assert(!SKEW || WIDE, "out-of-phase wave groups: the wide tiling only");
     constexpr int NP = PLN == 2 ? 2 : 1;           // operand planes
     static_assert(!GB || XFORM == 0, "GroupNorm-backward sums: plain data gradient");
     static_assert(!(GB && SE), "one statistics epilogue at a time");
@@ -316,8 +300,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
         for (int j = 0; j < NSLOT; ++j) r[j] = bload(rx, vh[j], sk);
     };
     auto load_raw = [&](int kc) { load_raw_to(rg, kc); };
-    // kc = the chunk the registers hold (its (scale, shift) slice), tile = the staged halo tile written (WIDE: two of them)
-    auto store_raw_to = [&](const float4 (&rg)[NSLOT], int kc, int tile) {
+    auto store_raw_from = [&](const float4 (&rg)[NSLOT], int kc) {  // kc = the chunk the registers hold
         float4 rsc = make_float4(0.f, 0.f, 0.f, 0.f), rsh = rsc;
         if (XFORM) {
             rsc = *reinterpret_cast<const float4*>(Aff + kc * 16 + q4 * 4);
@@ -328,10 +311,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
             const float4 t0 = xform4_t<XFORM>(rg[j], rsc, rsh, a.act);
             const float sj = (XFORM && !hok[j]) ? 0.f : Sa;                  // padding stays exactly zero behind the transform (finite values)
             const float4 t = make_float4(t0.x * sj, t0.y * sj, t0.z * sj, t0.w * sj);
-            if (j < NSLOT - 1 || tid < LASTN) *reinterpret_cast<float4*>(Rs + (WIDE ? tile * RAWB : 0) + ro[j]) = t;
+            if (j < NSLOT - 1 || tid < LASTN) *reinterpret_cast<float4*>(Rs + (WIDE ? (kc & 1) * RAWB : 0) + ro[j]) = t;
         }
     };
-    auto store_raw_from = [&](const float4 (&rg)[NSLOT], int kc) { store_raw_to(rg, kc, kc & 1); };
     auto store_raw = [&](int kc) { store_raw_from(rg, kc); };
 
     // transform item of this thread: Winograd tile (tty, ttx) of the 8 x 8, channel quad q4, half th = rows (2 th, 2 th + 1) of
@@ -470,144 +452,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     float4 rg1[NSLOT];                              // halo of chunk 1: a second register set, live in the prologue only
     load_raw(0);
     load_raw_to(rg1, KL < 1 ? KL : 1);
-    if constexpr (SKEW) {
-#pragma unroll
-        for (int ar = 0; ar < 3; ++ar) load_b(0, ar);
-        if (XFORM) {
-            if (tid < a.Cin) {
-                Aff[tid] = aff_sc;
-                Aff[AFF_C + tid] = aff_sh;
-            }
-            __syncthreads();                        // (scale, shift) staged
-        }
-        store_raw(0);
-        load_raw(KL < 2 ? KL : 2);
-        store_raw_from(rg1, KL < 1 ? KL : 1);       // KL = 0: tile 0 again, same values
-        __syncthreads();                            // halo tiles 0 and 1 staged
-        read_patch(0);
-        transform(0);
-        WTRACE(0, 1);
-        __syncthreads();                            // V[0] complete; halo tile 0 free
-        // T(kt): patch of chunk kt -> V[kt & 1]; this thread's share of chunk kt + 1 -> halo tile (kt + 1) & 1; request chunk kt + 2; the
-        // first three positions of the weight fragments of the NEXT M (their registers are free: the M in front of this T used them up).
-        // Chunks past KL: tile / buffer parities go on (dead targets), indices into memory and into the (scale, shift) table are clamped
-        // (left alone the compiler sinks every load to just in front of its first use -- the weight requests to the end of T, i.e. one
-        // barrier in front of the MFMAs that wait for them, the A-fragment reads between the MFMAs: scheduling barriers pin the order)
-        // Order of the memory requests (vmcnt retires in order: waiting for a load waits for every older one).  M: weight position 3, THEN
-        // the halo of the chunk the next T stages (HBM latency: it has the rest of M, a barrier and the transform to arrive) -- no wait
-        // for a weight ever sits behind a halo load.  T: weight positions 0 and 1 first (a whole T ahead of their MFMAs), position 2 at
-        // the end (its registers are the transform's until then; 12 MFMAs + a barrier of cover).
-        int trow = 1;                               // trace row of the current iteration (FAVAE_WINO_TRACE builds only)
-        auto Tphase = [&](int kt, int kb, auto with_b) {
-            if constexpr (decltype(with_b)::value != 0) {
-                load_b(kb, 0);
-                load_b(kb, 1);
-            }
-            read_patch(kt);
-            __builtin_amdgcn_sched_barrier(0);
-#ifdef FAVAE_WINO_TRACE2
-            WTRACE(trow, 6);                        // (waits for the patch: the stamp returns through lgkmcnt)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            transform(kt & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#ifdef FAVAE_WINO_TRACE2
-            WTRACE(trow, 7);
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            store_raw_to(rg, kt + 1 < KL ? kt + 1 : KL, (kt + 1) & 1);
-            if constexpr (decltype(with_b)::value != 0) load_b(kb, 2);
-        };
-        auto Mphase = [&](int k, auto first_c) {
-            constexpr bool FIRST = decltype(first_c)::value != 0;
-            load_b(k, 3);                           // consumed by the last six MFMAs: 18 x 32 cycles of cover for the L2 round trip
-            load_raw(k + 2 + wc < KL ? k + 2 + wc : KL);    // what T(k + 1 + wc), the T behind this M, stages
-            half8_t af[4][NP];                      // all A fragments of the chunk up front: one LDS round trip, not four
-#pragma unroll
-            for (int ar = 0; ar < 4; ++ar)
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
-                    af[ar][pl] = *reinterpret_cast<const half8_t*>(Afr + (k & 1) * VB + (ar * 4 * 2 + pl) * PLB);
-            __builtin_amdgcn_sched_barrier(0);
-#ifdef FAVAE_WINO_TRACE2
-            WTRACE(trow, 5);                        // (waits for the A fragments)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-            for (int ar = 0; ar < 4; ++ar) {
-                if constexpr (NP == 1) {
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) {
-                        f32x16 c;
-                        if constexpr (FIRST) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) c[r] = 0.f;
-                        } else c = acc[ar][cb];
-                        if constexpr (PLN == 4)
-                            acc[ar][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[ar][0]),
-                                                                                  __builtin_bit_cast(bf16x8_t, bfr[ar][cb][0]), c, 0, 0, 0);
-                        else acc[ar][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ar][0], bfr[ar][cb][0], c, 0, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int p3 = 0; p3 < 3; ++p3) {        // smallest terms first, as mma()
-                        const int pa = p3 == 0 ? 1 : 0, pb = p3 == 1 ? 1 : 0;
-#pragma unroll
-                        for (int cb = 0; cb < 2; ++cb) {
-                            f32x16 c;
-                            if constexpr (FIRST) {
-                                if (p3 == 0) {
-#pragma unroll
-                                    for (int r = 0; r < 16; ++r) c[r] = 0.f;
-                                } else c = acc[ar][cb];
-                            } else c = acc[ar][cb];
-                            acc[ar][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ar][NP == 2 ? pa : 0], bfr[ar][cb][NP == 2 ? pb : 0], c, 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        };
-        {                                           // KL >= 1 (the dispatcher keeps 16-channel inputs on the lock-step kernel)
-            if (wc) {                               // group B starts half a chunk behind: its T(1) beside group A's M(0)
-                Tphase(1, 0, sp::IC<0>{});          // (the weights of chunk 0 are on their way since the prologue)
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            WTRACE(1, 0);
-            Mphase(0, sp::IC<1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            WTRACE(1, 1);
-            __syncthreads();
-            WTRACE(1, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            Tphase(1 + wc, 1, sp::IC<1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            WTRACE(1, 3);
-            __syncthreads();
-            WTRACE(1, 4);
-            for (int k = 1; k < KL; ++k) {
-                trow = k + 1;
-                __builtin_amdgcn_sched_barrier(0);
-                WTRACE(k + 1, 0);
-                Mphase(k, sp::IC<0>{});
-                __builtin_amdgcn_sched_barrier(0);
-                WTRACE(k + 1, 1);
-                __syncthreads();
-                WTRACE(k + 1, 2);
-                __builtin_amdgcn_sched_barrier(0);
-                Tphase(k + 1 + wc, k + 1, sp::IC<1>{});
-                __builtin_amdgcn_sched_barrier(0);
-                WTRACE(k + 1, 3);
-                __syncthreads();
-                WTRACE(k + 1, 4);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            Mphase(KL, sp::IC<0>{});
-            __builtin_amdgcn_sched_barrier(0);
-            if (!wc) __syncthreads();               // group A: the slot in which group B runs its last M
-        }
-    } else {
     // WIDE holds 64 registers of weight fragments when all four positions are loaded a chunk ahead -- with the patch and the transform's
     // values that is more than the 256 of a wave.  Positions 2 and 3 are therefore requested INSIDE their chunk, behind the transform
     // (their registers are free while the transform runs); the matrix instructions of positions 1 (and 2) cover the L2 round trip.
@@ -708,7 +552,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     } else {
         last_chunk(sp::IC<1>{});
     }
-    }   // !SKEW
     __syncthreads();
     WTRACE(47, 0);
 

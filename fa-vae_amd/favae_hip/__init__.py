@@ -19,6 +19,18 @@ import torch
 if "GPU_MAX_HW_QUEUES" not in os.environ and not torch.cuda.is_initialized():
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
+
+def _parse_queues(v):
+    try:
+        return int(v)
+    except (TypeError, ValueError):
+        return None
+
+
+# What HIP saw: the value of the variable at import time, valid only if HIP was not yet initialised then (a later export changes the
+# environment, not the runtime).  None = unknown (HIP was up before this import, or the value does not parse): TrainStep warns.
+HW_QUEUES_AT_INIT = None if torch.cuda.is_initialized() else _parse_queues(os.environ.get("GPU_MAX_HW_QUEUES"))
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FAVAE_HIP_LIB") or os.path.join(_HERE, "libfavae_hip.so")     # FAVAE_HIP_LIB: same-box A/B of two builds
 ABI_VERSION = 20

@@ -1103,7 +1103,10 @@ class FusedConvFn(torch.autograd.Function):
                 gnb = None
                 if (_GNBWD_FUSE and has_gn and cfg.norm == "group" and not cfg.upsample and dys is None and mean is not None
                         and (dyb is not None or not _fp16_planes())):
-                    gn_tiles = query("favae_conv_gnbwd_tiles", byref(d2), PLANES_WINO4 if _wino4_wanted(d2, False, True) else 0)
+                    # the tile grid is the kernel's, and the kernel is the one the records were made for AT FORWARD TIME (ctx.wflip):
+                    # a set_wino4() between forward and backward must not change the grid under the records
+                    f43_now = ctx.wflip[1] if ctx.wflip is not None else _wino4_wanted(d2, False, True)
+                    gn_tiles = query("favae_conv_gnbwd_tiles", byref(d2), PLANES_WINO4 if f43_now else 0)
                     if gn_tiles:
                         gn_ws = workspace(query("favae_gn_bwd_tiles_workspace", N, gn_tiles, Cin), dev)
                         # FAVAE_GB_PREMUL: the epilogue writes dy = da * act'(y) (it has it in registers for the sums) and the apply

@@ -89,13 +89,12 @@ class GradExchange:
         # collectives then never compete with the whole-CU conv kernels for CUs -- the A/B arm for the first multi-GPU run: whether the
         # eagerly queued segments really overlap, or slow the conv chain by more than they hide, has never been observed.
         self.defer = defer
-        # timing: one event in front of every segment's collective (communication stream) and one behind it (a per-segment watcher
-        # stream that waits for the collective's completion): report() turns them into an overlap table against the backward pass
+        # timing: one event in front of every segment's collective and one behind it, both on the communication stream (the collective
+        # is queued there: its end event is ordered behind it); report() turns them into an overlap table against the backward pass
         self.timing = timing and self.cuda
         self.fired = [False] * len(self.segments)
         self.works = []
         self.marks = []                         # (segment, start event, end event, bytes)
-        self.watch = None                       # (round 4: one watcher stream per segment; see _launch)
 
     def set_timing(self, on):
         """switch the per-segment events on / off after construction (bench.py's comm diagnostics run both arms on one object)"""
@@ -181,11 +180,14 @@ class TrainStep:
         self.sl_kernel, self.sl_sigma = gaussian_kernel, gaussian_sigma
         self.distributed = distributed and dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.distributed else 1
-        if self.distributed and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
+        import favae_hip
+        if self.distributed and (favae_hip.HW_QUEUES_AT_INIT is None or favae_hip.HW_QUEUES_AT_INIT < 8):
             import warnings
-            warnings.warn("GPU_MAX_HW_QUEUES=%s: with a process group in the process the weight-gradient stream loses its overlap with the "
-                          "compute stream (+8.6 %% step time measured); export GPU_MAX_HW_QUEUES=8 before HIP is initialised, or import "
-                          "favae_hip before the first torch.cuda call" % os.environ.get("GPU_MAX_HW_QUEUES", "unset (4)"), RuntimeWarning)
+            warnings.warn("GPU_MAX_HW_QUEUES as HIP read it: %s.  With a process group in the process the weight-gradient stream loses its "
+                          "overlap with the compute stream below 8 hardware queues (+8.6 %% step time measured); export "
+                          "GPU_MAX_HW_QUEUES=8 before HIP is initialised, or import favae_hip before the first torch.cuda call"
+                          % ("unknown (HIP was initialised before favae_hip was imported, or the value is not a number)"
+                             if favae_hip.HW_QUEUES_AT_INIT is None else favae_hip.HW_QUEUES_AT_INIT), RuntimeWarning)
         self.t = 0                     # opt_g steps taken
         self.t_d = 0                   # opt_d steps taken (its own count: the reference's opt_d only starts at disc_start_epochs)
         # opt_g parameter set: encoder + decoder + quantizer (+ pair-wise model.sigmas at its own lr)

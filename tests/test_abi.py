@@ -196,5 +196,12 @@ def test_package_asks_for_eight_hardware_queues_before_hip_is_initialised():
     assert out.returncode == 0 and out.stdout.strip() == "8", out.stdout + out.stderr[-1000:]
     out = subprocess.run([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="16"), capture_output=True, text=True, timeout=300)
     assert out.stdout.strip() == "16"
+    # what TrainStep's warning looks at: the value HIP read (a number), or None when it cannot be known -- a non-numeric value must not
+    # raise (int() on the raw environment variable did)
+    code2 = "import sys; sys.path.insert(0, %r); import favae_hip; print(favae_hip.HW_QUEUES_AT_INIT)" % os.path.join(ROOT, "fa-vae_amd")
+    for val, want in (("8", "8"), ("lots", "None"), (None, "8")):
+        e = dict(env) if val is None else dict(env, GPU_MAX_HW_QUEUES=val)
+        out = subprocess.run([sys.executable, "-c", code2], env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.strip() == want, (val, out.stdout, out.stderr[-500:])
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert src.index('os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")') < src.index('dist.init_process_group("nccl"')

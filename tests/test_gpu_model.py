@@ -95,11 +95,11 @@ def test_forward_against_reference_golden(golden_dir, gtag, mtag):
     model.train()
     x_recon, loss_q, logits_fake, z, enc_feats, dec_feats = model(x, stage=0)
     p = gtag + "."
-    close(loss_q, g[p + "loss_q"], 1e-4, "loss_q")
+    close(loss_q, g[p + "loss_q"], LOSS_TOL, "loss_q")
     xr = x_recon.detach().cpu()
-    close(xr[:, :, ::max(1, H // 8), ::max(1, W // 8)], g[p + "x_recon_slice"], 1e-4, "x_recon")
+    close(xr[:, :, ::max(1, H // 8), ::max(1, W // 8)], g[p + "x_recon_slice"], XRECON_TOL, "x_recon")
     assert abs(float(xr.double().abs().sum()) - float(g[p + "x_recon_abs"])) < 1e-4 * float(g[p + "x_recon_abs"])
-    close(K.l1_loss(x, x_recon), g[p + "loss_l1"], 1e-4, "loss_l1")
+    close(K.l1_loss(x, x_recon), g[p + "loss_l1"], LOSS_TOL, "loss_l1")
     for i in range(4):
         s = float(enc_feats[i].detach().double().abs().sum())
         assert abs(s - float(g[p + f"enc_feat{i}_abs"])) < 1e-4 * float(g[p + f"enc_feat{i}_abs"]), f"enc_feat{i}"
@@ -124,7 +124,16 @@ def test_indices_against_reference_golden(golden_dir):
         assert flips == 0, f"{gtag}: {flips} near-tie flips"
 
 
-def _golden_step(g, gtag, mtag, grad_tol=5e-3):
+# Stage-0 bars (round 6): within 10 x of the worst error achieved on MI355X by the quantity's family over all fixtures
+# (profiles/r06_parity_margins.txt, checked by tests/test_margins.py) and never above north_star's 1e-4:
+#   losses 1.3e-6 -> 1e-5; x_recon 5.1e-6 -> 5e-5; gradients (max error / tensor max) 1.3e-5 -> 1e-4;
+#   sigma gradients 1.2e-4 -> 1e-3 (one scalar at the end of a k x k-tap reduction over a whole feature tensor with heavy
+#   cancellation: the only family above 1e-4; the oracle itself differs from the reference by 3e-6 there).
+# Rounds 1-5 carried 5e-3 / 2e-2 here: three orders above what the kernels deliver.
+LOSS_TOL, XRECON_TOL, GRAD_TOL, SIGMA_GRAD_TOL = 1e-5, 5e-5, 1e-4, 1e-3
+
+
+def _golden_step(g, gtag, mtag, grad_tol=GRAD_TOL):
     from favae_step import TrainStep
     model, cfg, _ = build(mtag)
     B, H, W, seed = [int(v) for v in g[gtag + ".shape"]]
@@ -136,24 +145,24 @@ def _golden_step(g, gtag, mtag, grad_tol=5e-3):
     out["loss_g"].sum().backward()
     p = gtag + "."
     for k, gk in (("loss_quant", "loss_q"), ("loss_l1", "loss_l1"), ("loss_ffl", "loss_ffl"), ("loss_dsl", "loss_dsl"), ("loss_g", "loss_g")):
-        close(out[k].reshape(-1), g[p + gk], 1e-4, gk)
-    close(torch.stack([v.reshape(()) for v in out["loss_dsl_levels"]]), g[p + "loss_dsl_levels"], 1e-4, "dsl levels")
+        close(out[k].reshape(-1), g[p + gk], LOSS_TOL, gk)
+    close(torch.stack([v.reshape(()) for v in out["loss_dsl_levels"]]), g[p + "loss_dsl_levels"], LOSS_TOL, "dsl levels")
     xr = out["x_recon"].detach().cpu()
-    close(xr[:, :, ::max(1, H // 8), ::max(1, W // 8)], g[p + "x_recon_slice"], 1e-4, "x_recon")
+    close(xr[:, :, ::max(1, H // 8), ::max(1, W // 8)], g[p + "x_recon_slice"], XRECON_TOL, "x_recon")
     # the slice above sits on the corners of the conv kernels' 16 x 16-pixel workgroup tiles; these cover every element: the sum and
     # abs-sum over the whole tensor, and (fixtures of the BASELINE sizes) 32768 hashed positions + per-channel sums / sums of squares
     xd = xr.double()
     assert abs(float(xd.sum()) - float(g[p + "x_recon_sum"])) < 1e-4 * float(g[p + "x_recon_abs"]), "x_recon sum"
     assert abs(float(xd.abs().sum()) - float(g[p + "x_recon_abs"])) < 1e-4 * float(g[p + "x_recon_abs"]), "x_recon abs-sum"
     if p + "x_recon.at" in g.files:
-        large_close(g, p + "x_recon", xr, 1e-4, "x_recon")
+        large_close(g, p + "x_recon", xr, XRECON_TOL, "x_recon")
     named = dict(model.named_parameters())
     n = n_full = 0
     for k, prm in named.items():
         key = p + "g." + k + ".head"
         if key in g.files:
             gr = prm.grad.detach().cpu().contiguous()
-            tol = 2e-2 if k.endswith("sigmas") else grad_tol
+            tol = SIGMA_GRAD_TOL if k.endswith("sigmas") else grad_tol
             scale = float(np.abs(g[key]).max()) + 1e-30
             err = float(np.abs(gr.reshape(-1)[:16].numpy() - g[key]).max()) / scale
             margins.record("grad head " + k, err, tol)

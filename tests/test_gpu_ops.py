@@ -1081,6 +1081,81 @@ def test_ffl_any_length_vs_oracle(K, shape):
     check(td.grad, t.grad, 1e-4, "gtarget")
 
 
+def test_ffl_beyond_the_32bit_reciprocal_bound(K):
+    """(1, 128, 512, 512): 512 * 257 * 128 bins x max(C, Wh) = 4.33e9 > 2^32 -- the multiply-high index decode of the weight pass is
+    not exact there and the pass takes ordinary divisions instead of refusing the size (`--res 512` of the reference
+    produces this pair).  Checked against the closed form of a single cosine (loss = A^2 / 2 per the known-answer tests, all energy in
+    two conjugate bins of weight 1) so that no CPU FFT of 33 M points is needed, and against the same tensor pair split in two halves
+    of 64 channels, which DO take the reciprocal path: the loss is a mean over (n, c) planes, so the halves must average to the whole."""
+    d = dev()
+    H = W = 512
+    yy, xx = torch.meshgrid(torch.arange(H, device=d, dtype=torch.float32), torch.arange(W, device=d, dtype=torch.float32), indexing="ij")
+    amp = torch.linspace(0.5, 1.5, 128, device=d).view(1, 128, 1, 1)
+    p = (amp * torch.cos(2 * math.pi * (3 * yy / H + 5 * xx / W))).contiguous(memory_format=torch.channels_last)
+    t = torch.zeros_like(p)
+    whole = float(K.focal_frequency_loss(p, t, 1.0))
+    halves = [float(K.focal_frequency_loss(p[:, i:i + 64].contiguous(memory_format=torch.channels_last),
+                                           t[:, i:i + 64].contiguous(memory_format=torch.channels_last), 1.0)) for i in (0, 64)]
+    assert abs(whole - 0.5 * (halves[0] + halves[1])) <= 1e-6 * abs(whole), (whole, halves)
+    # closed form: plane c holds |F|^2 = A_c^2 H W / 4 in each of two conjugate bins (ortho norm), weight 1 on both, mean over the
+    # H W bins: A_c^2 / 2 per plane (the cosine known-answer test), then the mean over the planes
+    want = float((amp.double() ** 2 / 2).mean())
+    assert abs(whole - want) <= 2e-4 * want, (whole, want)
+    # backward runs too (the spectrum was weighted in place by the same pass)
+    pg = p.clone().requires_grad_(True)
+    K.focal_frequency_loss(pg, t, 1.0).backward()
+    assert torch.isfinite(pg.grad).all() and float(pg.grad.abs().max()) > 0
+
+
+def test_one_plane_direct_stats_call_is_refused_off_the_wide_grid(K):
+    """in the one-plane modes the C ABI lets a caller keep a conv on the direct kernel (planes without FAVAE_PLANES_WINO).
+    For Cout = 192 (tiles by 64, not by 128) the tile count the library reports is the Winograd kernel's 16 x 16 grid while the direct
+    kernel writes a 16 x 8 grid: the statistics / GroupNorm-backward variants must refuse that call instead of writing past `part`."""
+    import favae_hip as H_
+    from ctypes import byref
+    d = dev()
+    prev = K.set_conv_mode("h1")
+    try:
+        N, cin, cout, Hh, Ww = 1, 64, 192, 32, 32
+        desc = H_.make_conv_desc(N, Hh, Ww, cin, Hh, Ww, cout, 3, 3, 1, 1, 0, 0, 1)
+        if not H_.query("favae_conv_wino_ok", byref(desc), 0):
+            pytest.skip("one-plane Winograd switched off")
+        tiles = H_.query("favae_conv_stats_tiles", byref(desc), 0, 0)
+        assert tiles == (Hh // 16) * (Ww // 16)
+        x = torch.randn(N, cin, Hh, Ww, device=d).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(cout, cin, 3, 3, device=d) * 0.05).contiguous(memory_format=torch.channels_last)
+        wsp = torch.empty(H_.query("favae_split_weights_bytes", w.numel(), 1), dtype=torch.uint8, device=d)
+        H_.call("favae_split_weights", H_.ptr(w), H_.ptr(wsp), w.numel(), 1)
+        y = K.new_cl(N, cout, Hh, Ww, d)
+        guard = 4096
+        part = torch.full((N * tiles * cout * 2 + guard,), -7.0, dtype=torch.float64, device=d)
+        xb, ya = K.absmax(x), torch.zeros(1, device=d)
+        lib = H_.load()
+        rc = lib.favae_conv_fwd_split_stats(byref(desc), H_.ptr(x), H_.ptr(wsp), 1, H_.ptr(xb), None, None, None, None, H_.ptr(y),
+                                            H_.ptr(part), N * tiles * cout * 2 * 8, H_.ptr(ya), H_.stream())
+        torch.cuda.synchronize()
+        assert rc == 3, rc                       # FAVAE_ERR_UNSUPPORTED
+        assert bool((part[-guard:] == -7.0).all()), "the refused call wrote behind the partial-sum buffer"
+        # the shape the wide tiling takes (Cout = 256) keeps accepting the direct call: both kernels share the 16 x 8 grid there
+        desc2 = H_.make_conv_desc(N, Hh, Ww, cin, Hh, Ww, 256, 3, 3, 1, 1, 0, 0, 1)
+        w2 = (torch.randn(256, cin, 3, 3, device=d) * 0.05).contiguous(memory_format=torch.channels_last)
+        wsp2 = torch.empty(H_.query("favae_split_weights_bytes", w2.numel(), 1), dtype=torch.uint8, device=d)
+        H_.call("favae_split_weights", H_.ptr(w2), H_.ptr(wsp2), w2.numel(), 1)
+        t2 = H_.query("favae_conv_stats_tiles", byref(desc2), 0, 0)
+        assert t2 == (Hh // 8) * (Ww // 16)
+        y2 = K.new_cl(N, 256, Hh, Ww, d)
+        part2 = torch.zeros((N * t2 * 256 * 2,), dtype=torch.float64, device=d)
+        rc = lib.favae_conv_fwd_split_stats(byref(desc2), H_.ptr(x), H_.ptr(wsp2), 1, H_.ptr(xb), None, None, None, None, H_.ptr(y2),
+                                            H_.ptr(part2), part2.numel() * 8, H_.ptr(ya), H_.stream())
+        torch.cuda.synchronize()
+        assert rc == 0, rc
+        s = part2.view(N, t2, 256, 2)[..., 0].sum(1)
+        ref = y2.double().sum((2, 3))
+        assert float((s - ref).abs().max()) <= 1e-6 * float(ref.abs().max()) + 1e-9
+    finally:
+        K.set_conv_mode(prev)
+
+
 def test_ffl_rejects_oversized_lines(K):
     p = torch.zeros(1, 1, 2, 1025, device=dev())
     with pytest.raises(RuntimeError):

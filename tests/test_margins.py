@@ -1,0 +1,57 @@
+"""CPU: the parity bars of the GPU model tests against what the kernels achieved on MI355X.
+
+`profiles/r06_parity_margins.txt` is the record of one full `pytest -m gpu` run (tests/margins.py appends `test | quantity | achieved
+| bar` at every tolerance check).  A bar far above the achieved error guards nothing: every stage-0 family's bar must be within 10 x
+of the worst error of that family over all fixtures, and at most north_star's 1e-4 (sigma gradients excepted, see test_gpu_model.py)."""
+import collections
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATH = os.path.join(ROOT, "profiles", "r06_parity_margins.txt")
+STAGE0 = ("test_forward_against_reference_golden", "test_train_step_f4_against_reference_golden",
+          "test_train_step_non_pow2_resolution_against_reference_golden", "test_train_step_variants_against_reference_golden",
+          "test_train_step_cfg1_256_against_reference_golden", "test_train_step_at_baseline_sizes_against_reference_golden")
+
+
+def family(name):
+    if name.startswith("grad"):
+        return "grad-sigma" if "sigma" in name else "grad"
+    if name.startswith("x_recon"):
+        return "x_recon"
+    if name.startswith("loss") or name.startswith("dsl"):
+        return "loss"
+    return None
+
+
+def rows():
+    out = []
+    for line in open(PATH):
+        if line.startswith("#") or "|" not in line:
+            continue
+        t, n, e, b = [v.strip() for v in line.split("|")]
+        out.append((t, n, float(e), float(b)))
+    return out
+
+
+def test_stage0_bars_are_within_ten_times_the_achieved_error():
+    worst, bars, count = collections.defaultdict(float), collections.defaultdict(set), collections.Counter()
+    for t, n, e, b in rows():
+        f = family(n)
+        if f is None or not t.startswith(STAGE0):
+            continue
+        assert e < b, (t, n, e, b)
+        worst[f] = max(worst[f], e)
+        bars[f].add(b)
+        count[f] += 1
+    assert set(worst) == {"grad", "grad-sigma", "x_recon", "loss"}, sorted(worst)
+    assert count["grad"] >= 300 and count["loss"] >= 50, dict(count)      # every checked tensor of every fixture is in the record
+    for f, w in worst.items():
+        for b in bars[f]:
+            assert b <= 10.0 * w * 1.0001, "%s: bar %.1e is more than 10 x the worst achieved error %.2e" % (f, b, w)
+            assert b <= (1e-3 if f == "grad-sigma" else 1e-4), (f, b)
+
+
+def test_record_covers_every_baseline_size():
+    tests = {t for t, _, _, _ in rows()}
+    for tag in ("cfg1_256", "cfg2_256", "f4_256", "gan_128", "cfg5_256"):
+        assert any(tag in t for t in tests), tag

@@ -18,7 +18,6 @@ dev = torch.device("cuda:0")
 raw = ctypes.CDLL(LIB)
 raw.favae_debug_wino_trace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 N = 64 * 8 * 48 * 8
-SKEW = os.environ.get("FAVAE_WINO_SKEW", "1") != "0"
 
 
 def read():
@@ -50,25 +49,6 @@ def report(name, t, KC):
     rows = [r for r in range(3, KC)]             # steady-state periods (generic copies of the loop body): chunk index r - 1
     if not rows:
         rows = [1]
-    if SKEW:                                     # out-of-phase wave groups (conv_wino.h SKEW): stamps 0 M 1 barrier 2 T 3 barrier 4
-        okg = (t[:, :, 0, 0] > 0).all(axis=1)
-        for gname, sl in (("group A (waves 0-3)", slice(0, 4)), ("group B (waves 4-7)", slice(4, 8))):
-            c = t[okg][:, sl][:, :, rows, :]
-            tot = (c[..., 4] - c[..., 0]).mean()
-            print("  -- %s: period %.0f cycles" % (gname, tot))
-            for i, nm in enumerate(["M: weight fragment 3 + A fragments + 24 MFMAs", "barrier wait", "T: patch, staging, transform + split, weight requests", "barrier wait"]):
-                dd = c[..., i + 1] - c[..., i]
-                print("     %-56s %7.0f cycles  %5.1f %%   (p10 %6.0f  p90 %6.0f)" % (nm, dd.mean(), 100 * dd.mean() / tot, np.percentile(dd, 10), np.percentile(dd, 90)))
-        if (t[okg][:, :, rows, 5] > 0).all():        # FAVAE_WINO_TRACE2 build: stamps inside the phases
-            c = t[okg][:, :, rows, :]
-            print("  inside M: start -> A fragments arrived %.0f, -> last MFMA issued %.0f | inside T: start -> patch arrived %.0f, -> transform issued %.0f, -> staging + end %.0f"
-                  % ((c[..., 5] - c[..., 0]).mean(), (c[..., 1] - c[..., 5]).mean(), (c[..., 6] - c[..., 2]).mean(),
-                     (c[..., 7] - c[..., 6]).mean(), (c[..., 3] - c[..., 7]).mean()))
-        ca, cb = t[okg][:, 0:4][:, :, rows, :], t[okg][:, 4:8][:, :, rows, :]
-        print("  start of B's M(k) - start of A's M(k): %.0f cycles; end of A's T - start of B's M(k): %.0f" %
-              ((cb[..., 0] - ca[..., 0]).mean(), (ca[..., 3] - cb[..., 0]).mean()))
-        print("  24 MFMAs = 768 pipe cycles per wave; %d chunks" % KC)
-        return
     if True:
         groups = [("all waves", slice(0, 8), ["read_patch + mma(0) + load_b", "barrier 1 wait", "store_raw + load_raw", "transform + split + V stores",
                                              "mma(1..3) + load_b", "barrier 2 wait"])]

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../fa-vae_amd/csrc"
 B=/tmp/favae_trace_build; mkdir -p $B
 for f in conv norm gemm blur ffl vq misc lpips trans prof; do
-  if [ $f = conv ]; then X="-DFAVAE_WINO_TRACE $WINO_TRACE_EXTRA"; else X=""; fi
+  if [ $f = conv ]; then X="-DFAVAE_WINO_TRACE"; else X=""; fi
   if [ $f = conv ] || [ ! -f $B/$f.o ] || [ $f.hip -nt $B/$f.o ]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -w $X -c $f.hip -o $B/$f.o &
   fi
