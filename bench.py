@@ -456,6 +456,16 @@ def main():
         t = time.perf_counter() - t0
         return t, prof.stop(), o
 
+    # distributed runs: the gradient-exchange arm is MEASURED on the job's first steps (favae_step.CommArmProbe: 9 steps, untimed here,
+    # in front of the W warm-up steps), not assumed; the line says which arm the timed region ran and on what numbers
+    n_probe = 0
+    while ts.comm_probe is not None and ts.comm_probe.active and n_probe < 16:
+        ts.step(xs[n_probe % 2])
+        n_probe += 1
+    if ts.exchange is not None:
+        exchange_desc = ("RCCL all-reduce, %d segments, %s (%s)" % (
+            len(ts.exchange.segments), "queued behind backward" if ts.exchange.defer else "overlapped with backward",
+            (ts.comm_choice or {}).get("how", "")))
     for i in range(args.warmup):
         ts.step(xs[i % 2])
     PROF_STEPS = min(args.steps, 4)
@@ -479,7 +489,7 @@ def main():
     if use_dist and ts.exchange is not None and not args.no_comm_diag:
         cb = ts.model.quantizer._codebook
         was_defer, was_timing = ts.exchange.defer, ts.exchange.timing
-        comm = {"default_arm": "defer" if was_defer else "eager", "steps_per_arm": 3, "arms": {}}
+        comm = {"default_arm": "defer" if was_defer else "eager", "chosen": ts.comm_choice, "steps_per_arm": 3, "arms": {}}
         for arm, defer in (("defer", True), ("eager", False)):
             ts.exchange.defer = defer
             # (i) the arm's step time WITHOUT any instrumentation: 1 warm-up + 3 steps between barrier + synchronize pairs, max over ranks

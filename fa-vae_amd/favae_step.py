@@ -163,6 +163,63 @@ class GradExchange:
         return {"backward_ms": t_end, "segments": rows}
 
 
+class CommArmProbe:
+    """Which arm of the gradient exchange -- every segment's all-reduce queued behind backward ("defer") or started where backward
+    finishes the segment ("eager") -- is faster on THIS job is measured on the job's own first steps, not assumed (VERDICT r05 item 8:
+    no N > 1 run has ever been observed here).  No extra training steps: the caller's steps are timed in blocks
+
+        2 warm-up (defer) | 3 timed (defer) | 1 warm-up (eager) | 3 timed (eager)
+
+    with a barrier + device synchronisation at the block boundaries only (4 in the first 9 steps).  The two block times are MAX-reduced
+    over the ranks, so every rank takes the same decision from the same numbers; eager must win by more than 0.5 % (noise keeps the
+    collectives off the conv kernels' CUs).  FAVAE_COMM_DEFER=0|1 in the environment pins an arm and switches the probe off;
+    FAVAE_COMM_AUTO=0 keeps the default (defer).  Pure host logic: exercised over gloo on CPU (tests/test_distributed_gloo.py)."""
+    PLAN = (("warm", True, 2), ("defer", True, 3), ("warm", False, 1), ("eager", False, 3))
+
+    def __init__(self, exchange, device):
+        import time
+        self._now = time.perf_counter
+        self.ex, self.dev = exchange, device
+        self.block, self.count, self.t0, self.ms = 0, 0, None, {}
+        self.active, self.choice = True, None
+        self._enter()
+
+    def _sync(self):
+        dist.barrier()
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+
+    def _enter(self):
+        name, defer, _ = self.PLAN[self.block]
+        self.ex.defer = defer
+        if name != "warm":
+            self._sync()
+            self.t0 = self._now()
+
+    def step_done(self):
+        """call once at the end of every training step while `active`"""
+        if not self.active:
+            return
+        name, _, n = self.PLAN[self.block]
+        self.count += 1
+        if self.count < n:
+            return
+        if name != "warm":
+            self._sync()
+            self.ms[name] = 1e3 * (self._now() - self.t0) / n
+        self.block, self.count = self.block + 1, 0
+        if self.block < len(self.PLAN):
+            self._enter()
+            return
+        t = torch.tensor([self.ms["defer"], self.ms["eager"]], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        d, e = float(t[0]), float(t[1])
+        arm = "eager" if e < 0.995 * d else "defer"
+        self.ex.defer = arm == "defer"
+        self.choice = {"arm": arm, "how": "measured at start: 3 steps per arm, max over ranks", "ms_per_step": {"defer": d, "eager": e}}
+        self.active = False
+
+
 class TrainStep:
     def __init__(self, model, lr, betas=(0.5, 0.9), eps=1e-8, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01,
                  sigma_lr=2.0e-7, distributed=False, train_disc=False, disc_weight=0.75, lpips=None, perceptual_weight=1.0,
@@ -202,6 +259,8 @@ class TrainStep:
             self.dparams = list(model.discriminator.parameters())
             self.dpflat, self.dgflat, self.dmflat, self.dvflat = _flatten(self.dparams, dev)
         self.exchange = None
+        self.comm_probe = None                    # CommArmProbe while the gradient-exchange arm is being measured
+        self.comm_choice = None                   # {"arm": "defer" | "eager", "how": ..., ["ms_per_step": {...}]} once distributed
         if self.distributed:
             self._broadcast_initial_state()
             self._setup_overlapped_exchange()
@@ -284,6 +343,14 @@ class TrainStep:
                                      timing=os.environ.get("FAVAE_COMM_TIMING", "0") == "1")
         self._armed = False
         self._bwd_events = None
+        # the arm is measured on the job's first steps unless the environment pins it (CommArmProbe)
+        if "FAVAE_COMM_DEFER" in os.environ:
+            self.comm_choice = {"arm": "defer" if self.exchange.defer else "eager", "how": "pinned by FAVAE_COMM_DEFER"}
+        elif os.environ.get("FAVAE_COMM_AUTO", "1") == "0":
+            self.comm_choice = {"arm": "defer", "how": "default (FAVAE_COMM_AUTO=0)"}
+        else:
+            self.comm_probe = CommArmProbe(self.exchange, self.gflat.device)
+            self.comm_choice = {"arm": "defer", "how": "being measured (first 9 steps)"}
 
         def mark(i):
             def cb():
@@ -518,4 +585,8 @@ class TrainStep:
             self.wino.refresh()
         if self.train_disc:
             out.update(self.disc_step(x))
+        if self.comm_probe is not None and self.comm_probe.active:
+            self.comm_probe.step_done()
+            if not self.comm_probe.active:
+                self.comm_choice = self.comm_probe.choice
         return out

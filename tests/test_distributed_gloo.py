@@ -261,6 +261,69 @@ def test_trainstep_host_logic_two_ranks(overlap):
             assert owners == [3], (a, b, owners)
 
 
+def _probe_worker(rank, world, port, q, slow_eager):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), FAVAE_OVERLAP_COMM="1")
+    os.environ.pop("FAVAE_COMM_DEFER", None)
+    os.environ.pop("FAVAE_COMM_AUTO", None)
+    import time
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from favae_step import TrainStep
+    torch.manual_seed(100)
+    model = _ToyModel()
+    ts = TrainStep(model, lr=1e-3, distributed=True, ffl_weight=0.0, dsl_weight=0.0)
+    assert ts.comm_probe is not None and ts.comm_probe.active and ts.exchange.defer and ts.comm_choice["how"].startswith("being measured")
+    x = torch.randn(2, 6, generator=torch.Generator().manual_seed(7 + rank))
+    arms = []
+    for step in range(12):                                  # the host side of TrainStep.step(): backward, finish, probe tick
+        arms.append("defer" if ts.exchange.defer else "eager")
+        ts.gflat.zero_()
+        loss = ((model(x) - x) ** 2).mean() + 0.1 * model.taps
+        ts.backward({"loss_g": loss})
+        if not ts.exchange.defer and slow_eager and rank == 1:
+            time.sleep(0.05)                                # ONE rank is slow in the eager arm: the MAX over ranks must decide for all
+        if ts.exchange.defer and not slow_eager and rank == 0:
+            time.sleep(0.05)
+        ts.exchange.finish()
+        if ts.comm_probe.active:
+            ts.comm_probe.step_done()
+            if not ts.comm_probe.active:
+                ts.comm_choice = ts.comm_probe.choice
+    q.put((rank, {"arms": arms, "choice": ts.comm_choice}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("slow_eager", [True, False])
+def test_comm_arm_is_measured_at_start_and_agreed_across_ranks(slow_eager):
+    """favae_step.CommArmProbe over gloo, world 2: 2 warm-up + 3 timed steps deferred, 1 + 3 eager, then every rank keeps the SAME arm
+    -- the one whose slowest rank was faster -- for the rest of the job."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_probe_worker, args=(r, world, port, q, slow_eager)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = "defer" if slow_eager else "eager"
+    for r in range(world):
+        assert got[r]["arms"][:9] == ["defer"] * 5 + ["eager"] * 4, got[r]["arms"]
+        assert got[r]["arms"][9:] == [want] * 3, got[r]["arms"]
+        ch = got[r]["choice"]
+        assert ch["arm"] == want and ch["how"].startswith("measured at start") and set(ch["ms_per_step"]) == {"defer", "eager"}
+    assert got[0]["choice"]["ms_per_step"] == got[1]["choice"]["ms_per_step"], "ranks decided on different numbers"
+
+
+def test_comm_arm_pinned_by_the_environment():
+    from favae_step import CommArmProbe  # noqa: F401
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fa-vae_amd", "favae_step.py")).read()
+    assert 'if "FAVAE_COMM_DEFER" in os.environ:' in src and '"pinned by FAVAE_COMM_DEFER"' in src
+
+
 def test_segments_are_final_when_fired():
     """World 1 (the all-reduce is the identity): what fire(i) hands to the collective equals the gradient at the end of backward,
     for every segment.  A layout that puts the encoder's sigmas into the encoder.mid segment fails here: the taps in front of `mid`

@@ -38,6 +38,11 @@ def test_bench_under_torchrun_rccl():
             assert t1 >= t0 and ov >= 0 and ex >= -1e-3 and abs((t1 - t0) - (ov + ex)) < 1e-2
     for mb, t0, t1, ov, ex in c["arms"]["defer"]["segments"]:
         assert ov < 0.05, "deferred arm: nothing starts before backward has ended"
+    # the arm the timed region ran was MEASURED on the job's first steps (favae_step.CommArmProbe), world 1 over RCCL here
+    ch = c["chosen"]
+    assert ch["arm"] in ("defer", "eager") and ch["arm"] == c["default_arm"] and ch["how"].startswith("measured at start"), ch
+    assert set(ch["ms_per_step"]) == {"defer", "eager"} and min(ch["ms_per_step"].values()) > 0
+    assert ("queued behind backward" if ch["arm"] == "defer" else "overlapped with backward") in res["config"]["gradient_exchange"]
 
 
 def test_model_under_torch_ddp():

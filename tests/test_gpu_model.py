@@ -312,6 +312,42 @@ def test_train_step_at_baseline_sizes_against_reference_golden(golden_dir, gtag,
     assert n >= 3
 
 
+def test_full_bench_batch_gives_the_reference_indices_on_its_first_images(golden_dir):
+    """Parity evidence AT THE BENCHMARKED SIZE: BASELINE configs[1] runs batch 32; the reference fixture
+    `cfg2_256` holds batch 2 of it (a CPU reference step at batch 32 takes minutes and 77 GB).  Every operator in front of the codebook
+    lookup is per-image (GroupNorm statistics per image, attention per image; models/vqgan_fcm.py:112-122, models/codec.py:125-314), so a
+    batch of 32 whose first two images are the fixture's must reproduce the REFERENCE's indices on those two -- bit for bit -- whatever
+    the other thirty are (here: bench.py's randn(seed 1234).clamp(-1, 1) images), in train mode (the lookup precedes the EMA update,
+    models/l2_quantize.py:403-438) and in eval mode; and the x_recon of the two images must be the batch-2 run's (decoder: per-image too)."""
+    g = np.load(os.path.join(golden_dir, "cfg2_256.npz"))
+    B, H, W, seed = [int(v) for v in g["cfg2_256.shape"]]
+    gen = torch.Generator().manual_seed(1234)
+    x32 = torch.randn(32, 3, H, W, generator=gen).clamp_(-1.0, 1.0)
+    x32[:B] = O.det_input(B, H, W, seed)
+    x32 = x32.to(DEV)
+    gap = g["cfg2_256.index_gap"]
+    for mode in ("train", "eval"):
+        m, _, _ = build("cfg2")
+        m.train() if mode == "train" else m.eval()
+        with torch.no_grad():
+            _, _, ind32, _ = m.encode(x32)
+            m2, _, _ = build("cfg2")
+            m2.train() if mode == "train" else m2.eval()
+            _, _, ind2, _ = m2.encode(x32[:B].contiguous())
+        assert tuple(ind32.shape) == (32, 16, 16) and ind32.dtype == torch.int64
+        assert check_indices(ind32[:B].cpu().numpy(), g["cfg2_256.indices"], gap, "batch 32, images 0-1, " + mode) == 0
+        assert torch.equal(ind32[:B], ind2), "indices of an image depend on its batch neighbours (%s)" % mode
+        assert len(torch.unique(ind32[B:])) > 32            # the other thirty went through the lookup as well
+    model, _, _ = build("cfg2")
+    model.eval()
+    with torch.no_grad():
+        xr32 = model(x32, stage=0)[0]
+        xr2 = model(x32[:B].contiguous(), stage=0)[0]
+    # (not bit for bit: the fp16 operand planes are scaled by a power of two taken from max|x| over the WHOLE tensor, batch neighbours
+    # included -- another rounding of the same values; the fixture's own x_recon bar applies)
+    close(xr32[:B], xr2, XRECON_TOL, "x_recon of images 0-1: batch 32 vs batch 2")
+
+
 @pytest.mark.parametrize("mtag,hw", [("nonpair_conv", 64), ("cfg1_k3", 64), ("f4_same_conv", 32)])
 def test_side_stream_weight_gradients_are_race_free(mtag, hw):
     """Weight gradients run on a second HIP stream and read dy / x there.  The autograd engine may accumulate IN PLACE into a

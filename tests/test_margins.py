@@ -44,7 +44,7 @@ def test_stage0_bars_are_within_ten_times_the_achieved_error():
         bars[f].add(b)
         count[f] += 1
     assert set(worst) == {"grad", "grad-sigma", "x_recon", "loss"}, sorted(worst)
-    assert count["grad"] >= 300 and count["loss"] >= 50, dict(count)      # every checked tensor of every fixture is in the record
+    assert count["grad"] >= 150 and count["grad-sigma"] >= 20 and count["loss"] >= 50, dict(count)      # every checked tensor of every fixture is in the record
     for f, w in worst.items():
         for b in bars[f]:
             assert b <= 10.0 * w * 1.0001, "%s: bar %.1e is more than 10 x the worst achieved error %.2e" % (f, b, w)
