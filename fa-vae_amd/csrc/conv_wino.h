@@ -11,10 +11,13 @@
 //
 // Workgroup = 16 x 16 output pixels (8 x 8 Winograd tiles = the 64 rows of two MFMA row blocks) x 64 output channels, 8 waves, two per
 // SIMD with 256 registers each: wave (b, c) owns the four Winograd positions (a, b), a = 0..3, for the 32 output channels of half c,
-// i.e. the accumulators M[a][b] of 64 tiles x 32 channels (8 x f32x16 = 128 registers).  On this part a SIMD's MFMAs and its other
-// vector instructions do not overlap (tools/experiments/mfma_valu_overlap.hip: time(interleaved) = time(MFMA) + time(FMA), also with
-// two waves per SIMD), so the design minimises matrix + vector instructions per output and uses the second wave only to hide LDS /
-// L2 / barrier latency.  Per 16-channel K chunk:
+// i.e. the accumulators M[a][b] of 64 tiles x 32 channels (8 x f32x16 = 128 registers).  What bounds the kernel (round 6,
+// profiles/r06_mfma_valu_sweep.txt, r06_wino_skew_trace.txt): a SIMD hides up to five single-issue vector instructions in the 32-cycle
+// shadow of every v_mfma_f32_32x32x16, whichever of its waves issues them (rounds 3-5 read a 12-per-MFMA test as "times add"), and the K
+// loop issues only 3.4 per MFMA -- yet running the two waves of a SIMD half a chunk out of phase (one multiplies while the other
+// transforms; bit-identical, commit 9d865e0) was 3-8 % SLOWER: each phase waits on latency of its own (the weight fragments of a chunk
+// are 128 KB per CU streamed from L2 into registers, 1 KB per wave-instruction; LDS round trips of patch and A fragments), and two
+// waves in the SAME phase hide that for each other.  The second wave is there to hide LDS / L2 / barrier latency.  Per 16-channel K chunk:
 //   * the 18 x 18 input halo is loaded ONCE, transformed (fused GroupNorm / SiLU), scaled and staged as fp32 in LDS;
 //   * thread (tile, channel quad, half h) reads three rows of its 4 x 4 patch, forms two rows of B^T d B in registers (packed adds),
 //     splits the 8 positions into (hi, lo) fp16 planes and stores them position-major: V[position][plane][tile][16 k] -- a wave's

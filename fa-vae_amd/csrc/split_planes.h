@@ -68,8 +68,8 @@ template <> struct Scheme<2> {
     static constexpr int WREC = 16;        // {plane0[4 fp16], plane1[4]}
     // hi = rne(a) as a packed pair (v_cvt_pk_f16_f32); the residual a - hi from one mixed-precision FMA per value (v_fma_mix_f32: the
     // f16 half of the pair x -1 + the fp32 value: exact, the same bits as a - (float)hi) -- 8 vector instructions per four values
-    // behind the scaling; the compiler's own lowering of the C expression converts every hi twice (16).  MFMAs and the other vector
-    // instructions of a SIMD do not overlap on this part (tools/experiments/mfma_valu_overlap.hip): every one saved is matrix time.
+    // behind the scaling; the compiler's own lowering of the C expression converts every hi twice (16).  A SIMD hides about five vector
+    // instructions per MFMA (profiles/r06_mfma_valu_sweep.txt); the direct kernels issue 3-12: beyond the fifth every one costs ~4 cycles.
     static __device__ __forceinline__ void split4(const float4 v, float S, uint2 (&p)[2]) {
         const float a0 = v.x * S, a1 = v.y * S, a2 = v.z * S, a3 = v.w * S;
         unsigned h01, h23, l01, l23;

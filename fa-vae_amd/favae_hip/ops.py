@@ -584,7 +584,7 @@ def _side_stream():
         # streams still run a pair of spin kernels concurrently (streams_overlap above: the cross-stream event waits of every
         # weight-gradient launch are what serialises on an oversubscribed queue).  8 queues remove it (134.7 ms with the full
         # distributed path): favae_hip/__init__.py and bench.py ask for them before HIP is initialised; a process that initialised HIP
-        # earlier with the default gets a warning from TrainStep (profiles/r05_dist_overhead.txt, tools/experiments/r05/dist_overhead*.sh).
+        # earlier with the default gets a warning from TrainStep (profiles/r05_dist_overhead.txt).
         _SIDE["stream"] = torch.cuda.Stream(priority=int(os.environ.get("FAVAE_SIDE_PRIORITY", "0")))
     return _SIDE["stream"]
 

@@ -87,7 +87,7 @@ class GradExchange:
         self.side_stream = side_stream          # callable -> the stream that carries the weight gradients (or None)
         # defer: fire(i) only marks segment i; every all-reduce is queued by finish(), behind backward (FAVAE_COMM_DEFER=1).  The
         # collectives then never compete with the whole-CU conv kernels for CUs -- the A/B arm for the first multi-GPU run: whether the
-        # eagerly queued segments really overlap, or slow the conv chain by more than they hide, has never been observed.
+        # eagerly queued segments really overlap, or slow the conv chain by more than they hide, has never been observed (profiles/HISTORY.md: round-5 DESIGN section 6).
         self.defer = defer
         # timing: one event in front of every segment's collective and one behind it, both on the communication stream (the collective
         # is queued there: its end event is ordered behind it); report() turns them into an overlap table against the backward pass
@@ -123,7 +123,7 @@ class GradExchange:
                 if self.timing:
                     # end of the segment: the COMMUNICATION stream waits for the collective (it would only queue the next segment's
                     # collective behind it anyway) and takes the time stamp.  Round 4 waited on a watcher stream per segment: that
-                    # block alone cost 30 ms per step (132 -> 165, bisected in tools/experiments/r05/comm_timing_cost2.sh)
+                    # block alone cost 30 ms per step (132 -> 165, bisected on the box: profiles/r05_dist_overhead.txt)
                     for w in ws:
                         w.wait()
                     ev1 = torch.cuda.Event(enable_timing=True)
@@ -337,7 +337,7 @@ class TrainStep:
         self.exchange = GradExchange(self.gflat, segs, side_stream=K.side_stream_flushed,
                                      # default since the end of round 4: every collective behind backward.  RCCL's reduction kernels
                                      # would otherwise share SIMDs with this library's MFMA waves -- the situation in which two of its own
-                                     # kernels turned out not to be bit-reproducible and which nobody has been able to run
+                                     # kernels turned out not to be bit-reproducible (profiles/HISTORY.md: round-5 DESIGN section 6) and which nobody has been able to run
                                      # here (single-GPU boxes).  331 MB over xGMI is ~2 ms of a 135 ms step; FAVAE_COMM_DEFER=0 = eager overlap
                                      defer=os.environ.get("FAVAE_COMM_DEFER", "1") != "0",
                                      timing=os.environ.get("FAVAE_COMM_TIMING", "0") == "1")

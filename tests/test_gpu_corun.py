@@ -2,7 +2,7 @@
 on a second stream of the same process -- the situation of every backward pass (weight-gradient stream) and the one in which round 4 found
 two kernels that did not: the GroupNorm-backward apply pass without its epilogue (a store-data hazard the compiler does not guard: fixed in
 common.h bstore) and the FFT passes of the focal frequency loss (SLP-packed radix-4 butterflies: ffl.hip is built without SLP
-vectorisation).  Both only failed when their waves shared a SIMD with waves sitting in MFMA sequences; see DESIGN.md 6."""
+vectorisation).  Both only failed when their waves shared a SIMD with waves sitting in MFMA sequences; see profiles/HISTORY.md 6."""
 import os
 import sys
 from ctypes import byref

@@ -58,7 +58,7 @@ def test_model_under_torch_ddp():
 def _run_probe(world, variant, overlap, port, backend="nccl", extra_env=None):
     """One launch, no repetition: a run whose ranks disagree numerically FAILS.  Rounds 3-4 repeated the
     two-processes-on-one-GPU runs up to twice because the FFT kernels were not bit-reproducible next to another process's MFMA waves
-    (DESIGN.md 6); `ffl.hip` has been built without SLP vectorisation since (0 of 1200 two-process steps differ), so a disagreement is a
+    (profiles/HISTORY.md: round-5 DESIGN section 6); `ffl.hip` has been built without SLP vectorisation since (0 of 1200 two-process steps differ), so a disagreement is a
     finding again.  The probe's DIAG lines are printed with the failure."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FAVAE_PROBE_VARIANT=variant, FAVAE_OVERLAP_COMM="1" if overlap else "0",
                FAVAE_PROBE_BACKEND=backend, **(extra_env or {}))

@@ -408,7 +408,7 @@ def test_winograd_f44_on_integer_data(K, N, cin, cout, H, W):
     """F(4x4, 3x3) kernel (csrc/conv_wino4.h) on data whose fp16 hi planes are exact and whose lo planes are zero: inputs in {-1, 0, 1},
     weights 576 * {-1, 0, 1} (G g G^T is then integral: G has 1/4, 1/6, 1/12, 1/24).  What is left is the rounding of the weight
     transform's own constants (1/6 is not a binary fraction: cancelling terms leave 1e-7 of the output range; a delta input reproduces
-    the flipped kernel to that level, tools/experiments/r05/wino4_debug.py) -- so ANY wrong position, plane, tile, channel or K-chunk
+    the flipped kernel to that level) -- so ANY wrong position, plane, tile, channel or K-chunk
     mapping shows as an error orders of magnitude above the 2e-6 bar.  Forward (bias + residual + statistics epilogue) and data gradient."""
     import favae_hip as H_
     d = dev()

@@ -1,7 +1,7 @@
 """CPU (cross-compile only): no 128-bit buffer store of the library is followed, in the next issue slot, by an instruction that writes
 its data registers.  gfx950 needs a wait state there (the ISA manuals' store-data hazard); the compiler's hazard recogniser leaves it out
 when the store takes its soffset from an SGPR, as every `__builtin_amdgcn_raw_buffer_store_b128` of this library does -- round 4 found
-wrong first components in gn_bwd_apply_rows_kernel<., false> next to the weight-gradient stream (tools/experiments/
+wrong first components in gn_bwd_apply_rows_kernel<., false> next to the weight-gradient stream (profiles/HISTORY.md, round-5 DESIGN section 6, tools/experiments/
 apply_race.py; common.h bstore carries the wait state).  The scanner must also still SEE the pattern in a build without the wait state."""
 import os
 import shutil
@@ -68,7 +68,7 @@ def test_no_unguarded_128bit_buffer_store(unit_asm, tmp_path):
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
 def test_no_half_dead_packed_fp32_result_is_overwritten(unit_asm, tmp_path):
-    """Round 4's FFT finding: SLP vectorisation made `v_pk_fma_f32 v[6:7], ...` of which only v7 was used, followed within
+    """Round 4's FFT finding (profiles/HISTORY.md: round-5 DESIGN section 6): SLP vectorisation made `v_pk_fma_f32 v[6:7], ...` of which only v7 was used, followed within
     three instructions by an unpacked write of v6 -- and exactly those low halves came out wrong in 2-10 % of the launches next to MFMA
     waves on the same SIMD.  Round 5 builds EVERY unit without SLP (profiles/r05_slp_ab.txt: neutral in time); no unit's assembly may
     show the pattern, the Makefile must carry the flag, and the scanner must still find the pattern in an SLP build of ffl.hip."""

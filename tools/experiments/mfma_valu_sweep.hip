@@ -1,6 +1,6 @@
 // How many single-issue vector instructions does one SIMD hide in the shadow of a v_mfma_f32_32x32x16_f16 (32 pipe cycles)?
 // round 4/5 rejected every interleaved variant of the Winograd kernel on a 12-fillers-per-MFMA test
-// (mfma_valu_roles.hip), which cannot tell "times add" (32 + c*NV) from "up to 5 hidden, the rest exposed".  This sweeps NV.
+// (mfma_valu_roles.hip, removed in round 6: git history), which cannot tell "times add" (32 + c*NV) from "up to 5 hidden, the rest exposed".  This sweeps NV.
 //
 // One workgroup per CU (150 KB of LDS), 256 threads (ONE wave per SIMD) or 512 threads (TWO waves per SIMD).  Every SIMD executes
 // the same totals in every arrangement: MT MFMAs on four independent accumulators and NV*MT fillers on independent registers.
