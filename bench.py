@@ -273,8 +273,10 @@ def kernel_planes(name):
             return int(args[1])
         if name.startswith("conv_fwd_sp_kernel") or name.startswith("conv_wgrad_sp_kernel"):
             return int(args[-1])
+        if name.startswith("conv3x3_wino_sp_kernel") and len(args) >= 5:
+            return int(args[4])   # <XFORM, GB, SE, WIDE, PLN, storage type>: 2 = h3, 1 = h1, 4 = b1
         if name.startswith(("conv3x3_wino_sp_kernel", "conv3x3_winow_sp_kernel", "conv3x3_wino4_sp_kernel")):
-            return 2          # h3 only; priced on the direct conv's FLOPs (F(2x2) executes 4/9 of the products, F(4x4) 1/4)
+            return 2          # priced on the direct conv's FLOPs (F(2x2) executes 4/9 of the products, F(4x4) 1/4)
     except ValueError:
         pass
     return None
@@ -479,6 +481,7 @@ def main():
         per_rank = [args.batch * args.steps / float(v.item()) for v in allt]
         dt = max(float(v.item()) for v in allt)
     loss = float(out["loss_g"].reshape(-1)[0])
+    peak_mem = torch.cuda.max_memory_allocated(dev)
 
     # ---- communication diagnostics (untimed; every rank; world > 1 or FAVAE_FORCE_DIST=1): BOTH arms of the gradient exchange on
     # this object -- collectives queued behind backward (FAVAE_COMM_DEFER=1) and started where backward finishes each segment (=0) --
@@ -600,6 +603,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
+            "peak_mem_gib": rnd(peak_mem / 2.0 ** 30, 4),      # torch.cuda.max_memory_allocated over warm-up + timed region, this rank
             "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.precision],
             "data": "synthetic",
             "config": {"workload": (desc % args.codebook) + ", FFL 1.0 + DSL 0.01, %dx%d, batch %d/GPU, stage-0 step (discriminator "
@@ -607,7 +611,8 @@ def main():
                                    + (", discriminator training" if args.gan else "")
                                    + (", LPIPS term on random-init weights" if args.lpips else ", no LPIPS term") + ")"
                                    + {"fp32": "", "fp16": "; MIXED PRECISION h1: conv operands in one scaled fp16 plane, fp32 accumulate",
-                                      "bf16": "; MIXED PRECISION b1: conv operands in one bf16 plane, fp32 accumulate"}[args.precision],
+                                      "bf16": "; MIXED PRECISION b1: conv operands in one bf16 plane, fp32 accumulate, activations of the "
+                                              "ResnetBlock chain STORED as bf16 (%s)" % ("on" if K.bf16_storage() else "off: FAVAE_BF16_STORAGE=0")}[args.precision],
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss_g_last": rnd(loss, 7),
                        "gradient_exchange": exchange_desc},
         }

@@ -111,6 +111,75 @@ __device__ __forceinline__ auto make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
 }
 
+// ---- bf16 activation STORAGE (round 6; BASELINE configs[4] "bf16") ---------------------------------------------------------------
+// The 16-bit operand mode b1 rounds conv operands to one bf16 plane but, through round 5, kept every activation fp32 in HBM -- where
+// its big layers sit at the HBM roofline (2.1 GB per launch at 5.4 TB/s on 128 -> 128 @256^2).  With the storage type AT = bf16_t the
+// kernels on the ResnetBlock chain read and write activations / activation gradients as bf16 (round to nearest even on store, exact
+// widening on load) and keep every accumulation, statistic and reduction in fp32 / fp64 as before.  Thread -> channel mapping, LDS
+// layouts and arithmetic are those of the fp32 instantiation (AT = float, the default: bit-identical code): a thread's four channels
+// are one 8-byte instead of one 16-byte access.  act_off<AT>(e) = byte offset of element e.
+typedef unsigned short bf16_t;
+template <typename AT> struct ActT { static constexpr unsigned B = 4; };
+template <> struct ActT<bf16_t> { static constexpr unsigned B = 2; };
+__device__ __forceinline__ float bf16_up(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ __forceinline__ unsigned bf16_pack_rne(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ unsigned short bf16_rne(float v) { return (unsigned short)(bf16_pack_rne(v, 0.f) & 0xffffu); }
+// four consecutive channels at byte offset voff + soff
+template <typename AT, typename R>
+__device__ __forceinline__ float4 act_load4(R rsrc, unsigned voff, unsigned soff) {
+    if constexpr (sizeof(AT) == 4) {
+        return bload(rsrc, voff, soff);
+    } else {
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t u = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+        return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                           __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+    }
+}
+template <typename AT, typename R>
+__device__ __forceinline__ void act_store4(R rsrc, unsigned voff, unsigned soff, float4 v) {
+    if constexpr (sizeof(AT) == 4) {
+        bstore(rsrc, voff, soff, v);
+    } else {
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t u = {bf16_pack_rne(v.x, v.y), bf16_pack_rne(v.z, v.w)};
+        __builtin_amdgcn_raw_buffer_store_b64(u, rsrc, voff, soff, 0);
+    }
+}
+// one element through a buffer descriptor (epilogues: a lane owns one channel of a pixel)
+template <typename AT, typename R>
+__device__ __forceinline__ float act_load1(R rsrc, unsigned voff, unsigned soff) {
+    if constexpr (sizeof(AT) == 4) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+    else return bf16_up((unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, soff, 0));
+}
+template <typename AT, typename R>
+__device__ __forceinline__ void act_store1(R rsrc, unsigned voff, unsigned soff, float v) {
+    if constexpr (sizeof(AT) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b16((short)bf16_rne(v), rsrc, voff, soff, 0);
+}
+// plain pointers (epilogue of the direct kernels)
+template <typename AT> __device__ __forceinline__ float act_get(const void* p, size_t i) {
+    if constexpr (sizeof(AT) == 4) return reinterpret_cast<const float*>(p)[i];
+    else return bf16_up(reinterpret_cast<const unsigned short*>(p)[i]);
+}
+// four consecutive channels from a plain pointer (element index i, a multiple of 4: 16-byte / 8-byte aligned)
+template <typename AT> __device__ __forceinline__ float4 act_get4(const void* p, size_t i) {
+    if constexpr (sizeof(AT) == 4) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+    else {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + i);
+        return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                           __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+    }
+}
+template <typename AT> __device__ __forceinline__ void act_put(void* p, size_t i, float v) {
+    if constexpr (sizeof(AT) == 4) reinterpret_cast<float*>(p)[i] = v;
+    else reinterpret_cast<unsigned short*>(p)[i] = bf16_rne(v);
+}
+
 // Zero arena (favae_set_zero_arena): a device range the caller guarantees to be all zero when an entry point receives a pointer into it
 // as a reduction target (max |x| scalars: atomicMax on the bit pattern needs a zeroed start).  Such targets are not memset again -- one
 // hipMemsetAsync per training step over the arena instead of one 4-byte memset launch per conv call (117-156 per step, 5 us + a queue

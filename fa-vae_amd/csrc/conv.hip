@@ -986,6 +986,7 @@ static bool wino_ok(const favae_conv_desc* d, bool has_affine);
 static bool wino4_ok(const favae_conv_desc* d, bool has_affine);
 // planes word of a call that passes Winograd records: F(2x2) records go with wino_ok, F(4x4) records (FAVAE_PLANES_WINO4 on top) with wino4_ok
 static bool wino_planes_ok(const favae_conv_desc* d, int planes, bool has_affine) {
+    planes &= ~FAVAE_PLANES_BF16IO;                                                          // storage type of the activations: not a records property
     if (planes == (conv_mode() | FAVAE_PLANES_WINO)) return wino_ok(d, has_affine);          // 2 (h3), 1 (h1) or 4 (b1) | the flag
     if (planes == (2 | FAVAE_PLANES_WINO | FAVAE_PLANES_WINO4)) return wino4_ok(d, has_affine);
     return false;
@@ -998,7 +999,8 @@ extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, co
         if (!wino_planes_ok(d, planes, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         FAVAE_REQUIRE(wsplit && (x_absmax || (planes & 0xff) == 4));
     } else {
-        FAVAE_REQUIRE(wsplit && (planes == 3 || planes == 4 || ((planes == 2 || planes == 1) && x_absmax)));
+        const int pl = planes & ~FAVAE_PLANES_BF16IO;
+        FAVAE_REQUIRE(wsplit && (pl == 3 || pl == 4 || ((pl == 2 || pl == 1) && x_absmax)));
     }
     return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr);
 }
@@ -1186,6 +1188,19 @@ static int wino_part_tiles(const favae_conv_desc* d, bool has_affine, int planes
 static bool direct_grid_mismatch(const favae_conv_desc* d, int planes, bool has_affine) {
     return conv_mode() != 2 && !(planes & FAVAE_PLANES_WINO) && wino_ok(d, has_affine) && !wino_wide_ok(d, has_affine);
 }
+static bool wgrad_row3_ok(const favae_conv_desc* d);
+// bf16 activation storage: does the kernel that would run `d` have the bf16 instantiation?  kind 0: forward / plain conv call
+// (favae_conv_fwd_split, _stats), 1: data gradient with the GroupNorm-backward epilogue (favae_conv_dgrad_gnbwd), 2: weight gradient.
+extern "C" int favae_conv_bf16io_ok(const favae_conv_desc* d, int has_affine, int kind) {
+    if (!desc_ok(d) || conv_mode() != 4) return 0;
+    if (kind == 2) {
+        if (!wgrad_row3_ok(d) || !use_nine() || nine_mode() != 1 || d->Hout != d->Hin || d->Wout != d->Win) return 0;
+        return (has_affine && d->act != FAVAE_ACT_NONE && d->act != FAVAE_ACT_SILU) ? 0 : 1;
+    }
+    if (!halo3_fp16_ok(d, has_affine != 0) || d->Cout <= 64) return 0;
+    if (kind == 1 && has_affine) return 0;
+    return 1;
+}
 extern "C" int favae_conv_gnbwd_tiles(const favae_conv_desc* d, int planes) {
     if (!desc_ok(d) || !halo3_fp16_ok(d, false)) return 0;
     if (wino_ok(d, false)) return wino_part_tiles(d, false, planes);
@@ -1251,7 +1266,17 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
                            (double)d->Cout * d->KH * d->KW * d->Cin));
     const bool wino = (wplanes & FAVAE_PLANES_WINO) != 0;     // Winograd records (favae_wino_weights): conv3x3_wino_sp_kernel
     const bool wino4 = (wplanes & FAVAE_PLANES_WINO4) != 0;   // ... F(4x4, 3x3) records: conv3x3_wino4_sp_kernel
+    // bf16 activation storage (round 6): x, resid, y (and the GroupNorm input of the GB epilogue) are bf16 tensors; scheme 4 only, and
+    // only the kernels with that instantiation (the dense 3x3 halo kernel and the wide Winograd kernel): favae_conv_bf16io_ok
+    const bool bf16io = (wplanes & FAVAE_PLANES_BF16IO) != 0;
     wplanes &= 0xff;
+    if (bf16io && (wplanes != 4 || wino4 || planes_out || ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)resid)) & 7) != 0))
+        return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (bf16io)          // the activation bytes of the note above at two bytes per element
+        FAVAE_PROF_NOTE(2.0 * d->N * d->Hout * d->Wout * d->Cout * d->KH * d->KW * d->Cin,
+                        2.0 * ((double)d->N * d->Hin * d->Win * d->Cin +
+                               (double)d->N * d->Hout * d->Wout * d->Cout * (1 + (resid ? 1 : 0) + (gb ? 1 : 0))) +
+                            4.0 * (double)d->Cout * d->KH * d->KW * d->Cin);
     const bool w6 = wplanes != 0;                            // pre-split weights: records start behind the header
     if (!w6) {
         const int tk = thin_kind(d, scale != nullptr);
@@ -1347,7 +1372,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     const bool buf_ok = !force_generic() && !force_nobuf() && d->Cin % 16 == 0 && xb < (1u << 31) && wb < (1u << 31) &&
                         (size_t)d->N * a.out_img * d->Cout * 4 < ((size_t)1 << 32) && (d->gather == FAVAE_GATHER_PLAIN || xf == 0);
     if (special && !(buf_ok && use_b6() && bn == 128 && w6 && d->gather == FAVAE_GATHER_PLAIN)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-    a.x_bytes = (unsigned)xb; a.aff_bytes = (unsigned)ab;
+    a.x_bytes = (unsigned)(bf16io ? xb / 2 : xb); a.aff_bytes = (unsigned)ab;
     a.planes_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)(wplanes ? wb / 16 * wrec_bytes(wplanes) : wb);
 #define FAVAE_LAUNCH_BUF(G, X)                                                                                     \
@@ -1415,6 +1440,28 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         }                                                                                                                   \
         FAVAE_KLAUNCH((conv3x3_wino_sp_kernel<X, GBV, SEV, WD, PL>), wgrid, dim3(512), wino::LDS_B, s, a);              \
     } while (0)
+#define FAVAE_LAUNCH_WINO_BF(X, GBV, SEV)                                                                                   \
+    do {                                                                                                                    \
+        static bool attr_set = false;                                                                                       \
+        if (!attr_set) {                                                                                                    \
+            (void)hipFuncSetAttribute((const void*)conv3x3_wino_sp_kernel<X, GBV, SEV, true, 4, bf16_t>,                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, wino::LDS_B);                             \
+            attr_set = true;                                                                                                \
+        }                                                                                                                   \
+        FAVAE_KLAUNCH((conv3x3_wino_sp_kernel<X, GBV, SEV, true, 4, bf16_t>), wgrid, dim3(512), wino::LDS_B, s, a);         \
+    } while (0)
+        if (bf16io) {                       // bf16 activation storage: the wide tiling with the bf16 plane
+            if (!(wplanes == 4 && wide)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+            if (gb) FAVAE_LAUNCH_WINO_BF(0, true, false);
+            else if (stats_part && xf == 0) FAVAE_LAUNCH_WINO_BF(0, false, true);
+            else if (stats_part) FAVAE_LAUNCH_WINO_BF(2, false, true);
+            else if (xf == 0) FAVAE_LAUNCH_WINO_BF(0, false, false);
+            else if (xf == 2) FAVAE_LAUNCH_WINO_BF(2, false, false);
+            else return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+            FAVAE_CHECK_LAUNCH();
+            return FAVAE_OK;
+        }
+#undef FAVAE_LAUNCH_WINO_BF
 #define FAVAE_LAUNCH_WINO(X, GBV, SEV)                                                                                      \
     do {                                                                                                                    \
         if (wplanes == 1 && wide) FAVAE_LAUNCH_WINO_T(X, GBV, SEV, true, 1);     /* one fp16 plane (h1) */            \
@@ -1444,6 +1491,21 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     } while (0)
 #define FAVAE_LAUNCH_HALO(X) FAVAE_LAUNCH_HALO_K(X, 3)
         if (planes_out && !(halo_ok && wplanes == 2 && xf != 3)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+        if (bf16io) {                       // bf16 activation storage: the dense 3x3 kernel with the bf16 plane
+            if (!(halo_ok && wplanes == 4) || (gb && (xf != 0 || bias || resid)) || (stats_part && (gb || !(xf == 0 || xf == 2))))
+                return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+#define FAVAE_LAUNCH_HALO_BF(X, GBV, SEV) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 4, 3, false, GBV, SEV, bf16_t>), hgrid, dim3(512), 0, s, a)
+            if (gb) FAVAE_LAUNCH_HALO_BF(0, true, false);
+            else if (stats_part && xf == 0) FAVAE_LAUNCH_HALO_BF(0, false, true);
+            else if (stats_part) FAVAE_LAUNCH_HALO_BF(2, false, true);
+            else if (xf == 0) FAVAE_LAUNCH_HALO_BF(0, false, false);
+            else if (xf == 1) FAVAE_LAUNCH_HALO_BF(1, false, false);
+            else if (xf == 2) FAVAE_LAUNCH_HALO_BF(2, false, false);
+            else FAVAE_LAUNCH_HALO_BF(3, false, false);
+#undef FAVAE_LAUNCH_HALO_BF
+            FAVAE_CHECK_LAUNCH();
+            return FAVAE_OK;
+        }
         const bool fp16p = wplanes == 2 || wplanes == 1 || wplanes == 4;           // schemes with the epilogue variants
         if (gb && !(halo_ok && fp16p && xf == 0 && !planes_out && !bias && !resid)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (stats_part && !(halo_ok && fp16p && (xf == 0 || xf == 2) && !planes_out && !gb)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
@@ -1467,6 +1529,8 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         else FAVAE_LAUNCH_HALO(3);
 #undef FAVAE_LAUNCH_HALO
 #undef FAVAE_LAUNCH_HALO_K
+    } else if (bf16io) {
+        return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     } else if (buf_ok && use_b6() && bn == 128) {
 #define FAVAE_LAUNCH_B6(G, X)                                                                     \
     do {                                                                                          \
@@ -1568,9 +1632,16 @@ static bool wgrad_row3_ok(const favae_conv_desc* d) {          // mirrors the `r
            d->Wout % 16 == 0 && xb < (1u << 31) && yb < (1u << 31) && d->KH == 3 && d->KW == 3 && d->pad == 1;
 }
 
-static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float* dy, const float* scale, const float* shift,
+static int conv_wgrad_impl(const favae_conv_desc* d_in, const float* x, const float* dy, const float* scale, const float* shift,
                            const float* x_absmax, const float* dy_absmax, const void* x_planes, const void* dy_planes, float* dw,
                            int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream, int* slabs_out) {
+    // bf16 activation storage (round 6): FAVAE_ACT_BF16IO on the descriptor's `act` = x and dy are bf16 tensors; only the nine-tap
+    // kernel of scheme 4 has that instantiation (favae_conv_bf16io_ok(d, has_affine, 2))
+    FAVAE_REQUIRE(d_in);
+    favae_conv_desc d_local = *d_in;
+    const bool bf16io = (d_local.act & FAVAE_ACT_BF16IO) != 0;
+    d_local.act &= ~FAVAE_ACT_BF16IO;
+    const favae_conv_desc* d = &d_local;
     FAVAE_REQUIRE(desc_ok(d) && x && dy && dw && ws);
     // fp16 planes need both operand maxima; without them the bf16 scheme (no range restrictions) runs
     const int cm = conv_mode();
@@ -1584,6 +1655,7 @@ static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float
     {
         const int tk = thin_kind(d, scale != nullptr);
         const int xf0 = scale ? (d->act == FAVAE_ACT_SILU ? 2 : (d->act == FAVAE_ACT_NONE ? 1 : 3)) : 0;
+        if (tk && bf16io) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (tk && xf0 != 3 && al16(x) && al16(dy) && al16(scale) && al16(shift) && al16(ws)) {
             ThinArgs t{};
             t.x = x; t.dy = dy; t.scale = scale; t.shift = shift; t.part = (float*)ws;
@@ -1674,7 +1746,20 @@ static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float
     const bool row3 = !special && buf_ok && use_b6() && use_row3() && bco == 128 && bci == 128 && d->gather == FAVAE_GATHER_PLAIN &&
                       d->KH == 3 && d->KW == 3 && d->pad == 1 && d->stride == 1;
     const bool nine = row3 && use_nine() && !x_planes && !dy_planes && d->Hout == d->Hin && d->Wout == d->Win;
-    if (nine) {
+    if (bf16io && !(nine && np == 4 && nine_mode() == 1 && xf != 3)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    if (bf16io) a.x_bytes = (unsigned)(xb / 2);
+    if (nine && bf16io) {
+        a.tiles_co = cdiv(d->Cout, 128);
+        a.tiles_ci = cdiv(d->Cin, 64);
+        const int tiles9 = a.tiles_co * a.tiles_ci;
+        int sps;
+        a.splitk = nine_splitk(d, tiles9, a.splitk, 256, &sps);
+        a.chunk = sps;
+        const dim3 g9((unsigned)(tiles9 * ((a.splitk + 7) / 8) * 8));
+        if (xf == 0) FAVAE_KLAUNCH((conv_wgrad_nine_sp_kernel<0, 4, 128, false, 1, bf16_t>), g9, dim3(512), 0, s, a);
+        else if (xf == 1) FAVAE_KLAUNCH((conv_wgrad_nine_sp_kernel<1, 4, 128, false, 1, bf16_t>), g9, dim3(512), 0, s, a);
+        else FAVAE_KLAUNCH((conv_wgrad_nine_sp_kernel<2, 4, 128, false, 1, bf16_t>), g9, dim3(512), 0, s, a);
+    } else if (nine) {
         // all nine taps per workgroup (BCO co x 64 ci), split-K over whole 16-pixel column strips
         const int nm = nine_mode();
         const int bco9 = nm == 3 ? 64 : 128;

@@ -410,8 +410,12 @@ __global__ __launch_bounds__(256) void split_w_kernel(const float4* __restrict__
 // ---------------------------------------------------------------------------------------------------------------
 // PL: also store the staged operand planes (ConvArgs::planes_out).  GB: GroupNorm-backward partial sums in the epilogue (gb_*)
 // SE: per-tile (sum y, sum y^2) of the output in the epilogue (gs_part): pass 1 of the GroupNorm that consumes this conv's output
-template <int XFORM, int SCH, int KS = 3, bool PL = false, bool GB = false, bool SE = false>
+// AT (round 6): storage type of the activation tensors x, resid, y (and the GroupNorm input of the GB epilogue) -- float, or bf16_t
+// (common.h: bf16 activation storage, scheme 4 only): a thread's four channels are one 8-byte access, an epilogue lane's channel 2 bytes.
+template <int XFORM, int SCH, int KS = 3, bool PL = false, bool GB = false, bool SE = false, typename AT = float>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 6 : 4, 8))) void conv3x3_halo_sp_kernel(ConvArgs a) {
+    static_assert(sizeof(AT) == 4 || (SCH == 4 && !PL), "bf16 activation storage: the one-bf16-plane scheme");
+    constexpr unsigned EB = ActT<AT>::B;
     static_assert(!PL || (SCH == 2 && KS == 3), "operand planes: dense 3x3 conv with two fp16 planes");
     static_assert(!GB || (XFORM == 0 && KS == 3 && !PL), "GroupNorm-backward sums: plain dense 3x3 data gradient");
     static_assert(!SE || (KS == 3 && !PL && !GB && SCH != 3), "output statistics: dense 3x3 forward conv, one or two planes");
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 
         const int y = ty0 - a.pad + hy, x = tx0 - a.pad_w + hx;
         hin[j] = wr_planes && hrow < HROWS && hy >= a.pad && hy < a.pad + TH && hx >= a.pad_w && hx < a.pad_w + TW;
         hok[j] = hrow < HROWS && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
-        vh[j] = hok[j] ? (unsigned)(((n * a.in_img + y * a.in_step * a.in_row + x * a.in_step + a.in_off) * a.Cin + q4 * 4) * 4) : FAVAE_OOB;
+        vh[j] = hok[j] ? (unsigned)(((n * a.in_img + y * a.in_step * a.in_row + x * a.in_step + a.in_off) * a.Cin + q4 * 4) * EB) : FAVAE_OOB;
     }
     const unsigned vs = (unsigned)((n * a.aff_stride + q4 * 4) * 4);
     const int brow = tid >> 2;                                           // weight row (output channel) staged by this thread
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && tid >= HROWS * 4 - 512) continue;              // second slot exists for the first 208 threads only
-            rh[j] = bload(rx, vh[j], sk);
+            rh[j] = act_load4<AT>(rx, vh[j], (unsigned)(kc * 16) * EB);
         }
         if (XFORM) {
             rsc = bload(rsc_d, vs, sk);
@@ -578,13 +582,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 
         const size_t obase = ((size_t)n * a.out_img + (size_t)ty0 * a.out_step * a.out_row + tx0 * a.out_step + a.out_off) * a.Cout + col;
         float xg[GB ? 16 : 1];
         if constexpr (GB) {              // the 16 x values first: one batch of independent loads in flight (32-bit offsets)
-            const auto rgx = make_rsrc(a.gb_x, (unsigned)((size_t)a.N * a.out_img * a.Cout * 4));
-            const unsigned ob32 = (unsigned)obase * 4u;
+            const auto rgx = make_rsrc(a.gb_x, (unsigned)((size_t)a.N * a.out_img * a.Cout * EB));
+            const unsigned ob32 = (unsigned)obase * EB;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                xg[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    rgx, ob32 + (unsigned)(((pr >> 4) * a.out_row + (pr & 15)) * a.Cout) * 4u, 0, 0));
+                xg[r] = act_load1<AT>(rgx, ob32 + (unsigned)(((pr >> 4) * a.out_row + (pr & 15)) * a.Cout) * EB, 0);
             }
         }
         float g_mu = 0.f, g_rs = 0.f, g_ga = 0.f, g_be = 0.f, f1 = 0.f, f2 = 0.f;
@@ -602,12 +605,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 
             float v = acc[j][r];
             if constexpr (S::SCALED) v = v * un_a * un_w;
             v += bv;
-            if (a.resid) v += a.resid[o];
-            if constexpr (!GB) a.y[o] = v;
+            if (a.resid) v += act_get<AT>(a.resid, o);
+            if constexpr (!GB) act_put<AT>(a.y, o, v);
             if constexpr (GB) {          // v = da at (pixel, channel col); the conv input x has the same shape
                 const float xh = (xg[r] - g_mu) * g_rs;
                 const float dyv = v * favae_act_grad(fmaf(xh, g_ga, g_be), a.gb_act & 0xff);
-                a.y[o] = (a.gb_act & FAVAE_GB_PREMUL) ? dyv : v;     // FAVAE_GB_PREMUL: da * act'(y), what the apply pass would recompute
+                act_put<AT>(a.y, o, (a.gb_act & FAVAE_GB_PREMUL) ? dyv : v);     // FAVAE_GB_PREMUL: da * act'(y), what the apply pass would recompute
                 f1 += dyv;               // 16 terms in fp32, everything above that in fp64
                 f2 = fmaf(dyv, xh, f2);
             }
@@ -844,8 +847,11 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 }  // namespace sp
-template <int XFORM, int SCH, int BCO = 128, bool CAP1 = false, int PF = 2>
+// AT (round 6): storage type of x and dy -- float, or bf16_t (bf16 activation storage, scheme 4; common.h)
+template <int XFORM, int SCH, int BCO = 128, bool CAP1 = false, int PF = 2, typename AT = float>
 __global__ __launch_bounds__(BCO * 4) void conv_wgrad_nine_sp_kernel(WgradArgs a) {
+    static_assert(sizeof(AT) == 4 || SCH == 4, "bf16 activation storage: the one-bf16-plane scheme");
+    constexpr unsigned EB = ActT<AT>::B;
     using S = sp::Scheme<SCH>;
     constexpr int NP = S::NPL;                 // operand planes of the scheme
     static_assert(PF >= 1 && PF <= 3, "prefetch distance in steps");
@@ -878,13 +884,13 @@ __global__ __launch_bounds__(BCO * 4) void conv_wgrad_nine_sp_kernel(WgradArgs a
     if (LPAD && a.M < 0) lds[LUSE + LPAD - 1 - tid] = 0;                      // never true: keeps the padding allocated
 
     const auto rx = make_rsrc(a.x, a.x_bytes);
-    const auto rdy = make_rsrc(a.dy, (unsigned)a.M * (unsigned)a.Cout * 4u);
+    const auto rdy = make_rsrc(a.dy, (unsigned)a.M * (unsigned)a.Cout * EB);
     const auto rsc_d = make_rsrc(XFORM ? a.scale : a.x, XFORM ? a.aff_bytes : 0u);
     const auto rsh_d = make_rsrc(XFORM ? a.shift : a.x, XFORM ? a.aff_bytes : 0u);
 
     // staging slots: dy float4 i = tid -> pixel tid / (BCO/4), co quad tid % (BCO/4); x float4 i = tid + j T < 288 -> pixel i / 16, ci quad i % 16
     const int opx = tid / (BCO / 4), oq = (tid % (BCO / 4)) * 4;
-    const unsigned voo = (co0 + oq < a.Cout) ? (unsigned)((opx * a.Cout + co0 + oq) * 4) : FAVAE_OOB;
+    const unsigned voo = (co0 + oq < a.Cout) ? (unsigned)((opx * a.Cout + co0 + oq) * EB) : FAVAE_OOB;
     const int iq = (tid & 15) * 4;                                   // T % 16 == 0: the same channel quad in every slot
     const bool ci_ok = ci0 + iq < a.Cin;
     const unsigned vsc = ci_ok ? (unsigned)((ci0 + iq) * 4) : FAVAE_OOB;
@@ -916,15 +922,15 @@ __global__ __launch_bounds__(BCO * 4) void conv_wgrad_nine_sp_kernel(WgradArgs a
         st_v[L] = ld_v;
         const unsigned img = (unsigned)(ld_n * H) * (unsigned)a.Wout;
         // dy row v: pixels (n, v, w0 .. w0 + 15)
-        ro[L] = bload(rdy, (live && ld_v >= 0) ? voo : FAVAE_OOB, (img + (unsigned)(max(ld_v, 0) * a.Wout + ld_w0)) * (unsigned)a.Cout * 4u);
+        ro[L] = act_load4<AT>(rdy, (live && ld_v >= 0) ? voo : FAVAE_OOB, (img + (unsigned)(max(ld_v, 0) * a.Wout + ld_w0)) * (unsigned)a.Cout * EB);
         // x row v + 1: pixels (n, v + 1, w0 - 1 .. w0 + 16)
         const int xr = ld_v + 1;
-        const unsigned sx = (img + (unsigned)(min(xr, H - 1) * a.Wout)) * (unsigned)a.Cin * 4u;
+        const unsigned sx = (img + (unsigned)(min(xr, H - 1) * a.Wout)) * (unsigned)a.Cin * EB;
 #pragma unroll
         for (int j = 0; j < NXS; ++j) {
             const int ipx = (tid + j * T) >> 4, iw = ld_w0 - 1 + ipx;
             x_ok[L][j] = live && ipx < 18 && ci_ok && xr < H && (unsigned)iw < (unsigned)a.Win;
-            ri[L][j] = bload(rx, x_ok[L][j] ? (unsigned)((iw * a.Cin + ci0 + iq) * 4) : FAVAE_OOB, sx);
+            ri[L][j] = act_load4<AT>(rx, x_ok[L][j] ? (unsigned)((iw * a.Cin + ci0 + iq) * EB) : FAVAE_OOB, sx);
         }
         if (XFORM) {                          // GroupNorm affine of (image, channel quad): an L1 hit after the first step of a strip
             const unsigned ss = (unsigned)(ld_n * a.aff_stride) * 4u;

@@ -226,9 +226,13 @@ __device__ unsigned long long g_wino_trace[64 * 8 * 48 * 8];
 // PLN (round 5): operand scheme -- 2 = two scaled fp16 planes, three products (h3, fp32-grade); 1 / 4 = ONE fp16 / bf16 plane, one product
 // (the 16-bit mixed-precision modes h1 / b1; b1 in the wide tiling only): a third of the MFMAs, a quarter of the split instructions,
 // half the fragments.
-template <int XFORM, bool GB, bool SE, bool WIDE = false, int PLN = 2>
+// AT (round 6): storage type of the activation tensors (x; y; the residual or, GB, the GroupNorm input read by the epilogue) -- float, or
+// bf16_t (common.h: bf16 activation storage, with the bf16 plane only).  Same thread -> channel mapping, LDS layout and arithmetic.
+template <int XFORM, bool GB, bool SE, bool WIDE = false, int PLN = 2, typename AT = float>
 __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     static_assert(PLN == 2 || PLN == 1 || (PLN == 4 && WIDE), "the bf16 plane: the wide tiling only");
+    static_assert(sizeof(AT) == 4 || PLN == 4, "bf16 activation storage: the one-bf16-plane scheme");
+    constexpr unsigned EB = ActT<AT>::B;
     constexpr int NP = PLN == 2 ? 2 : 1;           // operand planes
     static_assert(!GB || XFORM == 0, "GroupNorm-backward sums: plain data gradient");
     static_assert(!(GB && SE), "one statistics epilogue at a time");
@@ -293,14 +297,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
         const int hy = hrow / HP, hx = hrow - hy * HP;
         const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
         hok[j] = hrow < HPY * HP && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
-        vh[j] = hok[j] ? (unsigned)(((n * a.in_img + y * a.in_row + x) * a.Cin + q4 * 4) * 4) : FAVAE_OOB;
+        vh[j] = hok[j] ? (unsigned)(((n * a.in_img + y * a.in_row + x) * a.Cin + q4 * 4) * EB) : FAVAE_OOB;
         ro[j] = hrow * RAWP + q4 * 16;
     }
     float4 rg[NSLOT];
     auto load_raw_to = [&](float4 (&r)[NSLOT], int kc) {
-        const unsigned sk = (unsigned)(kc * 64);
+        const unsigned sk = (unsigned)(kc * 16) * EB;
 #pragma unroll
-        for (int j = 0; j < NSLOT; ++j) r[j] = bload(rx, vh[j], sk);
+        for (int j = 0; j < NSLOT; ++j) r[j] = act_load4<AT>(rx, vh[j], sk);
     };
     auto load_raw = [&](int kc) { load_raw_to(rg, kc); };
     auto store_raw_from = [&](const float4 (&rg)[NSLOT], int kc) {  // kc = the chunk the registers hold
@@ -565,11 +569,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
     const int fco = WIDE ? (wid & 1) * 64 + lane : lane;                 // finishing role: channel of the tile, tile row
     const int frow = WIDE ? wid >> 1 : wid;
     const int col = n0 + fco;
-    const unsigned ybytes = (unsigned)((size_t)a.N * a.out_img * a.Cout * 4);
+    const unsigned ybytes = (unsigned)((size_t)a.N * a.out_img * a.Cout * EB);
     const auto ry = make_rsrc(a.y, ybytes);
-    const unsigned vcol = (unsigned)(col * 4);
+    const unsigned vcol = (unsigned)col * EB;
     const unsigned pix0 = (unsigned)(n * a.out_img + (ty0 + frow * 2) * a.out_row + tx0);     // first pixel of this wave's tile row
-    const unsigned rowb = (unsigned)(a.out_row * a.Cout * 4), pxb = (unsigned)(a.Cout * 4);
+    const unsigned rowb = (unsigned)(a.out_row * a.Cout) * EB, pxb = (unsigned)a.Cout * EB;
     auto pix_off = [&](int q, int i, int j) { return pix0 * pxb + (unsigned)i * rowb + (unsigned)(q * 2 + j) * pxb; };
     // The residual (forward) or the GroupNorm input x (GB data gradient) of all 32 outputs is loaded HERE, before the exchange and
     // before any store: vmcnt counts stores too, so a load issued behind a store waits for that store's acknowledgement.
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    pre[q][i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rpre, vcol, pix_off(q, i, j), 0));
+                    pre[q][i][j] = act_load1<AT>(rpre, vcol, pix_off(q, i, j));
     } else {
 #pragma unroll
         for (int q = 0; q < 8; ++q) pre[q][0][0] = pre[q][0][1] = pre[q][1][0] = pre[q][1][1] = 0.f;
@@ -659,13 +663,13 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
                 float y = fmaf(v[i][j], un, bv);
                 if constexpr (!GB) {
                     y += pre[q][i][j];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), ry, vcol, pix_off(q, i, j), 0);
+                    act_store1<AT>(ry, vcol, pix_off(q, i, j), y);
                 }
                 if constexpr (GB) {
                     const float xh = (pre[q][i][j] - g_mu) * g_rs;
                     const float dyv = y * favae_act_grad(fmaf(xh, g_ga, g_be), a.gb_act & 0xff);
                     // FAVAE_GB_PREMUL: the tensor written is da * act'(y) -- what the GroupNorm-backward apply pass would recompute
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gb_pm ? dyv : y), ry, vcol, pix_off(q, i, j), 0);
+                    act_store1<AT>(ry, vcol, pix_off(q, i, j), gb_pm ? dyv : y);
                     f1 += dyv;
                     f2 = fmaf(dyv, xh, f2);
                 }

@@ -191,7 +191,53 @@ __global__ __launch_bounds__(256) void u8_norm_kernel(const unsigned char* __res
 
 }  // namespace
 
-extern "C" int favae_abi_version(void) { return 20; }
+extern "C" int favae_abi_version(void) { return 21; }
+
+// ---- bf16 activation storage: conversion passes at the boundaries of the kernels that have no bf16 instantiation (round 6) ---------
+namespace {
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float4* __restrict__ in, uint2* __restrict__ out, long n4, const float* in1,
+                                                        unsigned short* out1, long tail0, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = in[i];
+        out[i] = make_uint2(bf16_pack_rne(v.x, v.y), bf16_pack_rne(v.z, v.w));
+    }
+    if (blockIdx.x == 0)
+        for (long i = tail0 + threadIdx.x; i < n; i += 256) out1[i] = bf16_rne(in1[i]);
+}
+__global__ __launch_bounds__(256) void cast_f32_kernel(const uint2* __restrict__ in, float4* __restrict__ out, long n4,
+                                                       const unsigned short* in1, float* out1, long tail0, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const uint2 u = in[i];
+        out[i] = make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                             __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+    }
+    if (blockIdx.x == 0)
+        for (long i = tail0 + threadIdx.x; i < n; i += 256) out1[i] = bf16_up(in1[i]);
+}
+}  // namespace
+
+extern "C" int favae_cast_bf16(const float* in, void* out, int64_t n, favae_stream_t stream) {
+    FAVAE_REQUIRE(in && out && n > 0 && ((((uintptr_t)in) & 15) | (((uintptr_t)out) & 7)) == 0);
+    const long n4 = n / 4;
+    long blocks = (n4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks);
+    FAVAE_PROF_NOTE(0, 6.0 * n);
+    FAVAE_KLAUNCH(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)in, (uint2*)out, n4, in,
+                  (unsigned short*)out, n4 * 4, (long)n);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
+extern "C" int favae_cast_f32(const void* in, float* out, int64_t n, favae_stream_t stream) {
+    FAVAE_REQUIRE(in && out && n > 0 && ((((uintptr_t)in) & 7) | (((uintptr_t)out) & 15)) == 0);
+    const long n4 = n / 4;
+    long blocks = (n4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks);
+    FAVAE_PROF_NOTE(0, 6.0 * n);
+    FAVAE_KLAUNCH(cast_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint2*)in, (float4*)out, n4,
+                  (const unsigned short*)in, out, n4 * 4, (long)n);
+    FAVAE_CHECK_LAUNCH();
+    return FAVAE_OK;
+}
 
 extern "C" int favae_u8_to_float_nhwc(const unsigned char* in, float* out, int64_t pixels, int C, const float* mean, const float* std,
                                       favae_stream_t stream) {

@@ -18,7 +18,8 @@ __device__ __forceinline__ float act_grad(float y, int act) { return favae_act_g
 
 // part[n][split][c][2] (double): MODE 0: sum x, sum x^2 ; MODE 1: S1, S2 of the backward.
 // VEC: thread = (channel quad, row lane); otherwise thread = (channel, row lane); C > 256*V loops over channel blocks.
-template <int MODE, int V>
+// AT (round 6): storage type of x / da -- float, or bf16_t (V = 4 only): common.h
+template <int MODE, int V, typename AT = float>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ da,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -50,8 +51,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
                     be[e] = beta[c + e];
                 }
             }
-            const float* xp = x + ((size_t)n * HW) * C + c;
-            const float* dp = MODE == 1 ? da + ((size_t)n * HW) * C + c : nullptr;
+            static_assert(sizeof(AT) == 4 || V == 4, "bf16 storage: the vector path only");
+            const size_t e0 = ((size_t)n * HW) * C + c;                 // element index of (image n, row 0, channel c)
+            const float* xp = x + e0;                                   // (fp32 storage; the bf16 path indexes from x / da by element)
+            const float* dp = MODE == 1 ? da + e0 : nullptr;
             auto accum = [&](const float (&xv)[V], const float (&dv)[V]) {
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
@@ -74,8 +77,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
                     float4 t[U], d[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        t[u] = *reinterpret_cast<const float4*>(xp + (r + u * RL) * C);
-                        if (MODE == 1) d[u] = *reinterpret_cast<const float4*>(dp + (r + u * RL) * C);
+                        t[u] = act_get4<AT>(x, e0 + (size_t)(r + u * RL) * C);
+                        if (MODE == 1) d[u] = act_get4<AT>(da, e0 + (size_t)(r + u * RL) * C);
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
@@ -89,10 +92,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
             for (; r < r1; r += RL) {
                 float xv[V], dv[V];
                 if (V == 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(xp + r * C);
+                    const float4 t = act_get4<AT>(x, e0 + (size_t)r * C);
                     xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
                     if (MODE == 1) {
-                        const float4 d = *reinterpret_cast<const float4*>(dp + r * C);
+                        const float4 d = act_get4<AT>(da, e0 + (size_t)r * C);
                         dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
                     }
                 } else {
@@ -318,7 +321,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 // + blockIdx.x) and max |dx| -- dx is the `dy` of the conv in front of this GroupNorm, whose bias gradient and fp16 operand
 // range are exactly these two (favae_colsum read the tensor once more for them).
 // PM: `da` already is dy = da * act'(y) (FAVAE_GB_PREMUL: written by the data-gradient conv's epilogue, which needs it for the sums anyway)
-template <bool SKIP, bool CS, bool PM = false>
+// AT (round 6): storage type of da / x / dx_add / dx (float, or bf16_t: every tensor of the pass at half the bytes; same arithmetic)
+template <bool SKIP, bool CS, bool PM = false, typename AT = float>
 __global__ __launch_bounds__(256, 5) void gn_bwd_apply_rows_kernel(const float* __restrict__ da, const float* __restrict__ x,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -345,12 +349,14 @@ __global__ __launch_bounds__(256, 5) void gn_bwd_apply_rows_kernel(const float* 
     }
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(HW, r0 + rows_per_block);
     // per-image descriptors (an image is < 4 GiB); lane offset = (row lane, channel quad), the row block advances in an SGPR
-    const size_t img = ((size_t)n * HW) * C;
-    const unsigned img_bytes = (unsigned)((size_t)HW * C * 4);
-    const auto rx = make_rsrc(x + img, img_bytes), rda = make_rsrc(da + img, img_bytes), rdx = make_rsrc(dx + img, img_bytes);
-    const auto rsk = make_rsrc(SKIP ? dx_add + img : x, SKIP ? img_bytes : 0u);
-    const unsigned voff = on ? (unsigned)((li * C + c) * 4) : FAVAE_OOB;
-    const unsigned row_b = (unsigned)C * 4u;
+    constexpr unsigned EB = ActT<AT>::B;                              // bytes per stored element
+    const size_t img = ((size_t)n * HW) * C * EB;                     // byte offset of image n
+    const unsigned img_bytes = (unsigned)((size_t)HW * C * EB);
+    auto at = [&](const float* p) { return reinterpret_cast<const char*>(p) + img; };
+    const auto rx = make_rsrc(at(x), img_bytes), rda = make_rsrc(at(da), img_bytes), rdx = make_rsrc(at(dx), img_bytes);
+    const auto rsk = make_rsrc(SKIP ? at(dx_add) : (const char*)x, SKIP ? img_bytes : 0u);
+    const unsigned voff = on ? (unsigned)((li * C + c) * EB) : FAVAE_OOB;
+    const unsigned row_b = (unsigned)C * EB;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
     float mx = 0.f;
     auto one = [&](const float4 t, const float4 d, const float4 q) -> float4 {
@@ -382,14 +388,14 @@ __global__ __launch_bounds__(256, 5) void gn_bwd_apply_rows_kernel(const float* 
         for (int u = 0; u < U; ++u) {
             vo[u] = (rb + u * RL + li < r1) ? voff : FAVAE_OOB;
             const unsigned so = (unsigned)(rb + u * RL) * row_b;
-            t[u] = bload(rx, vo[u], so);
-            d[u] = bload(rda, vo[u], so);
-            q[u] = SKIP ? bload(rsk, vo[u], so) : z4;
+            t[u] = act_load4<AT>(rx, vo[u], so);
+            d[u] = act_load4<AT>(rda, vo[u], so);
+            q[u] = SKIP ? act_load4<AT>(rsk, vo[u], so) : z4;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float4 o = one(t[u], d[u], q[u]);
-            bstore(rdx, vo[u], (unsigned)(rb + u * RL) * row_b, o);
+            act_store4<AT>(rdx, vo[u], (unsigned)(rb + u * RL) * row_b, o);
             if (CS && vo[u] != FAVAE_OOB) tally(o);
         }
     }
@@ -448,12 +454,17 @@ size_t acc_bytes(int N, int C) { return (size_t)N * C * 2 * sizeof(double); }
 
 template <int MODE>
 void launch_partial(const float* x, const float* da, const float* gamma, const float* beta, const float* mean,
-                    const float* rstd, double* part, int N, long HW, int C, int G, int act, hipStream_t s) {
+                    const float* rstd, double* part, int N, long HW, int C, int G, int act, hipStream_t s, bool bf16io = false) {
     const int S = gn_splits(N, HW);
     const long rpb = (HW + S - 1) / S;
-    FAVAE_PROF_NOTE(0, (MODE == 0 ? 4.0 : 8.0) * N * HW * C);             // one read of x (+ one of da)
+    FAVAE_PROF_NOTE(0, (MODE == 0 ? 4.0 : 8.0) * (bf16io ? 0.5 : 1.0) * N * HW * C);   // one read of x (+ one of da)
     const bool vec = (C % 4 == 0) && ((((uintptr_t)x) & 15) == 0) && (MODE == 0 || (((uintptr_t)da) & 15) == 0);
-    if (vec) {
+    if (bf16io) {                         // bf16 storage: the caller guarantees C % 4 == 0 and 8-byte alignment
+        const int QT = C / 4, Q = QT < 256 ? QT : 256, RL = 256 / Q;
+        const size_t shm = (size_t)RL * Q * 8 * sizeof(double);
+        FAVAE_KLAUNCH((gn_partial_kernel<MODE, 4, bf16_t>), dim3(S, N), dim3(256), shm, s, x, da, gamma, beta, mean, rstd, part, HW, C,
+                           G, act, rpb);
+    } else if (vec) {
         const int QT = C / 4, Q = QT < 256 ? QT : 256, RL = 256 / Q;
         const size_t shm = (size_t)RL * Q * 8 * sizeof(double);
         FAVAE_KLAUNCH((gn_partial_kernel<MODE, 4>), dim3(S, N), dim3(256), shm, s, x, da, gamma, beta, mean, rstd, part, HW, C,
@@ -473,9 +484,24 @@ extern "C" size_t favae_gn_workspace(int N, int64_t HW, int C) {
     return part_bytes(N, HW, C) + acc_bytes(N, C) + 2 * (size_t)N * C * sizeof(float) + 512;
 }
 
+static int gn_stats_impl(const float* x, const float* gamma, const float* beta, int N, int64_t HW, int C, int G, float eps, float* mean,
+                         float* rstd, float* scale, float* shift, float* absmax_out, void* ws, size_t ws_bytes, favae_stream_t stream,
+                         bool bf16io);
 extern "C" int favae_gn_stats(const float* x, const float* gamma, const float* beta, int N, int64_t HW, int C, int G,
                               float eps, float* mean, float* rstd, float* scale, float* shift, float* absmax_out, void* ws,
                               size_t ws_bytes, favae_stream_t stream) {
+    return gn_stats_impl(x, gamma, beta, N, HW, C, G, eps, mean, rstd, scale, shift, absmax_out, ws, ws_bytes, stream, false);
+}
+// the same statistics of a tensor STORED as bf16 (round 6, bf16 activation storage): x points at bf16 elements; C % 4 == 0
+extern "C" int favae_gn_stats_bf16(const void* x, const float* gamma, const float* beta, int N, int64_t HW, int C, int G,
+                                   float eps, float* mean, float* rstd, float* scale, float* shift, float* absmax_out, void* ws,
+                                   size_t ws_bytes, favae_stream_t stream) {
+    if (C % 4 != 0 || (((uintptr_t)x) & 7) != 0) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+    return gn_stats_impl((const float*)x, gamma, beta, N, HW, C, G, eps, mean, rstd, scale, shift, absmax_out, ws, ws_bytes, stream, true);
+}
+static int gn_stats_impl(const float* x, const float* gamma, const float* beta, int N, int64_t HW, int C, int G, float eps, float* mean,
+                         float* rstd, float* scale, float* shift, float* absmax_out, void* ws, size_t ws_bytes, favae_stream_t stream,
+                         bool bf16io) {
     FAVAE_REQUIRE(x && mean && rstd && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     if (ws_bytes < favae_gn_workspace(N, HW, C)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
@@ -483,7 +509,7 @@ extern "C" int favae_gn_stats(const float* x, const float* gamma, const float* b
     double* part = (double*)ws;
     double* acc = (double*)((char*)ws + part_bytes(N, HW, C));
     FAVAE_REQUIRE(!absmax_out || scale);
-    launch_partial<0>(x, nullptr, gamma, beta, nullptr, nullptr, part, N, (long)HW, C, G, 0, s);
+    launch_partial<0>(x, nullptr, gamma, beta, nullptr, nullptr, part, N, (long)HW, C, G, 0, s, bf16io);
     FAVAE_CHECK_LAUNCH();
     FAVAE_KLAUNCH(gn_finalize_kernel, dim3(N, gn_slabs(G)), dim3(256), 0, s, (const double*)part, gamma, beta, mean, rstd, scale, shift,
                        acc, (long)HW, C, G, gn_splits(N, HW), eps, (unsigned*)absmax_out);
@@ -569,6 +595,12 @@ static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, 
     FAVAE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr));
     const bool pm = (act & FAVAE_GB_PREMUL) != 0;     // `da` is dy = da * act'(y): only the conv epilogue that made the sums can have written it
     FAVAE_REQUIRE(!pm || tile_partials > 0);
+    // FAVAE_ACT_BF16IO (round 6): da, x, dx_add and dx are bf16 tensors (bf16 activation storage); the row-organised pass only
+    const bool bf = (act & FAVAE_ACT_BF16IO) != 0;
+    act &= ~FAVAE_ACT_BF16IO;
+    if (bf && (pm || C % 4 != 0 || ((((uintptr_t)da) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)dx_add)) & 7) != 0 ||
+               !apply_rows_blocks(N, HW, C)))
+        return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (ws_bytes < (tile_partials ? favae_gn_bwd_tiles_workspace(N, tile_partials, C) : favae_gn_workspace(N, HW, C)))
         return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     hipStream_t s = (hipStream_t)stream;
@@ -577,7 +609,7 @@ static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, 
     float* k1 = (float*)((char*)acc + acc_bytes(N, C));
     float* k2 = k1 + (size_t)N * C;
     if (!tile_partials) {
-        launch_partial<1>(x, da, gamma, beta, mean, rstd, part, N, (long)HW, C, G, act, s);
+        launch_partial<1>(x, da, gamma, beta, mean, rstd, part, N, (long)HW, C, G, act, s, bf);
         FAVAE_CHECK_LAUNCH();
     }
     FAVAE_KLAUNCH(gn_bwd_finalize_kernel, dim3(N, gn_slabs(G)), dim3(256), 0, s, (const double*)part, gamma, k1, k2, acc, (long)HW, C, G,
@@ -588,8 +620,8 @@ static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, 
         FAVAE_CHECK_LAUNCH();
     }
     const size_t total = (size_t)N * HW * C;
-    FAVAE_PROF_NOTE(0, (dx_add ? 16.0 : 12.0) * total);                   // reads da, x (+ dx_add), writes dx
-    const bool vec = (C % 4 == 0) && (((((uintptr_t)da) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)dx_add)) & 15) == 0);
+    FAVAE_PROF_NOTE(0, (dx_add ? 16.0 : 12.0) * (bf ? 0.5 : 1.0) * total);    // reads da, x (+ dx_add), writes dx
+    const bool vec = bf || ((C % 4 == 0) && (((((uintptr_t)da) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)dx_add)) & 15) == 0));
     const long S = apply_rows_blocks(N, HW, C);
     if (cs_part && !(vec && S)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (vec && S) {
@@ -597,7 +629,9 @@ static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, 
         const dim3 grid((unsigned)S, N);
 #define FAVAE_LAUNCH_APPLY(SK, CS)                                                                                             \
     do {                                                                                                                       \
-        if (pm) FAVAE_KLAUNCH((gn_bwd_apply_rows_kernel<SK, CS, true>), grid, dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2, \
+        if (bf) FAVAE_KLAUNCH((gn_bwd_apply_rows_kernel<SK, CS, false, bf16_t>), grid, dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, \
+                              k2, dx_add, dx, (long)HW, C, G, act, rpb, cs_part, (unsigned*)cs_amax);                          \
+        else if (pm) FAVAE_KLAUNCH((gn_bwd_apply_rows_kernel<SK, CS, true>), grid, dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2, \
                               dx_add, dx, (long)HW, C, G, act & 0xff, rpb, cs_part, (unsigned*)cs_amax);                       \
         else FAVAE_KLAUNCH((gn_bwd_apply_rows_kernel<SK, CS>), grid, dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2, dx_add, \
                            dx, (long)HW, C, G, act, rpb, cs_part, (unsigned*)cs_amax);                                         \

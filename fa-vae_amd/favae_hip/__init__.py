@@ -33,7 +33,7 @@ HW_QUEUES_AT_INIT = None if torch.cuda.is_initialized() else _parse_queues(os.en
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FAVAE_HIP_LIB") or os.path.join(_HERE, "libfavae_hip.so")     # FAVAE_HIP_LIB: same-box A/B of two builds
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02, ACT_RELU = 0, 1, 2, 3
@@ -81,6 +81,10 @@ SIGNATURES = {
     "favae_upsample2x_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     "favae_gn_workspace": (c_size_t, [c_int, c_int64, c_int]),
     "favae_gn_stats": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _S]),
+    "favae_gn_stats_bf16": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _S]),
+    "favae_conv_bf16io_ok": (c_int, [POINTER(ConvDesc), c_int, c_int]),
+    "favae_cast_bf16": (c_int, [_P, _P, c_int64, _S]),
+    "favae_cast_f32": (c_int, [_P, _P, c_int64, _S]),
     "favae_gn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_size_t, _S]),
     "favae_bn_update_running": (c_int, [_P, _P, c_int, c_int64, c_float, c_float, _P, _P, _S]),
     "favae_bgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int64, c_int64, _P, c_int64, c_int64, _P,

@@ -21,15 +21,65 @@ CL = torch.channels_last
 # ---------------------------------------------------------------------------------------------------------------
 # layout helpers
 # ---------------------------------------------------------------------------------------------------------------
-def _require_gpu(t):
+def _require_gpu(t, bf16_ok=False):
     if not t.is_cuda:
         raise RuntimeError("favae_hip ops run on MI355X only (tensor is on %s); there is no CPU fallback" % t.device)
-    if t.dtype != torch.float32:
+    if t.dtype != torch.float32 and not (bf16_ok and t.dtype == torch.bfloat16):
         raise RuntimeError("favae_hip ops compute in fp32 (got %s)" % t.dtype)
 
 
-def new_cl(N, C, H, W, device):
-    return torch.empty((N, C, H, W), dtype=torch.float32, device=device, memory_format=CL)
+def new_cl(N, C, H, W, device, dtype=torch.float32):
+    return torch.empty((N, C, H, W), dtype=dtype, device=device, memory_format=CL)
+
+
+# ---- bf16 activation STORAGE (round 6; BASELINE configs[4] "bf16", favae_scripts/train_favae.py:239-240) ---------------------------
+# In the conv mode b1 (one bf16 plane per operand) the dense 3x3 convs of the ResnetBlock chain -- forward, data gradient with the
+# GroupNorm-backward epilogue, weight gradient -- and the GroupNorm-backward apply pass between them read and write their activation
+# tensors as torch.bfloat16 (include/favae_hip.h FAVAE_PLANES_BF16IO / FAVAE_ACT_BF16IO): the big layers of that mode sit at the HBM
+# roofline in fp32 I/O.  Every other op keeps fp32 I/O: to_cl() widens a bf16 input with one conversion pass, and the autograd engine
+# converts the fp32 gradient such an op returns back to the dtype of the tensor it belongs to.  Statistics, losses, the codebook lookup,
+# FFL and Adam stay fp32 (reference: models/l2_quantize.py:391,395 keep the quantizer out of autocast).
+# FAVAE_BF16_STORAGE=0 / set_bf16_storage(False): activations stay fp32 in b1 as in rounds 1-5 (A/B arm).
+_BF16_STORAGE = os.environ.get("FAVAE_BF16_STORAGE", "1") != "0"
+BF16IO_PLANES = 0x400                  # include/favae_hip.h FAVAE_PLANES_BF16IO
+BF16IO_ACT = 0x200                     # include/favae_hip.h FAVAE_ACT_BF16IO
+
+
+def set_bf16_storage(on):
+    global _BF16_STORAGE
+    prev, _BF16_STORAGE = _BF16_STORAGE, bool(on)
+    return prev
+
+
+def bf16_storage():
+    return _BF16_STORAGE and query("favae_get_conv_mode") == 4
+
+
+def cast_bf16(t):
+    """fp32 -> bf16 copy of a dense tensor (same shape and strides), round to nearest even; by-products riding on t are carried over"""
+    if t.dtype == torch.bfloat16:
+        return t
+    out = torch.empty_like(t, dtype=torch.bfloat16)
+    call("favae_cast_bf16", ptr(t), ptr(out), t.numel())
+    for attr in ("_favae_gnstats", "_favae_amax", "_favae_dycs"):
+        st = getattr(t, attr, None)
+        if st is not None:
+            if attr == "_favae_gnstats":
+                st = (st[0], st[1], out._version)
+            elif attr == "_favae_amax":
+                st = (st[0], out._version, st[2])
+            else:
+                st = (st[0], st[1], st[2], out._version, st[4])
+            setattr(out, attr, st)
+    return out
+
+
+def cast_f32(t):
+    if t.dtype == torch.float32:
+        return t
+    out = torch.empty_like(t, dtype=torch.float32)
+    call("favae_cast_f32", ptr(t), ptr(out), t.numel())
+    return out
 
 
 def _is_cl(t):
@@ -39,8 +89,16 @@ def _is_cl(t):
     return all(sz == 1 or st == w for sz, st, w in zip(t.shape, t.stride(), want))
 
 
-def to_cl(t):
-    """Return `t` (N,C,H,W) with NHWC memory; NCHW-contiguous inputs go through the HIP transpose kernel."""
+def to_cl(t, keep_bf16=False):
+    """Return `t` (N,C,H,W) with NHWC memory; NCHW-contiguous inputs go through the HIP transpose kernel.  A bf16 tensor (bf16
+    activation storage) is widened to fp32 unless the caller has a bf16 kernel for it (keep_bf16)."""
+    if t.dtype == torch.bfloat16 and t.is_cuda:
+        if _is_cl(t):
+            return t if keep_bf16 else cast_f32(t)
+        # a bf16 tensor in another layout: only a gradient the autograd engine converted from a caller's NCHW fp32 tensor (tests, module
+        # boundaries) -- widen it with torch, lay it out below, narrow it again if the caller keeps bf16
+        t32 = to_cl(t.float())
+        return cast_bf16(t32) if keep_bf16 else t32
     _require_gpu(t)
     if _is_cl(t):
         return t
@@ -155,8 +213,8 @@ def gn_stats(x, gamma, beta, groups, eps=1e-5, with_bound=False):
         call("favae_gn_stats_tiles", ptr(pre[0]), pre[1], ptr(gamma), ptr(beta), N, H * W, C, groups, eps, ptr(mean), ptr(rstd),
              ptr(scale), ptr(shift), ptr(bound), ptr(ws), ws.numel())
     else:
-        call("favae_gn_stats", ptr(x), ptr(gamma), ptr(beta), N, H * W, C, groups, eps, ptr(mean), ptr(rstd), ptr(scale),
-             ptr(shift), ptr(bound), ptr(ws), ws.numel())
+        call("favae_gn_stats_bf16" if x.dtype == torch.bfloat16 else "favae_gn_stats", ptr(x), ptr(gamma), ptr(beta), N, H * W, C, groups,
+             eps, ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(bound), ptr(ws), ws.numel())
     if with_bound:
         return mean, rstd, scale, shift, bound
     return mean, rstd, scale, shift
@@ -790,6 +848,8 @@ def _bias_grad_and_range(dy, p_b, need_b, want_range, M, Cout, dev):
         return db, (pre[2] if want_range else None)
     if want_range:
         dyb = _max_target(dev)
+    if (need_b or want_range) and dy.dtype == torch.bfloat16:       # no by-product: one conversion pass in front of the column sums
+        dy = cast_f32(dy)
     if need_b:
         ws = workspace(query("favae_colsum_workspace", M, Cout), dev)
         tgt = _direct_grad(p_b)
@@ -820,7 +880,7 @@ def _wino_records(w, co, ci, flip, w_amax):
 
 
 def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=None, planes_out=None, gnbwd=None, stats_out=None,
-                 y_amax=None, wino_rec=None):
+                 y_amax=None, wino_rec=None, bf16io=False):
     """conv forward / data gradient.  When the library runs this shape on the split-precision matrix path the weights are
     pre-split once per call (instead of once per tile in the K loop); the fp16 scheme (2 planes) also needs the operand
     range: `x_bound` = device scalar >= max|T(x)| (computed here for an un-transformed operand when not supplied).
@@ -873,6 +933,10 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
                 call("favae_split_weights", ptr(w_ohwi), ptr(wsp), n, planes)
             if planes in (1, 2):
                 w_amax = wsp[:4].view(torch.float32)          # header of the record buffer (keeps the buffer alive while saved)
+    if bf16io:                               # bf16 activation storage: x, resid, y (and the GroupNorm input of gnbwd) are bf16 tensors
+        if (planes & 0xFF) != 4:
+            raise RuntimeError("bf16 activation storage needs the one-bf16-plane conv mode (b1)")
+        planes |= BF16IO_PLANES
     if planes:
         if (planes & 0xFF) in (1, 2) and x_bound is None:
             if scale is not None:
@@ -908,6 +972,24 @@ def _flipped(flip_of):
     return wt
 
 
+def _bf16_conv_ok(N, Hin, Win, Cin, Ho, Wo, Cout, cfg, has_aff, has_gn, need_grad):
+    """bf16 activation storage for this conv: the mode is on and every kernel the conv will run -- forward, data gradient (with the
+    GroupNorm-backward epilogue when a GroupNorm sits in front), weight gradient, apply pass -- has the bf16 instantiation"""
+    if not bf16_storage() or cfg.norm in ("batch", "act") or cfg.upsample or cfg.stride != 1 or cfg.kh != 3 or cfg.kw != 3:
+        return False
+    act = cfg.act if has_aff else ACT_NONE
+    d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad, GATHER_PLAIN, act, 1)
+    if not query("favae_conv_bf16io_ok", byref(d), 1 if has_aff else 0, 0):
+        return False
+    if need_grad:
+        d2 = make_conv_desc(N, Ho, Wo, Cout, Hin, Win, Cin, cfg.kh, cfg.kw, 1, cfg.kh - 1 - cfg.pad, GATHER_PLAIN, ACT_NONE, 1)
+        if not query("favae_conv_bf16io_ok", byref(d2), 0, 1 if has_gn else 0) or not query("favae_conv_bf16io_ok", byref(d), 1 if has_aff else 0, 2):
+            return False
+        if has_gn and not query("favae_gn_bwd_colsum_blocks", N, Hin * Win, Cin):
+            return False
+    return True
+
+
 class FusedConvFn(torch.autograd.Function):
     """y = conv(act(GN(x)), w) + b + resid   -- GN/act optional (gn_w is None -> plain conv).
 
@@ -920,12 +1002,17 @@ class FusedConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gn_w, gn_b, resid, cfg, pass_input=False, stats=None):
-        x = to_cl(x)
         N, Cin, Hin, Win = x.shape
         w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
         wk = weight_ohwi(w4)
         Cout = w4.shape[0]
         Ho, Wo = cfg.out_hw(Hin, Win)
+        # bf16 activation storage (b1 mode): x, resid and y of this conv are bf16 tensors when all of its kernels can take them
+        st = _bf16_conv_ok(N, Hin, Win, Cin, Ho, Wo, Cout, cfg, cfg.norm in ("batch", "act") or gn_w is not None, gn_w is not None,
+                           any(ctx.needs_input_grad))
+        x = to_cl(x, keep_bf16=st)
+        if st:
+            x = cast_bf16(x)
         dev = x.device
         mean = rstd = scale = shift = xb = None
         per_image = 1
@@ -940,8 +1027,10 @@ class FusedConvFn(torch.autograd.Function):
         elif gn_w is not None:
             mean, rstd, scale, shift, xb = gn_stats(x, gn_w, gn_b, cfg.groups, cfg.eps, with_bound=True)
         if resid is not None:
-            resid = to_cl(resid)
-        y = new_cl(N, Cout, Ho, Wo, dev)
+            resid = to_cl(resid, keep_bf16=st)
+            if st:
+                resid = cast_bf16(resid)
+        y = new_cl(N, Cout, Ho, Wo, dev, torch.bfloat16 if st else torch.float32)
         d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad,
                            GATHER_UPSAMPLE2 if cfg.upsample else GATHER_PLAIN, cfg.act if scale is not None else ACT_NONE,
                            per_image)
@@ -963,7 +1052,7 @@ class FusedConvFn(torch.autograd.Function):
             if st_tiles:
                 st_part = torch.empty((N * st_tiles * Cout * 2,), dtype=torch.float64, device=dev)
         y_amax = _max_target(dev) if st_part is not None else None
-        w_amax = _conv_launch(d, x, wk, b, resid, scale, shift, y, xb, planes_out=xs, stats_out=st_part, y_amax=y_amax)
+        w_amax = _conv_launch(d, x, wk, b, resid, scale, shift, y, xb, planes_out=xs, stats_out=st_part, y_amax=y_amax, bf16io=st)
         if st_part is not None:
             y._favae_gnstats = (st_part, st_tiles, y._version)
             y._favae_amax = (y_amax, y._version, _ARENA["epoch"])
@@ -982,6 +1071,7 @@ class FusedConvFn(torch.autograd.Function):
                     rec = _wino_records(wk, Cout, Cin, key, w_amax)
                 ctx.wflip = (rec, f43)
         ctx.cfg = cfg
+        ctx.st = st
         ctx.arena_epoch = _ARENA["epoch"]
         ctx.has_b = b is not None
         ctx.has_gn = gn_w is not None
@@ -999,10 +1089,16 @@ class FusedConvFn(torch.autograd.Function):
     def backward(ctx, dy, dskip=None):
         x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb, w_amax, xs = ctx.saved_tensors
         _check_arena_epoch(ctx, xb)
+        st = ctx.st                               # bf16 activation storage: dy, da, dskip, dx are bf16 tensors like x
+        adt = torch.bfloat16 if st else torch.float32
         if dskip is not None:
-            dskip = to_cl(dskip)
+            dskip = to_cl(dskip, keep_bf16=st)
+            if st:
+                dskip = cast_bf16(dskip)
         cfg = ctx.cfg
-        dy = to_cl(dy)
+        dy = to_cl(dy, keep_bf16=st)
+        if st:
+            dy = cast_bf16(dy)                    # (the engine hands dy over in y's dtype: a no-op)
         N, Cin, Hin, Win = x.shape
         _, Cout, Ho, Wo = dy.shape
         dev = x.device
@@ -1035,7 +1131,9 @@ class FusedConvFn(torch.autograd.Function):
                 dw = dwk.permute(0, 3, 1, 2)                  # (Cout,Cin,KH,KW) view with channels-last strides
                 if ctx.w_dim == 2:
                     dw = dwk.view(Cout, Cin)
-            wd, wws, wtgt = d, ws, (tgt if tgt is not None else dwk)
+            wd = d if not st else make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad, gather,
+                                                 act | BF16IO_ACT, ctx.per_image)          # x and dy are bf16 (include/favae_hip.h)
+            wws, wtgt = ws, (tgt if tgt is not None else dwk)
             acc = 1 if tgt is not None else 0
 
             defer = _DEFER_REDUCE and tgt is not None and _SIDE["on"] and not use_planes
@@ -1096,7 +1194,7 @@ class FusedConvFn(torch.autograd.Function):
             dys = None
             gn_tiles, gn_ws, act_gn = 0, None, act
             if not phased:
-                da = new_cl(N, Cin, Hv, Wv, dev)
+                da = new_cl(N, Cin, Hv, Wv, dev, adt)
                 d2 = make_conv_desc(N, Ho, Wo, Cout, Hv, Wv, Cin, cfg.kh, cfg.kw, 1, pad2, g2, ACT_NONE, 1)
                 if use_planes and query("favae_conv_planes_ok", byref(d2), 0):
                     dys = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=dev)
@@ -1111,13 +1209,13 @@ class FusedConvFn(torch.autograd.Function):
                         gn_ws = workspace(query("favae_gn_bwd_tiles_workspace", N, gn_tiles, Cin), dev)
                         # FAVAE_GB_PREMUL: the epilogue writes dy = da * act'(y) (it has it in registers for the sums) and the apply
                         # pass below takes it as such -- no second transcendental per element in the HBM-bound pass
-                        act_gn = act | GB_PREMUL if _GB_PREMUL else act
+                        act_gn = act | GB_PREMUL if (_GB_PREMUL and not st) else act
                         gnb = (x, mean, rstd, gn_w, gn_b, cfg.groups, act_gn, gn_ws)
                 if _SERIALIZE_MFMA and gn_tiles and _SIDE["used"]:
                     # experiment: the dense data gradient starts only after the weight gradient of the layer behind it has retired
                     torch.cuda.current_stream().wait_stream(_SIDE["stream"])
                 _conv_launch(d2, dy, None, None, None, None, None, da, dyb, flip_of=(wk, Cout, cfg.kh, cfg.kw, Cin, w_amax),
-                             planes_out=dys, gnbwd=gnb, wino_rec=ctx.wflip if dys is None else None)
+                             planes_out=dys, gnbwd=gnb, wino_rec=ctx.wflip if dys is None else None, bf16io=st)
             if run_wgrad is not None:
                 run_wgrad(dys)
                 run_wgrad = None
@@ -1126,7 +1224,7 @@ class FusedConvFn(torch.autograd.Function):
                 call("favae_upsample2x_bwd", ptr(da), ptr(dlow), N, Hin, Win, Cin)
                 da = dlow
             if has_gn:
-                dx = new_cl(N, Cin, Hin, Win, dev)
+                dx = new_cl(N, Cin, Hin, Win, dev, adt)
                 tg, tb = _direct_grad(p_gw), _direct_grad(p_gb)
                 direct = tg is not None and tb is not None
                 if not direct:
@@ -1140,6 +1238,8 @@ class FusedConvFn(torch.autograd.Function):
                 if not gn_tiles:
                     gn_ws = workspace(query("favae_gn_workspace", gN, gHW, Cin), dev)
                 act_ap = act_gn if gn_tiles else act          # flagged only when the epilogue really wrote the pre-multiplied tensor
+                if st:
+                    act_ap |= BF16IO_ACT                      # da, x, dskip, dx are bf16 tensors (include/favae_hip.h FAVAE_ACT_BF16IO)
                 if cs_blocks:                                 # the apply pass also leaves colsum / max|dx| for the conv in front
                     cs_part = torch.empty((cs_blocks * Cin,), dtype=torch.float32, device=dev)
                     cs_amax = torch.empty((1,), dtype=torch.float32, device=dev)
@@ -1153,8 +1253,8 @@ class FusedConvFn(torch.autograd.Function):
                          gn_tiles, ptr(gn_ws), gn_ws.numel())
                 else:
                     call("favae_gn_act_bwd", ptr(da), ptr(x), ptr(gn_w), ptr(gn_b), ptr(mean), ptr(rstd), gN, gHW, Cin,
-                         gG, act, ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb), 1 if direct else 0,
-                         ptr(gn_ws), gn_ws.numel())
+                         gG, act | (BF16IO_ACT if st else 0), ptr(dskip), ptr(dx), ptr(tg if direct else dgw), ptr(tb if direct else dgb),
+                         1 if direct else 0, ptr(gn_ws), gn_ws.numel())
                 dskip = None                                  # consumed by the kernel (dx = GN-backward + dskip)
             elif ctx.has_xform:                               # activation without normalisation
                 dx = new_cl(N, Cin, Hin, Win, dev)

@@ -146,6 +146,17 @@ int favae_get_wino(void);              /* the current setting, no side effect */
  * favae_conv_fwd_split / _stats / favae_conv_dgrad_gnbwd.  The tile grid of the partial sums stays the F(2x2) kernel's (16 x 16 pixels).
  * FAVAE_WINO4=0 in the environment (favae_set_wino4(0)) makes favae_conv_wino4_ok return 0 for every shape. */
 #define FAVAE_PLANES_WINO4 0x200
+/* bf16 activation STORAGE (ABI 21): with this flag on `planes` (scheme 4 = b1 only) favae_conv_fwd_split / _stats / favae_conv_dgrad_gnbwd /
+ * favae_conv_wgrad_planes take x, resid (and the GroupNorm input of the data-gradient epilogue, and dy of the weight gradient) and write
+ * y as bf16 tensors: the same element counts at two bytes each, rounded to nearest even on store, widened exactly on load; products,
+ * accumulation, statistics and partial sums stay fp32 / fp64.  favae_conv_bf16io_ok(d, has_affine, kind) says whether the kernel that
+ * would run `d` has the bf16 instantiation (kind 0 forward, 1 data gradient with the GroupNorm-backward epilogue, 2 weight gradient);
+ * otherwise the caller converts with favae_cast_bf16 / favae_cast_f32 and uses the fp32 call. */
+#define FAVAE_PLANES_BF16IO 0x400
+int favae_conv_bf16io_ok(const favae_conv_desc* d, int has_affine, int kind);
+/* element-wise conversion passes between the two storage types (n elements, 8-byte aligned) */
+int favae_cast_bf16(const float* in, void* out, int64_t n, favae_stream_t stream);
+int favae_cast_f32(const void* in, float* out, int64_t n, favae_stream_t stream);
 int favae_conv_wino4_ok(const favae_conv_desc* d, int has_affine);
 int favae_set_wino4(int on);           /* returns the previous setting */
 size_t favae_wino4_weights_bytes(int Cout, int Cin);
@@ -246,6 +257,10 @@ size_t favae_gn_workspace(int N, int64_t HW, int C);
 int favae_gn_stats(const float* x, const float* gamma, const float* beta, int N, int64_t HW, int C, int G, float eps,
                    float* mean, float* rstd, float* scale, float* shift, float* absmax_out, void* ws, size_t ws_bytes,
                    favae_stream_t stream);
+/* the same statistics of a tensor STORED as bf16 (x: bf16 elements, C % 4 == 0, 8-byte aligned): bf16 activation storage, ABI 21 */
+int favae_gn_stats_bf16(const void* x, const float* gamma, const float* beta, int N, int64_t HW, int C, int G, float eps,
+                        float* mean, float* rstd, float* scale, float* shift, float* absmax_out, void* ws, size_t ws_bytes,
+                        favae_stream_t stream);
 
 /* Given da = dL/d act(GN(x)): dx, dgamma[C], dbeta[C].  act as in favae_conv_desc.  If `dx_add` != NULL it is
  * added to dx (fused skip-connection gradient).  dx may alias da. */
@@ -479,6 +494,11 @@ int favae_gn_stats_tiles(const void* part, int tiles, const float* gamma, const 
  * Reference: autograd of GroupNorm + SiLU in ResnetBlock / NonResnetBlock / final (models/codec.py:38-46,65-73,170-175).
  * ---------------------------------------------------------------------------------------------------------- */
 #define FAVAE_GB_PREMUL 0x100
+/* bf16 activation STORAGE (ABI 21, round 6; BASELINE configs[4] "bf16": accelerate's autocast keeps conv outputs in bf16,
+ * favae_scripts/train_favae.py:239-240).  With the flag on `act`, favae_gn_act_bwd / _tiles / _colsum take da, x, dx_add and write dx as
+ * bf16 tensors (same element counts; round to nearest even on store, exact widening on load); statistics, sums and the arithmetic stay
+ * fp32 / fp64.  favae_gn_stats_bf16 = favae_gn_stats of a tensor stored as bf16.  Conv entry points: FAVAE_PLANES_BF16IO on `planes`. */
+#define FAVAE_ACT_BF16IO 0x200
 int favae_conv_gnbwd_tiles(const favae_conv_desc* d, int planes);
 size_t favae_gn_bwd_tiles_workspace(int N, int tiles, int C);
 int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy, const void* wsplit, int planes, const float* dy_absmax,

@@ -41,6 +41,18 @@ def test_winograd_kernel_is_priced_on_executed_flops():
     assert abs(e["frac_of_pipe_peak"] - 0.150) < 1e-3 and abs(e["frac_fp32_equivalent"] - 0.337) < 1e-3
 
 
+def test_one_plane_winograd_kernel_is_priced_with_one_product():
+    """round 6: the kernel names carry the operand scheme and the activation storage type -- conv3x3_wino_sp_kernel<XFORM, GB, SE, WIDE,
+    PLN, storage>: PLN 4 (one bf16 plane, b1) executes algorithmic x 1 product x 4/9, PLN 2 (h3) x 3 x 4/9"""
+    for name, prod in (("conv3x3_wino_sp_kernel<0, true, false, true, 4, unsigned short>", 1), ("conv3x3_wino_sp_kernel<0, true, false, true, 2, float>", 3),
+                       ("conv3x3_wino_sp_kernel<2, false, true, true, 1, float>", 1)):
+        assert bench.kernel_planes(name) == {1: 4, 3: 2}[prod] or (prod == 1 and bench.kernel_planes(name) in (1, 4))
+        e = bench.roofline_entry(name, _rec(67, 400.0, 177.41, 0.534), 4 * 135000.0, {}, None)
+        assert abs(e["executed_gflop_per_launch"] - 177.41 * prod * 4 / 9) < 0.01, (name, e["executed_gflop_per_launch"])
+    assert bench.kernel_planes("conv3x3_halo_sp_kernel<2, 4, 3, false, false, true, unsigned short>") == 4
+    assert bench.kernel_planes("conv_wgrad_nine_sp_kernel<2, 4, 128, false, 1, unsigned short>") == 4
+
+
 def test_f44_winograd_kernel_is_priced_on_executed_flops():
     """round 5: the F(4x4, 3x3) kernel executes 36 of the direct conv's 144 products per 16 outputs, x 3 split products: executed =
     algorithmic x 3 / 4, against the same 2.5 PFLOP/s pipe (it once showed up at frac 1.64 of the fp32-MFMA peak: no planes matched)."""

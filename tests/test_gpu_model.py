@@ -687,7 +687,15 @@ def test_cfg5_256_b1_index_flips_and_loss_deltas(golden_dir):
             K.set_conv_mode(prev)
 
     ref_ind = g[tag + ".indices"]
-    a, b = encode("h3"), encode("b1")
+    # b1 = bf16 conv operands AND (round 6) bf16 activation storage on the ResnetBlock chain; b1f = the same operands with fp32 storage
+    # (rounds 1-5, FAVAE_BF16_STORAGE=0)
+    prev_st = K.set_bf16_storage(False)
+    try:
+        a, b = encode("h3"), encode("b1")
+        K.set_bf16_storage(True)
+        bs = encode("b1")
+    finally:
+        K.set_bf16_storage(prev_st)
     n = ref_ind.size
     flips_h3, flips_b1 = int((a["ind"] != ref_ind).sum()), int((b["ind"] != ref_ind).sum())
     d = {k: abs(float(b[k][0]) - float(g[tag + "." + ("loss_q" if k == "loss_q" else k)][0])) / abs(float(g[tag + "." + k][0]))
@@ -709,6 +717,21 @@ def test_cfg5_256_b1_index_flips_and_loss_deltas(golden_dir):
     assert flips_b1 <= ref_flips, "b1 flips more codebook indices than the reference's own bf16 autocast run"
     assert d["loss_l1"] <= max(ref_dl1, 1e-3) and d["loss_q"] <= max(2 * ref_dq, 1e-3)
     assert rms_b1 <= float(g[tag + ".bf16ref.x_recon_rms_rel"])
+    # With bf16 STORAGE the build rounds what the reference's autocast rounds (conv outputs kept in bf16, train_favae.py:239-240): it is no
+    # longer MORE precise than the reference's bf16 run but a second draw from the same precision class -- one scalar per quantity, so
+    # the bar is the class, not the draw: no more index flips than the reference's run, loss deltas within 2 x its deltas, x_recon rms
+    # within 1.25 x.  (Statistics from the fp32 accumulators and a single rounding of conv + residual keep it at or below the reference's
+    # rounding count per layer.)
+    flips_bs = int((bs["ind"] != ref_ind).sum())
+    ds = {k: abs(float(bs[k][0]) - float(g[tag + "." + k][0])) / abs(float(g[tag + "." + k][0])) for k in ("loss_l1", "loss_q")}
+    rms_bs = float(((bs["x_recon"].float() - xr32).pow(2).mean() / xr32.pow(2).mean()).sqrt())
+    print("HIP b1 + bf16 activation storage: %d flips, loss_l1 %.2e, loss_q %.2e, x_recon rms-rel %.2e" % (flips_bs, ds["loss_l1"], ds["loss_q"], rms_bs))
+    margins.record("b1+storage flips", flips_bs, ref_flips + 0.5)
+    margins.record("b1+storage loss_l1 delta", ds["loss_l1"], 2 * ref_dl1)
+    margins.record("b1+storage x_recon rms-rel", rms_bs, 1.25 * float(g[tag + ".bf16ref.x_recon_rms_rel"]))
+    assert flips_bs <= ref_flips
+    assert ds["loss_l1"] <= 2 * max(ref_dl1, 1e-3) and ds["loss_q"] <= max(4 * ref_dq, 2e-3)
+    assert rms_bs <= 1.25 * float(g[tag + ".bf16ref.x_recon_rms_rel"])
     # trained-like codebook: l2-normalised encoder outputs (fp32-grade) of other images, one per code
     codes = []
     with torch.no_grad():

@@ -119,13 +119,61 @@ def test_conv_mixed_precision_b1(K, case):
     the arithmetic BASELINE configs[4] names): every split-path kernel family within bf16-operand tolerance of the fp32 reference
     (8-bit significand: eight times the bar of the fp16 plane), and measurably coarser than fp32-grade."""
     prev = K.set_conv_mode("b1")
+    prev_st = K.set_bf16_storage(False)      # the OPERAND mode: fp32 tensors in and out (bf16 storage: test_bf16_activation_storage_chain)
     try:
         assert K.get_conv_mode() == "b1"
         errs = _conv_case(K, case, 800.0)
         assert max(errs["y"], errs["dx"], errs["dw"]) > 2e-4, errs
     finally:
+        K.set_bf16_storage(prev_st)
         K.set_conv_mode(prev)
     assert K.get_conv_mode() == prev
+
+
+@pytest.mark.parametrize("N,C,HW", [(2, 128, 64), (1, 256, 32), (2, 512, 16), (1, 128, 48)])
+def test_bf16_activation_storage_chain(K, N, C, HW):
+    """bf16 activation STORAGE (round 6, conv mode b1): two ResnetBlock-shaped pairs of GroupNorm + SiLU + conv3x3 (+ residual through the
+    pass_input alias) with bf16 tensors between the fused convs -- forward (direct kernel, statistics epilogue), data gradient (Winograd
+    bf16 plane, GroupNorm-backward epilogue), GroupNorm-backward apply pass, nine-tap weight gradient, all reading / writing bf16 --
+    against the SAME chain with fp32 storage: every output and gradient within the rounding the storage adds (2^-9 per stored tensor,
+    accumulated over the chain: rms <= 2e-2), tensors between the convs really are bf16, and the fp32-storage run is untouched
+    (bit-identical to itself with the switch toggled in between).  W = 48: a width the Winograd kernel does not tile (direct dgrad)."""
+    d = dev()
+    prev = K.set_conv_mode("b1")
+    prev_st = K.set_bf16_storage(False)
+    try:
+        def run(storage):
+            K.set_bf16_storage(storage)
+            torch.manual_seed(5)
+            x0 = torch.randn(N, C, HW, HW, device=d).contiguous(memory_format=torch.channels_last)
+            ws = [(torch.randn(C, C, 3, 3, device=d) / (3 * C ** 0.5)).contiguous(memory_format=torch.channels_last).requires_grad_(True) for _ in range(4)]
+            bs = [(0.1 * torch.randn(C, device=d)).requires_grad_(True) for _ in range(4)]
+            gs = [(1 + 0.2 * torch.randn(C, device=d)).requires_grad_(True) for _ in range(4)]
+            gb = [(0.2 * torch.randn(C, device=d)).requires_grad_(True) for _ in range(4)]
+            gy = torch.randn(N, C, HW, HW, device=d).contiguous(memory_format=torch.channels_last)
+            cfg = K.ConvCfg(3, 3, 1, 1, groups=32)
+            x = x0.clone().requires_grad_(True)
+            h, mids = x, []
+            for blk in range(2):
+                a, skip = K.fused_conv(h, ws[2 * blk], bs[2 * blk], gs[2 * blk], gb[2 * blk], None, cfg, pass_input=True)
+                h = K.fused_conv(a, ws[2 * blk + 1], bs[2 * blk + 1], gs[2 * blk + 1], gb[2 * blk + 1], skip, cfg)
+                mids += [a.dtype, h.dtype]
+            grads = torch.autograd.grad(h.float(), [x] + ws + bs + gs + gb, gy)
+            K.sync_side_stream()
+            torch.cuda.synchronize()
+            return [h.detach().float()] + [g.float() for g in grads], mids
+        f0, m0 = run(False)
+        f1, m1 = run(True)
+        f2, _ = run(False)
+        assert all(t == torch.float32 for t in m0) and all(t == torch.bfloat16 for t in m1), (m0, m1)
+        for i, (u, v) in enumerate(zip(f0, f2)):
+            assert torch.equal(u, v), "the fp32-storage path changed after a bf16-storage run (output %d)" % i
+        for i, (u, v) in enumerate(zip(f1, f0)):
+            rms = float(((u.double() - v.double()).pow(2).mean() / (v.double().pow(2).mean() + 1e-30)).sqrt())
+            assert 1e-5 < rms < 2e-2, "output %d: rms %.2e against the fp32-storage run" % (i, rms)
+    finally:
+        K.set_bf16_storage(prev_st)
+        K.set_conv_mode(prev)
 
 
 def _conv_case(K, case, tol_scale):
@@ -571,6 +619,7 @@ def test_one_plane_winograd_against_the_direct_one_plane_kernel(K, mode, cout, b
         return [t.detach().double() for t in (y, z) + tuple(grads)]
     ref = run()
     prev_mode, prev_fwd = K.get_conv_mode(), K._WINO1_FWD
+    prev_st = K.set_bf16_storage(False)          # the operand modes themselves: fp32 tensors between the convs
     K.set_conv_mode(mode)
     K._WINO1_FWD = True
     try:
@@ -586,6 +635,7 @@ def test_one_plane_winograd_against_the_direct_one_plane_kernel(K, mode, cout, b
     finally:
         K._WINO1_FWD = prev_fwd
         K.set_conv_mode(prev_mode)
+        K.set_bf16_storage(prev_st)
     for i, (r, u, v) in enumerate(zip(ref, wino, direct)):
         s = float(r.abs().max())
         eu, ev = float((u - r).abs().max()) / s, float((v - r).abs().max()) / s

@@ -105,7 +105,11 @@ if steps:
                 return i
         return default
     bwd0 = first(lambda n: n.startswith(("absdiff_bwd", "diff_bwd", "fft_lines_kernel<2", "blur9_stream_kernel<1", "sqdiff_bwd")), len(names) - 1)
-    is_dg = lambda n: (n.startswith("conv3x3_halo_sp_kernel<0") and "true, false>" in n) or n.startswith(("conv3x3_wino_sp_kernel<0, true", "conv3x3_winow_sp_kernel<0, true"))
+    def is_dg(n):       # dense data gradient with the GroupNorm-backward epilogue: halo <0, S, 3, false, true, ...> / wino <0, true, ...>
+        if n.startswith("conv3x3_halo_sp_kernel<0"):
+            a = [v.strip() for v in n[n.index("<") + 1:n.rindex(">")].split(",")]
+            return len(a) >= 5 and a[4] == "true"
+        return n.startswith(("conv3x3_wino_sp_kernel<0, true", "conv3x3_winow_sp_kernel<0, true"))
     dg = [i for i, n in enumerate(names) if is_dg(n)]
     cuts = [0, bwd0, dg[0] if dg else bwd0, dg[-1] + 1 if dg else bwd0, len(names)]
     labels = ["forward", "backward head (losses, blur / FFT backward, decoder tail)", "conv chain (first..last dense data gradient)", "backward tail + Adam"]
