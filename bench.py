@@ -46,7 +46,7 @@ MFMA_WALL_RANDOM_TFLOPS = 1400.0      # measured: register-resident v_mfma_f32_3
                                       # over 3 ms .. 1.5 s runs (tools/experiments/mfma_power.hip; 1.84-1.92 on zeros): what the matrix
                                       # pipe sustains on real data
 SPLIT_PRODUCTS = {0: None, 1: 1, 2: 3, 3: 6, 4: 1}   # 16-bit MFMA products per multiply-add by scheme id (conv_split.h): h1, h3, b6, b1
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_hbm_traffic.json")
 MAX_LINE_BYTES = 4096                 # the driver keeps an 8 KB tail of stdout: the JSON line must stay far below it
 NOTES = {
     "roofline": "dominant kernel of the timed region by total time among all matrix-bound launches (conv forward, data-gradient and "

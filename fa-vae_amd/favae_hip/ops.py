@@ -383,8 +383,14 @@ class WinoRecords:
     def refresh(self):
         on = bool(query("favae_get_wino"))
         mode = get_conv_mode()
+        # the one-plane modes take the Winograd kernel only with FAVAE_WINO1 on (b1: and only in the wide tiling): without them the
+        # library never reads a record and the store (~1 GB) and its grouped launch would be spent for nothing
+        if mode in ("h1", "b1") and (os.environ.get("FAVAE_WINO1", "1") == "0" or
+                                     (mode == "b1" and os.environ.get("FAVAE_WINO_WIDE", "1") == "0")):
+            on = False
         if not self.n or not on or mode not in ("h3", "h1", "b1"):
             self.versions = {}
+            self.store, self.bufs = None, {}
             return
         if self.store is None or self._dirty or getattr(self, "_mode_bf", None) != (4 if mode == "b1" else 0):
             self._materialize()

@@ -53,7 +53,7 @@ def test_no_unguarded_128bit_buffer_store(unit_asm, tmp_path):
         text = open(os.path.join(CSRC, f)).read()
         incs = [l.split('"')[1] for l in text.splitlines() if l.startswith('#include "') and l.split('"')[1].endswith(".h")]
         blob = text + "".join(open(os.path.join(CSRC, h)).read() for h in incs if h != "common.h" and os.path.exists(os.path.join(CSRC, h)))
-        if "bstore(" in blob or "raw_buffer_store_b128(" in blob:
+        if "bstore(" in blob or "act_store4<" in blob or "raw_buffer_store_b128(" in blob:      # act_store4<float> = bstore (common.h)
             users.append(f)
     assert "norm.hip" in users and "conv.hip" in users
     hits = []
