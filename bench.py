@@ -72,6 +72,23 @@ NOTES = {
 }
 
 
+class stdout_to_stderr:
+    """RCCL prints a five-line version banner on fd 1 when a communicator is created; stdout of this program carries ONE JSON line.
+    Route fd 1 to fd 2 while a process group is being initialised (OS level: the banner comes from C++)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def rnd(v, digits=5):
     """5 significant digits: keeps the JSON line short without touching `value` / `ms_per_step`"""
     if v is None or not isinstance(v, float) or v != v or v in (float("inf"), float("-inf")):
@@ -395,7 +412,8 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))           # RCCL on ROCm
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))       # RCCL on ROCm
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -562,7 +580,10 @@ def main():
         # (e) the loop a user of the drop-in boundary runs: train_favae.py:68-119 restated on the drop-in modules -- torch DDP
         # (find_unused_parameters=True), torch.optim.Adam(betas=(0.5, 0.9)), the ten-scalar .item() read-back (tools/ref_loop_bench.py).
         # Last of the extras: it needs a process group (RCCL, world 1 when bench.py runs without one), created and destroyed here.
-        if args.config == "celeba_f16" and not args.gan and not args.lpips and args.precision == "fp32":
+        # World 1 only: at N > 1 nothing here has ever run over RCCL (single-GPU boxes), and an untimed extra must not be able to hang or
+        # kill the run that carries the first scaling numbers.
+        if args.config == "celeba_f16" and not args.gan and not args.lpips and args.precision == "fp32" and world == 1:
+          try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from ref_loop_bench import build_model, reference_loop
             ts = None
@@ -572,11 +593,13 @@ def main():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29549")
                 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                with stdout_to_stderr():
+                    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
             torch.manual_seed(0)
             ref_model = build_model(dev, args.codebook, n_embed, sync_codebook=use_dist, **mk)
             n_ref = min(args.steps, 4)
-            r = reference_loop(ref_model, xs, n_ref, warmup=2, lr=4.5e-6 * args.batch * world, sync_fn=sync)
+            with stdout_to_stderr():                  # (the first collective may print as well)
+                r = reference_loop(ref_model, xs, n_ref, warmup=2, lr=4.5e-6 * args.batch * world, sync_fn=sync)
             t = torch.tensor([r["ms_per_step"]], device=dev, dtype=torch.float64)
             if use_dist:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -587,6 +610,9 @@ def main():
             del ref_model
             if own_pg:
                 dist.destroy_process_group()
+          except Exception as e:                      # an untimed extra: report, never lose the line
+            print("[bench] reference_loop extra failed: %r" % (e,), file=sys.stderr)
+            extras["reference_loop"] = {"error": repr(e)[:200]}
 
     if rank == 0:
         step_us = 1e6 * dt * PROF_STEPS / args.steps           # wall time of the profiled steps (for share_of_step_time)
@@ -654,7 +680,8 @@ def main():
             res["with_lpips"] = extras["with_lpips"]
         if "reference_loop" in extras:
             res["reference_loop"] = extras["reference_loop"]
-            res["reference_loop"]["vs_trainstep"] = rnd(res["reference_loop"]["images_per_s"] / res["value"], 4)
+            if "images_per_s" in res["reference_loop"]:
+                res["reference_loop"]["vs_trainstep"] = rnd(res["reference_loop"]["images_per_s"] / res["value"], 4)
         if comm is not None:
             res["comm"] = comm
         if world == 1 and not use_dist and not args.no_cpu_baseline:

@@ -610,7 +610,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 
             if constexpr (GB) {          // v = da at (pixel, channel col); the conv input x has the same shape
                 const float xh = (xg[r] - g_mu) * g_rs;
                 const float dyv = v * favae_act_grad(fmaf(xh, g_ga, g_be), a.gb_act & 0xff);
-                act_put<AT>(a.y, o, (a.gb_act & FAVAE_GB_PREMUL) ? dyv : v);     // FAVAE_GB_PREMUL: da * act'(y), what the apply pass would recompute
+                act_put<AT>(a.y, o, v);
                 f1 += dyv;               // 16 terms in fp32, everything above that in fp64
                 f2 = fmaf(dyv, xh, f2);
             }

@@ -635,7 +635,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
 
     double gs1 = 0.0, gs2 = 0.0;
     float se_amax = 0.f;
-    const bool gb_pm = GB && (a.gb_act & FAVAE_GB_PREMUL) != 0;
     const float* tr = Ts + fco * TPITCH + frow * 8;
     float tv[2][4][8];                              // [i][b][tile of the row]
 #pragma unroll
@@ -668,8 +667,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_sp_kernel(ConvArgs a) {
                 if constexpr (GB) {
                     const float xh = (pre[q][i][j] - g_mu) * g_rs;
                     const float dyv = y * favae_act_grad(fmaf(xh, g_ga, g_be), a.gb_act & 0xff);
-                    // FAVAE_GB_PREMUL: the tensor written is da * act'(y) -- what the GroupNorm-backward apply pass would recompute
-                    act_store1<AT>(ry, vcol, pix_off(q, i, j), gb_pm ? dyv : y);
+                    act_store1<AT>(ry, vcol, pix_off(q, i, j), y);
                     f1 += dyv;
                     f2 = fmaf(dyv, xh, f2);
                 }

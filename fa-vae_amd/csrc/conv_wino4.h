@@ -392,7 +392,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_sp_kernel(ConvArgs a) {
     }
     double gs1 = 0.0, gs2 = 0.0;
     float se_amax = 0.f;
-    const bool gb_pm = GB && (a.gb_act & FAVAE_GB_PREMUL) != 0;
     float* Ms = reinterpret_cast<float*>(wlds);
     // writer: accumulator register r of a lane = tile 8 (r / 4) + 4 (lane >> 5) + (r & 3) = tile row r / 4, tile column 4 (lane >> 5) + (r & 3);
     // [position][tile quad = 2 (row in pass) + (lane >> 5)][half][co][2]: 8-byte stores, consecutive lanes consecutive addresses
@@ -457,8 +456,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_sp_kernel(ConvArgs a) {
                     if constexpr (GB) {
                         const float xh = (pre[ps][t][i][jj] - g_mu) * g_rs;
                         const float dyv = y * favae_act_grad(fmaf(xh, g_ga, g_be), a.gb_act & 0xff);
-                        // FAVAE_GB_PREMUL: the tensor written is da * act'(y) -- what the GroupNorm-backward apply pass would recompute
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gb_pm ? dyv : y), ry, vcol, pix_off(ps, t, i, jj), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), ry, vcol, pix_off(ps, t, i, jj), 0);
                         f1 += dyv;
                         f2 = fmaf(dyv, xh, f2);
                     }

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
             const float ga = gamma[c], be = beta[c];
             const float xh = (xv[e] - mu) * rs;
             const float y = fmaf(xh, ga, be);
-            const float dy = (act & FAVAE_GB_PREMUL) ? dv[e] : dv[e] * act_grad(y, act);
+            const float dy = dv[e] * act_grad(y, act);
             float o = rs * (dy * ga - k1[n * G + g] - xh * k2[n * G + g]);
             if (dx_add) o += av[e];
             ov[e] = o;
@@ -320,9 +320,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 // CS: the pass also emits, for the tensor dx it writes, the per-block column sums cs_part[block][C] (block = blockIdx.y * gridDim.x
 // + blockIdx.x) and max |dx| -- dx is the `dy` of the conv in front of this GroupNorm, whose bias gradient and fp16 operand
 // range are exactly these two (favae_colsum read the tensor once more for them).
-// PM: `da` already is dy = da * act'(y) (FAVAE_GB_PREMUL: written by the data-gradient conv's epilogue, which needs it for the sums anyway)
 // AT (round 6): storage type of da / x / dx_add / dx (float, or bf16_t: every tensor of the pass at half the bytes; same arithmetic)
-template <bool SKIP, bool CS, bool PM = false, typename AT = float>
+template <bool SKIP, bool CS, typename AT = float>
 __global__ __launch_bounds__(256, 5) void gn_bwd_apply_rows_kernel(const float* __restrict__ da, const float* __restrict__ x,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -367,8 +366,7 @@ __global__ __launch_bounds__(256, 5) void gn_bwd_apply_rows_kernel(const float* 
             // explicit fused multiply-adds: every instantiation rounds the same way (left to the compiler, the contraction of
             // rs (dy ga - k1 - xh k2) changed with the code around it)
             const float xh = (xv[e] - mu[e]) * rs[e];
-            float dy = dv[e];
-            if constexpr (!PM) dy = dv[e] * act_grad(fmaf(xh, ga[e], be[e]), act);
+            const float dy = dv[e] * act_grad(fmaf(xh, ga[e], be[e]), act);
             const float t = fmaf(-xh, rk2[e], fmaf(dy, ga[e], -rk1[e]));
             ov[e] = SKIP ? fmaf(rs[e], t, av[e]) : rs[e] * t;
         }
@@ -593,12 +591,10 @@ static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, 
                            favae_stream_t stream, float* cs_part, float* cs_amax) {
     FAVAE_REQUIRE(da && x && gamma && beta && mean && rstd && dx && ws && N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0);
     FAVAE_REQUIRE((dgamma == nullptr) == (dbeta == nullptr));
-    const bool pm = (act & FAVAE_GB_PREMUL) != 0;     // `da` is dy = da * act'(y): only the conv epilogue that made the sums can have written it
-    FAVAE_REQUIRE(!pm || tile_partials > 0);
     // FAVAE_ACT_BF16IO (round 6): da, x, dx_add and dx are bf16 tensors (bf16 activation storage); the row-organised pass only
     const bool bf = (act & FAVAE_ACT_BF16IO) != 0;
     act &= ~FAVAE_ACT_BF16IO;
-    if (bf && (pm || C % 4 != 0 || ((((uintptr_t)da) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)dx_add)) & 7) != 0 ||
+    if (bf && (C % 4 != 0 || ((((uintptr_t)da) | ((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)dx_add)) & 7) != 0 ||
                !apply_rows_blocks(N, HW, C)))
         return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (ws_bytes < (tile_partials ? favae_gn_bwd_tiles_workspace(N, tile_partials, C) : favae_gn_workspace(N, HW, C)))
@@ -629,10 +625,8 @@ static int gn_act_bwd_impl(const float* da, const float* x, const float* gamma, 
         const dim3 grid((unsigned)S, N);
 #define FAVAE_LAUNCH_APPLY(SK, CS)                                                                                             \
     do {                                                                                                                       \
-        if (bf) FAVAE_KLAUNCH((gn_bwd_apply_rows_kernel<SK, CS, false, bf16_t>), grid, dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, \
+        if (bf) FAVAE_KLAUNCH((gn_bwd_apply_rows_kernel<SK, CS, bf16_t>), grid, dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, \
                               k2, dx_add, dx, (long)HW, C, G, act, rpb, cs_part, (unsigned*)cs_amax);                          \
-        else if (pm) FAVAE_KLAUNCH((gn_bwd_apply_rows_kernel<SK, CS, true>), grid, dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2, \
-                              dx_add, dx, (long)HW, C, G, act & 0xff, rpb, cs_part, (unsigned*)cs_amax);                       \
         else FAVAE_KLAUNCH((gn_bwd_apply_rows_kernel<SK, CS>), grid, dim3(256), 0, s, da, x, gamma, beta, mean, rstd, k1, k2, dx_add, \
                            dx, (long)HW, C, G, act, rpb, cs_part, (unsigned*)cs_amax);                                         \
     } while (0)

@@ -490,13 +490,6 @@ _WREC = {1: 8, 2: 16, 3: 24, 4: 8}    # bytes of one pre-split record (4 weights
 _WINO_FLIP_FWD = os.environ.get("FAVAE_WINO_FLIP_FWD", "1") != "0"
 PLANES_WINO = 0x100                   # include/favae_hip.h FAVAE_PLANES_WINO: the records are Winograd records (favae_wino_weights)
 PLANES_WINO4 = 0x200                  # ... F(4x4, 3x3) records (flip | 2): conv3x3_wino4_sp_kernel
-GB_PREMUL = 0x100                     # include/favae_hip.h FAVAE_GB_PREMUL (flag on `act` of favae_conv_dgrad_gnbwd / favae_gn_act_bwd_*)
-# FAVAE_GB_PREMUL=1 (A/B arm, bit-identical results; default off): the apply pass gets 25 % lighter -- 14.4 -> 13.6 ms exclusive, the
-# single-stream step 155.5 -> 154.4 ms -- and the two-stream step 0.4-0.9 ms SLOWER (134.3 / 134.5 / 134.8 / 135.4 against 135.3 / 135.3 /
-# 135.3 / 135.8, four same-box pairs): the main queue reaches the next data gradient sooner, which then shares the CUs with the weight
-# gradient still running on the second stream for longer (in-step data gradient 42.8 -> 45.0 ms, weight gradient 36.8 -> 37.9).  The
-# HBM-bound pass was hiding in the shadow of the matrix kernels; making it faster moves matrix work into matrix work.
-_GB_PREMUL = os.environ.get("FAVAE_GB_PREMUL", "0") == "1"
 CONV_MODES = {"fp32": 0, "h1": 1, "h3": 2, "b6": 3, "b1": 4}
 
 
@@ -1213,9 +1206,6 @@ class FusedConvFn(torch.autograd.Function):
                     gn_tiles = query("favae_conv_gnbwd_tiles", byref(d2), PLANES_WINO4 if f43_now else 0)
                     if gn_tiles:
                         gn_ws = workspace(query("favae_gn_bwd_tiles_workspace", N, gn_tiles, Cin), dev)
-                        # FAVAE_GB_PREMUL: the epilogue writes dy = da * act'(y) (it has it in registers for the sums) and the apply
-                        # pass below takes it as such -- no second transcendental per element in the HBM-bound pass
-                        act_gn = act | GB_PREMUL if (_GB_PREMUL and not st) else act
                         gnb = (x, mean, rstd, gn_w, gn_b, cfg.groups, act_gn, gn_ws)
                 if _SERIALIZE_MFMA and gn_tiles and _SIDE["used"]:
                     # experiment: the dense data gradient starts only after the weight gradient of the layer behind it has retired
@@ -1243,7 +1233,7 @@ class FusedConvFn(torch.autograd.Function):
                 cs_blocks = query("favae_gn_bwd_colsum_blocks", gN, gHW, Cin) if _DYCS_FUSE else 0
                 if not gn_tiles:
                     gn_ws = workspace(query("favae_gn_workspace", gN, gHW, Cin), dev)
-                act_ap = act_gn if gn_tiles else act          # flagged only when the epilogue really wrote the pre-multiplied tensor
+                act_ap = act
                 if st:
                     act_ap |= BF16IO_ACT                      # da, x, dskip, dx are bf16 tensors (include/favae_hip.h FAVAE_ACT_BF16IO)
                 if cs_blocks:                                 # the apply pass also leaves colsum / max|dx| for the conv in front

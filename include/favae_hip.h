@@ -487,13 +487,8 @@ int favae_gn_stats_tiles(const void* part, int tiles, const float* gamma, const 
  * deterministic); favae_gn_act_bwd_tiles = favae_gn_act_bwd without its streaming pass 1 (two tensor reads less per GroupNorm).
  *   favae_conv_gnbwd_tiles(d, planes)   tiles per image when the data gradient `d` runs that kernel, else 0 (planes: as above)
  *   favae_gn_bwd_tiles_workspace    bytes of the workspace shared by the two calls: it STARTS with `part`
- *   act | FAVAE_GB_PREMUL (round 5): the epilogue has dy = da * act'(y) in registers for the sums -- with the flag it WRITES that
- *     tensor instead of da, and favae_gn_act_bwd_tiles / favae_gn_act_bwd_colsum called with the same flagged `act` (and tiles > 0)
- *     take it as dy: the apply pass loses its transcendental per element (it was co-bound by the vector ALU: 0.58 of the HBM
- *     roofline).  Same values bit for bit: both sides evaluate the same expression.
  * Reference: autograd of GroupNorm + SiLU in ResnetBlock / NonResnetBlock / final (models/codec.py:38-46,65-73,170-175).
  * ---------------------------------------------------------------------------------------------------------- */
-#define FAVAE_GB_PREMUL 0x100
 /* bf16 activation STORAGE (ABI 21, round 6; BASELINE configs[4] "bf16": accelerate's autocast keeps conv outputs in bf16,
  * favae_scripts/train_favae.py:239-240).  With the flag on `act`, favae_gn_act_bwd / _tiles / _colsum take da, x, dx_add and write dx as
  * bf16 tensors (same element counts; round to nearest even on store, exact widening on load); statistics, sums and the arithmetic stay

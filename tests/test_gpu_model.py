@@ -403,7 +403,7 @@ def test_side_stream_weight_gradients_are_race_free(mtag, hw):
     assert float((ref1 - ref2).abs().max()) < 2e-5 * scale, float((ref1 - ref2).abs().max()) / scale
 
 
-@pytest.mark.parametrize("switch", ["_DYCS_FUSE", "_GNBWD_FUSE", "_DEFER_REDUCE", "_DIRECT_GRAD", "_GB_PREMUL"])
+@pytest.mark.parametrize("switch", ["_DYCS_FUSE", "_GNBWD_FUSE", "_DEFER_REDUCE", "_DIRECT_GRAD"])
 def test_ab_switches_give_the_same_gradients(switch):
     """Every A/B arm of the backward pass (FAVAE_DYCS_FUSE / FAVAE_GNBWD_FUSE / FAVAE_DEFER_REDUCE / FAVAE_DIRECT_GRAD = 0) is a
     different schedule of the same sums: whole-model gradients must agree with the default path to rounding.  (Round 4: FAVAE_DYCS_FUSE=0
@@ -433,8 +433,6 @@ def test_ab_switches_give_the_same_gradients(switch):
     assert torch.isfinite(got).all()
     scale = float(ref.abs().max())
     assert float((got - ref).abs().max()) < 2e-5 * scale, "%s=0 changes the gradients by %g of the max" % (switch, float((got - ref).abs().max()) / scale)
-    if switch == "_GB_PREMUL":     # the data-gradient epilogue writes da * act'(y), the apply pass takes it: the SAME expression on both sides
-        assert torch.equal(got, ref), "FAVAE_GB_PREMUL must not change a bit (max diff %g of the max)" % (float((got - ref).abs().max()) / scale)
 
 
 def test_gan_stage1_discriminator_alone_against_reference_golden(golden_dir):
