@@ -285,8 +285,7 @@ def kernel_planes(name):
         return None
     args = [a.strip() for a in name[name.index("<") + 1:-1].split(",")]
     try:
-        if (name.startswith("conv3x3_halo_sp_kernel") or name.startswith("conv_wgrad_row3_sp_kernel")
-                or name.startswith("conv_wgrad_nine_sp_kernel")):
+        if name.startswith("conv3x3_halo_sp_kernel") or name.startswith("conv_wgrad_nine_sp_kernel"):
             return int(args[1])
         if name.startswith("conv_fwd_sp_kernel") or name.startswith("conv_wgrad_sp_kernel"):
             return int(args[-1])

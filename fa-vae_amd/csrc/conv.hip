@@ -53,13 +53,7 @@ bool use_halo2() {
     if (v < 0) { const char* e = getenv("FAVAE_CONV_HALO2"); v = (e && e[0] == '0') ? 0 : 1; }
     return v == 1;
 }
-// FAVAE_WGRAD_ROW3=0 disables the three-taps-per-workgroup weight-gradient kernel (A/B switch)
-bool use_row3() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FAVAE_WGRAD_ROW3"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
-}
-// FAVAE_WGRAD_NINE=0 sends the 3x3 weight gradients back to the three-taps-per-workgroup kernel (A/B switch)
+// FAVAE_WGRAD_NINE=0 sends the 3x3 weight gradients back to the per-tap kernel conv_wgrad_sp_kernel (A/B switch)
 // 1 (default) = 128 co x 64 ci, 8 waves, prefetch distance 1 (204 registers: 96 of a SIMD lane's 512 stay free next to its two waves,
 // which is what lets the <= 96-register GroupNorm-backward / bias-gradient passes of the main stream run beside it) | 2 = the same with
 // prefetch distance 2 (220 registers) | 3 = 64 x 64, 4 waves, one workgroup per CU (A/B: half the rate, a single wave per SIMD)
@@ -125,9 +119,7 @@ struct ConvArgs {
     // conv3x3_halo_sp_kernel<., 2, 3> only: when set, the kernel also stores the transformed + split operand T(x) it stages
     // (two scaled fp16 planes, one 16-byte record {hi[4], lo[4]} per 4 channels = the bytes of the fp32 tensor) for the
     // weight-gradient kernel, which then loads its operands without any transform / split arithmetic
-    void* planes_out;
-    unsigned planes_bytes;
-    // conv3x3_halo_sp_kernel<0, 2, 3, false, true> only (data gradient of a conv whose input was GroupNorm(+act)'ed): the epilogue
+    // conv3x3_halo_sp_kernel<0, 2, 3, true> only (data gradient of a conv whose input was GroupNorm(+act)'ed): the epilogue
     // also forms this tile's share of the two GroupNorm-backward sums S1 = sum dy, S2 = sum dy * xhat (dy = da * act'(y)) from the
     // da it has in registers and the matching tile of the conv input x -- the streaming pass-1 kernel (2 tensor reads) goes away.
     const float* gb_x;
@@ -137,7 +129,7 @@ struct ConvArgs {
     const float* gb_beta;
     double* gb_part;          // [N][tiles per image][C][2]
     int gb_groups, gb_act;
-    // conv3x3_halo_sp_kernel<., 2, 3, false, false, true>: per-tile sums (sum y, sum y^2) per output channel of the FINAL output
+    // conv3x3_halo_sp_kernel<., 2, 3, false, true>: per-tile sums (sum y, sum y^2) per output channel of the FINAL output
     // (bias and residual included) -- pass 1 of the GroupNorm that consumes this conv's output (gn_partial<0>: one tensor read)
     double* gs_part;          // [N][tiles per image][Cout][2]
     unsigned* gs_amax;        // optional (same variant): max |y| of the output, bit pattern, one atomicMax per workgroup (pre-zeroed)
@@ -358,8 +350,6 @@ struct WgradArgs {
     const float* dy_amax;
     int pad_w;                              // conv_wgrad_sp_kernel only: left padding, dy on a sub-grid (see ConvArgs)
     int dy_step, dy_row, dy_img, dy_off;
-    const void* x_planes;                   // conv_wgrad_row3_sp_kernel<., 2, PRE>: pre-split operands (ConvArgs::planes_out)
-    const void* dy_planes;
 };
 
 template <int BCO, int BCI, int WAVES_O, int WAVES_I>
@@ -712,27 +702,6 @@ int wgrad_splitk(const favae_conv_desc* d, int tiles, int* chunk) {
     return (int)sk;
 }
 
-// Split-K for the one-workgroup-per-CU row3 kernel: the grid must be a whole number of 256-CU rounds (all workgroups take
-// the same time, so 513 workgroups cost three rounds, not two).  Picks the round count (1..3) with the best fill, never
-// more splits than wgrad_splitk (the workspace is sized by that one).
-int row3_splitk(const favae_conv_desc* d, int tiles3, int sk_max, int* chunk) {
-    const long M = (long)d->N * d->Hout * d->Wout;
-    long best_sk = 1;
-    double best_eff = 0.0;
-    for (int r = 1; r <= 3; ++r) {
-        long sk = (256L * r) / tiles3;
-        if (sk < 1) sk = 1;
-        if (sk > sk_max) sk = sk_max;
-        const long total = sk * tiles3;
-        const double eff = (double)total / (256.0 * ((total + 255) / 256));
-        if (eff > best_eff + 0.01 || (r == 2 && eff >= best_eff - 0.01)) { best_eff = eff; best_sk = sk; }
-    }
-    long ch = (M + best_sk - 1) / best_sk;
-    ch = (ch + 15) / 16 * 16;
-    *chunk = (int)ch;
-    return (int)((M + ch - 1) / ch);
-}
-
 // Split-K of the nine-tap kernel (one 512-thread workgroup per CU): slabs are whole 16-pixel column strips of the images
 // (N * Wout / 16 of them); the grid should be a whole number of 256-CU rounds, with equal strips per slab.
 int nine_splitk(const favae_conv_desc* d, int tiles, int sk_max, int per_round, int* strips_per_slab) {
@@ -973,7 +942,7 @@ struct GnBwdEpi {              // GroupNorm-backward partial sums in the data-gr
 };
 static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                          const float* scale, const float* shift, float* y, int wplanes, const float* x_amax,
-                         favae_stream_t stream, void* planes_out, const GnBwdEpi* gb = nullptr, double* stats_part = nullptr,
+                         favae_stream_t stream, const GnBwdEpi* gb = nullptr, double* stats_part = nullptr,
                          float* stats_amax = nullptr);
 
 extern "C" int favae_conv_fwd(const favae_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -1002,20 +971,13 @@ extern "C" int favae_conv_fwd_split(const favae_conv_desc* d, const float* x, co
         const int pl = planes & ~FAVAE_PLANES_BF16IO;
         FAVAE_REQUIRE(wsplit && (pl == 3 || pl == 4 || ((pl == 2 || pl == 1) && x_absmax)));
     }
-    return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr);
+    return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream);
 }
 
-// producer side of the pre-split operand planes: 1 when favae_conv_fwd_split(d, ...) runs the dense 3x3 halo kernel with two fp16
-// planes -- the kernel that can store its staged operand as a by-product (ConvArgs::planes_out)
 // 1 when favae_conv_fwd_split(d, ...) runs the dense 3x3 halo kernel with fp16 planes (two: h3, or one: h1) -- the kernel whose
 // epilogue can emit GroupNorm sums (SE / GB variants)
 static bool halo3_fp16_ok(const favae_conv_desc* d, bool has_affine);
 static bool wino_ok(const favae_conv_desc* d, bool has_affine);
-
-static bool planes_producer_ok(const favae_conv_desc* d, bool has_affine) {      // the direct halo kernel stores them: its shapes only
-    return conv_mode() == 2 && halo3_fp16_ok(d, has_affine) && d->Cout > 64 &&
-           (!has_affine || d->act == FAVAE_ACT_NONE || d->act == FAVAE_ACT_SILU);
-}
 
 static bool halo3_fp16_ok(const favae_conv_desc* d, bool has_affine) {
     if (!sp_fwd_eligible(d, has_affine) || conv_mode() == 3 || conv_mode() == 0 || desc_special(d) || !use_halo()) return false;
@@ -1159,19 +1121,6 @@ extern "C" int favae_wino_weights_grouped(const void* jobs, const int* block_job
     return FAVAE_OK;
 }
 
-extern "C" int favae_conv_planes_ok(const favae_conv_desc* d, int has_affine) {
-    return desc_ok(d) && planes_producer_ok(d, has_affine != 0) ? 1 : 0;
-}
-
-extern "C" int favae_conv_fwd_split_planes(const favae_conv_desc* d, const float* x, const void* wsplit, int planes,
-                                           const float* x_absmax, const float* bias, const float* resid, const float* scale,
-                                           const float* shift, float* y, void* planes_out, favae_stream_t stream) {
-    if (!sp_fwd_eligible(d, scale != nullptr)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-    FAVAE_REQUIRE(wsplit && (planes == 3 || ((planes == 2 || planes == 1) && x_absmax)));
-    if (planes_out && !(planes == 2 && planes_producer_ok(d, scale != nullptr) && al16(planes_out))) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-    return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, planes_out);
-}
-
 // Data gradient of a conv whose INPUT was act(GroupNorm(x)): da = conv(dy, flipped w) as favae_conv_fwd_split, plus, from the
 // epilogue, the per-tile partial sums of the GroupNorm backward (norm.hip: S1 = sum dy, S2 = sum dy xhat with dy = da act'(y))
 // into part[N][tiles][C][2] (double; tiles = (H/8) (W/16) per image) -- favae_gn_act_bwd_tiles consumes them.
@@ -1188,13 +1137,13 @@ static int wino_part_tiles(const favae_conv_desc* d, bool has_affine, int planes
 static bool direct_grid_mismatch(const favae_conv_desc* d, int planes, bool has_affine) {
     return conv_mode() != 2 && !(planes & FAVAE_PLANES_WINO) && wino_ok(d, has_affine) && !wino_wide_ok(d, has_affine);
 }
-static bool wgrad_row3_ok(const favae_conv_desc* d);
+static bool wgrad_nine_geom_ok(const favae_conv_desc* d);
 // bf16 activation storage: does the kernel that would run `d` have the bf16 instantiation?  kind 0: forward / plain conv call
 // (favae_conv_fwd_split, _stats), 1: data gradient with the GroupNorm-backward epilogue (favae_conv_dgrad_gnbwd), 2: weight gradient.
 extern "C" int favae_conv_bf16io_ok(const favae_conv_desc* d, int has_affine, int kind) {
     if (!desc_ok(d) || conv_mode() != 4) return 0;
     if (kind == 2) {
-        if (!wgrad_row3_ok(d) || !use_nine() || nine_mode() != 1 || d->Hout != d->Hin || d->Wout != d->Win) return 0;
+        if (!wgrad_nine_geom_ok(d) || !use_nine() || nine_mode() != 1 || d->Hout != d->Hin || d->Wout != d->Win) return 0;
         return (has_affine && d->act != FAVAE_ACT_NONE && d->act != FAVAE_ACT_SILU) ? 0 : 1;
     }
     if (!halo3_fp16_ok(d, has_affine != 0) || d->Cout <= 64) return 0;
@@ -1231,7 +1180,7 @@ extern "C" int favae_conv_fwd_split_stats(const favae_conv_desc* d, const float*
     if (!tiles || ((planes & 0xff) != 2 && (planes & 0xff) != 1 && (planes & 0xff) != 4)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     if (y_absmax && favae_zero_target(y_absmax, sizeof(float), (hipStream_t)stream) != hipSuccess) return favae_prof_fail_(FAVAE_ERR_LAUNCH);
-    return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr, nullptr,
+    return conv_fwd_impl(d, x, (const float*)wsplit, bias, resid, scale, shift, y, planes, x_absmax, stream, nullptr,
                          (double*)part, y_absmax);
 }
 
@@ -1248,12 +1197,12 @@ extern "C" int favae_conv_dgrad_gnbwd(const favae_conv_desc* d, const float* dy,
     if (!tiles || ((planes & 0xff) != 2 && (planes & 0xff) != 1 && (planes & 0xff) != 4) || d->Cout % groups != 0) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (part_bytes < (size_t)d->N * tiles * d->Cout * 2 * sizeof(double)) return favae_prof_fail_(FAVAE_ERR_WORKSPACE);
     GnBwdEpi gb{x, mean, rstd, gamma, beta, (double*)part, groups, act};
-    return conv_fwd_impl(d, dy, (const float*)wsplit, nullptr, nullptr, nullptr, nullptr, da, planes, dy_absmax, stream, nullptr, &gb);
+    return conv_fwd_impl(d, dy, (const float*)wsplit, nullptr, nullptr, nullptr, nullptr, da, planes, dy_absmax, stream, &gb);
 }
 
 static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                          const float* scale, const float* shift, float* y, int wplanes, const float* x_amax,
-                         favae_stream_t stream, void* planes_out, const GnBwdEpi* gb, double* stats_part, float* stats_amax) {
+                         favae_stream_t stream, const GnBwdEpi* gb, double* stats_part, float* stats_amax) {
     FAVAE_REQUIRE(desc_ok(d) && x && w && y);
     FAVAE_REQUIRE((scale == nullptr) == (shift == nullptr));
     // roofline numerators of this conv: 2*M*Cout*KH*KW*Cin FLOP; one read of x (+ resid), one write of y, the weights --
@@ -1270,7 +1219,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     // only the kernels with that instantiation (the dense 3x3 halo kernel and the wide Winograd kernel): favae_conv_bf16io_ok
     const bool bf16io = (wplanes & FAVAE_PLANES_BF16IO) != 0;
     wplanes &= 0xff;
-    if (bf16io && (wplanes != 4 || wino4 || planes_out || ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)resid)) & 7) != 0))
+    if (bf16io && (wplanes != 4 || wino4 || ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)resid)) & 7) != 0))
         return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (bf16io)          // the activation bytes of the note above at two bytes per element
         FAVAE_PROF_NOTE(2.0 * d->N * d->Hout * d->Wout * d->Cout * d->KH * d->KW * d->Cin,
@@ -1329,7 +1278,6 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         }
     }
     ConvArgs a;
-    a.planes_out = planes_out;
     a.gb_x = nullptr; a.gb_mean = a.gb_rstd = a.gb_gamma = a.gb_beta = nullptr; a.gb_part = nullptr; a.gb_groups = 1; a.gb_act = 0;
     a.gs_part = stats_part;
     a.gs_amax = (unsigned*)stats_amax;
@@ -1373,7 +1321,6 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
                         (size_t)d->N * a.out_img * d->Cout * 4 < ((size_t)1 << 32) && (d->gather == FAVAE_GATHER_PLAIN || xf == 0);
     if (special && !(buf_ok && use_b6() && bn == 128 && w6 && d->gather == FAVAE_GATHER_PLAIN)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     a.x_bytes = (unsigned)(bf16io ? xb / 2 : xb); a.aff_bytes = (unsigned)ab;
-    a.planes_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)(wplanes ? wb / 16 * wrec_bytes(wplanes) : wb);
 #define FAVAE_LAUNCH_BUF(G, X)                                                                                     \
     do {                                                                                                           \
@@ -1391,7 +1338,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
     // that would read them as fp32 weights
     if (w6 && !wino && bn != 128) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (wino) {
-        if (!(!special && buf_ok && use_b6() && w6 && wino_geometry(d) && wplanes == conv_mode() && !planes_out && d->w_rec_offset == 0))
+        if (!(!special && buf_ok && use_b6() && w6 && wino_geometry(d) && wplanes == conv_mode() && d->w_rec_offset == 0))
             return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (gb && (xf != 0 || bias || resid)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (stats_part && !(xf == 0 || xf == 2)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
@@ -1490,11 +1437,10 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         else FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 3, KS>), hgrid, dim3(512), 0, s, a);               \
     } while (0)
 #define FAVAE_LAUNCH_HALO(X) FAVAE_LAUNCH_HALO_K(X, 3)
-        if (planes_out && !(halo_ok && wplanes == 2 && xf != 3)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (bf16io) {                       // bf16 activation storage: the dense 3x3 kernel with the bf16 plane
             if (!(halo_ok && wplanes == 4) || (gb && (xf != 0 || bias || resid)) || (stats_part && (gb || !(xf == 0 || xf == 2))))
                 return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-#define FAVAE_LAUNCH_HALO_BF(X, GBV, SEV) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 4, 3, false, GBV, SEV, bf16_t>), hgrid, dim3(512), 0, s, a)
+#define FAVAE_LAUNCH_HALO_BF(X, GBV, SEV) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 4, 3, GBV, SEV, bf16_t>), hgrid, dim3(512), 0, s, a)
             if (gb) FAVAE_LAUNCH_HALO_BF(0, true, false);
             else if (stats_part && xf == 0) FAVAE_LAUNCH_HALO_BF(0, false, true);
             else if (stats_part) FAVAE_LAUNCH_HALO_BF(2, false, true);
@@ -1507,21 +1453,17 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
             return FAVAE_OK;
         }
         const bool fp16p = wplanes == 2 || wplanes == 1 || wplanes == 4;           // schemes with the epilogue variants
-        if (gb && !(halo_ok && fp16p && xf == 0 && !planes_out && !bias && !resid)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-        if (stats_part && !(halo_ok && fp16p && (xf == 0 || xf == 2) && !planes_out && !gb)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-        if (gb && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, true>), hgrid, dim3(512), 0, s, a);
-        else if (gb && wplanes == 4) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 4, 3, false, true>), hgrid, dim3(512), 0, s, a);
-        else if (gb) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 1, 3, false, true>), hgrid, dim3(512), 0, s, a);
-        else if (stats_part && xf == 0 && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
-        else if (stats_part && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 2, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
-        else if (stats_part && xf == 0 && wplanes == 4) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 4, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
-        else if (stats_part && wplanes == 4) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 4, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
-        else if (stats_part && xf == 0) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 1, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
-        else if (stats_part) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 1, 3, false, false, true>), hgrid, dim3(512), 0, s, a);
-        else
-        if (planes_out && xf == 0) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, true>), hgrid, dim3(512), 0, s, a);
-        else if (planes_out && xf == 1) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<1, 2, 3, true>), hgrid, dim3(512), 0, s, a);
-        else if (planes_out) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 2, 3, true>), hgrid, dim3(512), 0, s, a);
+        if (gb && !(halo_ok && fp16p && xf == 0 && !bias && !resid)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+        if (stats_part && !(halo_ok && fp16p && (xf == 0 || xf == 2) && !gb)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
+        if (gb && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, true>), hgrid, dim3(512), 0, s, a);
+        else if (gb && wplanes == 4) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 4, 3, true>), hgrid, dim3(512), 0, s, a);
+        else if (gb) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 1, 3, true>), hgrid, dim3(512), 0, s, a);
+        else if (stats_part && xf == 0 && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (stats_part && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 2, 3, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (stats_part && xf == 0 && wplanes == 4) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 4, 3, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (stats_part && wplanes == 4) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 4, 3, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (stats_part && xf == 0) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 1, 3, false, true>), hgrid, dim3(512), 0, s, a);
+        else if (stats_part) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<2, 1, 3, false, true>), hgrid, dim3(512), 0, s, a);
         else if (halo2_ok) FAVAE_LAUNCH_HALO_K(0, 2);
         else if (xf == 0) FAVAE_LAUNCH_HALO(0);
         else if (xf == 1) FAVAE_LAUNCH_HALO(1);
@@ -1587,7 +1529,7 @@ extern "C" size_t favae_conv_wgrad_workspace(const favae_conv_desc* d) {
 }
 
 static int conv_wgrad_impl(const favae_conv_desc* d, const float* x, const float* dy, const float* scale, const float* shift,
-                           const float* x_absmax, const float* dy_absmax, const void* x_planes, const void* dy_planes, float* dw,
+                           const float* x_absmax, const float* dy_absmax, float* dw,
                            int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream, int* slabs_out = nullptr);
 
 // Weight gradient WITHOUT its slab reduction: the partial slabs stay in `ws` ([*slabs][Cout][KH][KW][Cin] floats, *slabs written on
@@ -1597,32 +1539,17 @@ extern "C" int favae_conv_wgrad_slabs(const favae_conv_desc* d, const float* x, 
                                       const float* shift, const float* x_absmax, const float* dy_absmax, void* ws, size_t ws_bytes,
                                       int* slabs, favae_stream_t stream) {
     FAVAE_REQUIRE(slabs);
-    return conv_wgrad_impl(d, x, dy, scale, shift, x_absmax, dy_absmax, nullptr, nullptr, (float*)ws, 0, ws, ws_bytes, stream, slabs);
+    return conv_wgrad_impl(d, x, dy, scale, shift, x_absmax, dy_absmax, (float*)ws, 0, ws, ws_bytes, stream, slabs);
 }
 
 extern "C" int favae_conv_wgrad(const favae_conv_desc* d, const float* x, const float* dy, const float* scale,
                                 const float* shift, const float* x_absmax, const float* dy_absmax, float* dw, int accumulate,
                                 void* ws, size_t ws_bytes, favae_stream_t stream) {
-    return conv_wgrad_impl(d, x, dy, scale, shift, x_absmax, dy_absmax, nullptr, nullptr, dw, accumulate, ws, ws_bytes, stream);
+    return conv_wgrad_impl(d, x, dy, scale, shift, x_absmax, dy_absmax, dw, accumulate, ws, ws_bytes, stream);
 }
 
-extern "C" int favae_conv_wgrad_planes(const favae_conv_desc* d, const float* x, const float* dy, const float* scale,
-                                       const float* shift, const float* x_absmax, const float* dy_absmax, const void* x_planes,
-                                       const void* dy_planes, float* dw, int accumulate, void* ws, size_t ws_bytes,
-                                       favae_stream_t stream) {
-    FAVAE_REQUIRE(al16(x_planes) && al16(dy_planes));
-    return conv_wgrad_impl(d, x, dy, scale, shift, x_absmax, dy_absmax, x_planes, dy_planes, dw, accumulate, ws, ws_bytes, stream);
-}
-
-static bool wgrad_row3_ok(const favae_conv_desc* d);
-
-// consumer side: 1 when the weight gradient of `d` runs the three-tap kernel with two fp16 planes, which can take pre-split operands
-extern "C" int favae_conv_wgrad_takes_planes(const favae_conv_desc* d) {
-    return desc_ok(d) && conv_mode() == 2 && wgrad_row3_ok(d) ? 1 : 0;
-}
-
-static bool wgrad_row3_ok(const favae_conv_desc* d) {          // mirrors the `row3` branch of conv_wgrad_impl
-    if (thin_kind(d, false) || thin_kind(d, true) || desc_special(d) || force_generic() || force_nobuf() || !use_b6() || !use_row3())
+static bool wgrad_nine_geom_ok(const favae_conv_desc* d) {     // mirrors the `dense3` condition of conv_wgrad_impl
+    if (thin_kind(d, false) || thin_kind(d, true) || desc_special(d) || force_generic() || force_nobuf() || !use_b6())
         return false;
     if (d->act != FAVAE_ACT_NONE && d->act != FAVAE_ACT_SILU) return false;
     int bco, bci;
@@ -1633,7 +1560,7 @@ static bool wgrad_row3_ok(const favae_conv_desc* d) {          // mirrors the `r
 }
 
 static int conv_wgrad_impl(const favae_conv_desc* d_in, const float* x, const float* dy, const float* scale, const float* shift,
-                           const float* x_absmax, const float* dy_absmax, const void* x_planes, const void* dy_planes, float* dw,
+                           const float* x_absmax, const float* dy_absmax, float* dw,
                            int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream, int* slabs_out) {
     // bf16 activation storage (round 6): FAVAE_ACT_BF16IO on the descriptor's `act` = x and dy are bf16 tensors; only the nine-tap
     // kernel of scheme 4 has that instantiation (favae_conv_bf16io_ok(d, has_affine, 2))
@@ -1697,7 +1624,6 @@ static int conv_wgrad_impl(const favae_conv_desc* d_in, const float* x, const fl
     wgrad_tiles(d, &bco, &bci);
     WgradArgs a;
     a.x = x; a.dy = dy; a.scale = scale; a.shift = shift; a.part = (float*)ws;
-    a.x_planes = x_planes; a.dy_planes = dy_planes;
     a.x_amax = x_absmax; a.dy_amax = dy_absmax;
     const bool special = desc_special(d);
     a.pad_w = d->pad + d->pad_dw;
@@ -1743,9 +1669,9 @@ static int conv_wgrad_impl(const favae_conv_desc* d_in, const float* x, const fl
         else if (bco == 32) FAVAE_KLAUNCH((conv_wgrad_buf_kernel<32, 128, 1, 4, X>), grid, dim3(256), 0, s, a);            \
         else FAVAE_KLAUNCH((conv_wgrad_buf_kernel<128, 32, 4, 1, X>), grid, dim3(256), 0, s, a);                           \
     } while (0)
-    const bool row3 = !special && buf_ok && use_b6() && use_row3() && bco == 128 && bci == 128 && d->gather == FAVAE_GATHER_PLAIN &&
+    const bool dense3 = !special && buf_ok && use_b6() && bco == 128 && bci == 128 && d->gather == FAVAE_GATHER_PLAIN &&
                       d->KH == 3 && d->KW == 3 && d->pad == 1 && d->stride == 1;
-    const bool nine = row3 && use_nine() && !x_planes && !dy_planes && d->Hout == d->Hin && d->Wout == d->Win;
+    const bool nine = dense3 && use_nine() && d->Hout == d->Hin && d->Wout == d->Win;
     if (bf16io && !(nine && np == 4 && nine_mode() == 1 && xf != 3)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     if (bf16io) a.x_bytes = (unsigned)(xb / 2);
     if (nine && bf16io) {
@@ -1788,29 +1714,6 @@ static int conv_wgrad_impl(const favae_conv_desc* d_in, const float* x, const fl
         else FAVAE_LAUNCH_NINE(2);
 #undef FAVAE_LAUNCH_NINE
 #undef FAVAE_LAUNCH_NINE_M
-    } else if (row3) {
-        // three taps per workgroup: grid.x = tiles * 3 filter rows; split-K sized for the smaller grid
-        const int tiles3 = a.tiles_co * a.tiles_ci * 3;
-        a.splitk = row3_splitk(d, tiles3, a.splitk, &chunk);
-        a.chunk = chunk;
-        const dim3 g3(tiles3, a.splitk);
-#define FAVAE_LAUNCH_ROW3(X)                                                                              \
-    do {                                                                                                  \
-        if (np == 2) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<X, 2>), g3, dim3(512), 0, s, a);       \
-        else if (np == 1) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<X, 1>), g3, dim3(512), 0, s, a);  \
-        else if (np == 4) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<X, 4>), g3, dim3(512), 0, s, a);  \
-        else FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<X, 3>), g3, dim3(512), 0, s, a);               \
-    } while (0)
-        const int pre = np == 2 ? ((dy_planes ? 1 : 0) | (x_planes ? 2 : 0)) : 0;
-        if (pre == 3) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<0, 2, 3>), g3, dim3(512), 0, s, a);
-        else if (pre == 2) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<0, 2, 2>), g3, dim3(512), 0, s, a);
-        else if (pre == 1 && xf == 0) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<0, 2, 1>), g3, dim3(512), 0, s, a);
-        else if (pre == 1 && xf == 1) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<1, 2, 1>), g3, dim3(512), 0, s, a);
-        else if (pre == 1) FAVAE_KLAUNCH((conv_wgrad_row3_sp_kernel<2, 2, 1>), g3, dim3(512), 0, s, a);
-        else if (xf == 0) FAVAE_LAUNCH_ROW3(0);
-        else if (xf == 1) FAVAE_LAUNCH_ROW3(1);
-        else FAVAE_LAUNCH_ROW3(2);
-#undef FAVAE_LAUNCH_ROW3
     } else if (buf_ok && use_b6() && bco == 128 && bci == 128) {
 #define FAVAE_LAUNCH_WSP(X, U)                                                                            \
     do {                                                                                                  \

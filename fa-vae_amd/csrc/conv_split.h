@@ -14,7 +14,7 @@
 //   2^-17 of the maximum keep full relative precision.  The accumulator is un-scaled in the epilogue (exact, powers of two).
 //
 // Kernels: conv_fwd_sp_kernel (implicit GEMM, any gather), conv3x3_halo_sp_kernel (3x3 s1, input halo staged once per
-// K chunk), conv_wgrad_sp_kernel (per tap), conv_wgrad_row3_sp_kernel (one filter row per workgroup); split_w*_kernel
+// K chunk), conv_wgrad_sp_kernel (per tap), conv_wgrad_nine_sp_kernel (all nine taps of a 3x3 conv per workgroup); split_w*_kernel
 // pre-split the weights once per call into per-4-float records.
 #pragma once
 
@@ -408,17 +408,16 @@ __global__ __launch_bounds__(256) void split_w_kernel(const float4* __restrict__
 // Per-thread global offsets are constants of the launch: only the scalar offsets advance (K chunk, tap).
 // Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, H % 8 == 0, W % 16 == 0, Cin % 16 == 0, pre-split weights.
 // ---------------------------------------------------------------------------------------------------------------
-// PL: also store the staged operand planes (ConvArgs::planes_out).  GB: GroupNorm-backward partial sums in the epilogue (gb_*)
+// GB: GroupNorm-backward partial sums in the epilogue (gb_*)
 // SE: per-tile (sum y, sum y^2) of the output in the epilogue (gs_part): pass 1 of the GroupNorm that consumes this conv's output
 // AT (round 6): storage type of the activation tensors x, resid, y (and the GroupNorm input of the GB epilogue) -- float, or bf16_t
 // (common.h: bf16 activation storage, scheme 4 only): a thread's four channels are one 8-byte access, an epilogue lane's channel 2 bytes.
-template <int XFORM, int SCH, int KS = 3, bool PL = false, bool GB = false, bool SE = false, typename AT = float>
+template <int XFORM, int SCH, int KS = 3, bool GB = false, bool SE = false, typename AT = float>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 6 : 4, 8))) void conv3x3_halo_sp_kernel(ConvArgs a) {
-    static_assert(sizeof(AT) == 4 || (SCH == 4 && !PL), "bf16 activation storage: the one-bf16-plane scheme");
+    static_assert(sizeof(AT) == 4 || SCH == 4, "bf16 activation storage: the one-bf16-plane scheme");
     constexpr unsigned EB = ActT<AT>::B;
-    static_assert(!PL || (SCH == 2 && KS == 3), "operand planes: dense 3x3 conv with two fp16 planes");
-    static_assert(!GB || (XFORM == 0 && KS == 3 && !PL), "GroupNorm-backward sums: plain dense 3x3 data gradient");
-    static_assert(!SE || (KS == 3 && !PL && !GB && SCH != 3), "output statistics: dense 3x3 forward conv, one or two planes");
+    static_assert(!GB || (XFORM == 0 && KS == 3), "GroupNorm-backward sums: plain dense 3x3 data gradient");
+    static_assert(!SE || (KS == 3 && !GB && SCH != 3), "output statistics: dense 3x3 forward conv, one or two planes");
     static_assert(!GB || SCH != 3, "GroupNorm-backward sums: one or two planes");
     using S = sp::Scheme<SCH>;
     constexpr int NP = S::NPL;                 // operand planes of the scheme
@@ -451,16 +450,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 
     const auto rw = make_rsrc(a.w, a.w_bytes);
     const auto rsc_d = make_rsrc(XFORM ? a.scale : a.x, XFORM ? a.aff_bytes : 0u);
     const auto rsh_d = make_rsrc(XFORM ? a.shift : a.x, XFORM ? a.aff_bytes : 0u);
-    const auto rpl = make_rsrc(PL ? a.planes_out : (const void*)a.x, (PL && tn == 0) ? a.planes_bytes : 0u);
 
     // halo staging slots of this thread (720 float4 over 512 threads): constant offsets.  The fused-transform operands
     // (scale, shift) depend on (image, channel quad) only: one load per K chunk serves both slots; padding pixels must
     // stay exactly zero after the transform, so they are masked with a select instead of zeroed operands.
     unsigned vh[2];
     int hoff[2];
-    bool hok[2], hin[2];
-    // planes_out (dense 3x3 convs, two planes): the workgroups of output-channel tile 0 store the interior pixels of their halo
-    const bool wr_planes = PL;
+    bool hok[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i = tid + 512 * j;
@@ -468,7 +464,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 
         const int hy = hrow / HW, hx = hrow - hy * HW;
         hoff[j] = hy * HPITCH + hx * S::ROWB;
         const int y = ty0 - a.pad + hy, x = tx0 - a.pad_w + hx;
-        hin[j] = wr_planes && hrow < HROWS && hy >= a.pad && hy < a.pad + TH && hx >= a.pad_w && hx < a.pad_w + TW;
         hok[j] = hrow < HROWS && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
         vh[j] = hok[j] ? (unsigned)(((n * a.in_img + y * a.in_step * a.in_row + x * a.in_step + a.in_off) * a.Cin + q4 * 4) * EB) : FAVAE_OOB;
     }
@@ -499,24 +494,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 
             if (XFORM && !hok[j]) t = make_float4(0.f, 0.f, 0.f, 0.f);
             S::split4(t, Sa, p);
             sp::store_planes<NP>(Hs + buf * HALO_B + hoff[j] + q4 * 8, 32, p);
-        }
-    };
-    // planes_out: the staged planes of chunk kc are read back from the LDS halo (where they sit in final form) and stored to HBM
-    // while few registers are live (tap 1 of the chunk), instead of from store_halo, whose operands are the kernel's register peak.
-    // The record of (pixel, channel quad) goes to the byte offset of the fp32 quad it was made from; non-interior slots (and every
-    // slot when no planes were asked for: zero-sized resource) are dropped by the buffer range check.
-    auto flush_planes = [&](int buf, int kc) {
-        if constexpr (PL) {
-            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (j == 1 && tid >= HROWS * 4 - 512) continue;
-                const unsigned char* src = Hs + buf * HALO_B + hoff[j] + q4 * 8;
-                const uint2 p0 = *reinterpret_cast<const uint2*>(src), p1 = *reinterpret_cast<const uint2*>(src + 32);
-                const u32x4_t rec = {p0.x, p0.y, p1.x, p1.y};
-                __builtin_amdgcn_raw_buffer_store_b128(rec, rpl, hin[j] ? vh[j] : FAVAE_OOB, (unsigned)(kc * 64), 0);
-                asm volatile("s_nop 0" ::: "memory");      // store-data hazard with an SGPR soffset: see common.h bstore
-            }
         }
     };
     auto load_b = [&](int kc, int tap) { sp::load_wrec<NP>(rw, vb, (unsigned)((tap * a.Cin + kc * 16) / 4 * S::WREC), rbp); };
@@ -550,7 +527,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 
             if (!last_tap) load_b(kc, tap + 1);
             else if (more_kc) load_b(kc + 1, 0);
             if (tap == TAPS / 2 && more_kc) load_halo(kc + 1);           // in flight over the second half of the taps
-            if (PL && tap == 1) flush_planes(hb, kc);
             const int kh = tap / KS, kw = tap - kh * KS;
             const unsigned char* Ab = Afr + hb * HALO_B + kh * HPITCH + kw * S::ROWB;
             const unsigned char* Bb = Bfr + cur * BT_B;
@@ -665,161 +641,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// 3x3 weight gradient, three taps per workgroup: a workgroup owns (128 co x 128 ci, one filter ROW kh) and accumulates the
-// taps kw = 0,1,2 together.  Per 16-pixel step it stages ONE dy tile (16 px) and ONE 18-pixel input halo row, which serve
-// the three taps as shifted pixel windows of the transposing fragment reads -- 2.8x fewer loads / transforms / splits /
-// LDS stores per MFMA than the tap-per-workgroup conv_wgrad_sp_kernel.  8 waves (4 co x 2 ci, 32 x 64 each, 3 taps).
-// Preconditions: KH = KW = 3, stride 1, pad 1, plain gather, Wout % 16 == 0, channels % 4 == 0, operands < 2 GiB.
-// ---------------------------------------------------------------------------------------------------------------
-template <int XFORM, int SCH, int PRE = 0>
-__global__ __launch_bounds__(512) void conv_wgrad_row3_sp_kernel(WgradArgs a) {
-    using S = sp::Scheme<SCH>;
-    constexpr int NP = S::NPL;                 // operand planes of the scheme
-    constexpr int OPL = 16 * sp::RSB, IPL = 18 * sp::RSB;           // bytes per plane (dy: 16 px, x: 18 px)
-    constexpr int OB = NP * OPL, IB = NP * IPL;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (OB + IB)];
-    unsigned char* Os = lds;
-    unsigned char* Is = lds + 2 * OB;
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wo = wid >> 1, wi = wid & 1;
-    int t = blockIdx.x;
-    const int kh = t % 3; t /= 3;
-    const int ci0 = (t % a.tiles_ci) * 128;
-    const int co0 = (t / a.tiles_ci) * 128;
-    const int z = blockIdx.y;
-    const int p_begin = z * a.chunk;
-    const int p_end = min(a.M, p_begin + a.chunk);
-    const int T = (p_end > p_begin) ? (p_end - p_begin + 15) / 16 : 0;
-    const float So = S::SCALED ? sp::pow2_scale(a.dy_amax) : 1.f, Si = S::SCALED ? sp::pow2_scale(a.x_amax) : 1.f;
-
-    // PRE bit 0: dy arrives as pre-split plane records (WgradArgs::dy_planes), bit 1: the transformed x does (x_planes) --
-    // records sit at the byte offsets of the fp32 quads, so the addressing is unchanged and out-of-range reads are zero planes
-    const auto rx = make_rsrc((PRE & 2) ? (const float*)a.x_planes : a.x, a.x_bytes);
-    const auto rdy = make_rsrc((PRE & 1) ? (const float*)a.dy_planes : a.dy, (unsigned)p_end * (unsigned)a.Cout * 4u);
-    const auto rsc_d = make_rsrc(XFORM ? a.scale : a.x, XFORM ? a.aff_bytes : 0u);
-    const auto rsh_d = make_rsrc(XFORM ? a.shift : a.x, XFORM ? a.aff_bytes : 0u);
-
-    const int spx = tid >> 5, sq = (tid & 31) * 4;                  // staging slot: pixel (0..15), channel
-    const bool two = tid < 64;                                      // second x slot: halo pixels 16, 17
-    const unsigned voo = (co0 + sq < a.Cout) ? (unsigned)((spx * a.Cout + co0 + sq) * 4) : FAVAE_OOB;
-    const bool ci_ok = ci0 + sq < a.Cin;
-    const unsigned vsc = (unsigned)((ci0 + sq) * 4);
-
-    int s_n, s_oh, s_ow;
-    {
-        const int hw = a.Hout * a.Wout;
-        const int mb = min(p_begin, a.M - 1);
-        s_n = mb / hw;
-        const int r = mb - s_n * hw;
-        s_oh = r / a.Wout;
-        s_ow = r - s_oh * a.Wout;
-    }
-    int ld_pb = p_begin;
-
-    float4 ro, ri[2], rsc[2], rsh[2];
-    auto load_tiles = [&]() {
-        ro = bload(rdy, voo, (unsigned)ld_pb * (unsigned)a.Cout * 4u);
-        const int ih = s_oh + kh - 1;
-        const bool row_ok = (unsigned)ih < (unsigned)a.Hin;
-        const unsigned sx = row_ok ? (unsigned)(((s_n * a.Hin + ih) * a.Win) * a.Cin) * 4u : 0u;
-        const unsigned ss = (unsigned)(s_n * a.aff_stride) * 4u;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (j == 1 && !two) continue;
-            const int iw = s_ow - 1 + spx + 16 * j;
-            const bool ok = row_ok && ci_ok && (unsigned)iw < (unsigned)a.Win;
-            ri[j] = bload(rx, ok ? (unsigned)((iw * a.Cin + ci0 + sq) * 4) : FAVAE_OOB, sx);
-            if (XFORM) {
-                rsc[j] = bload(rsc_d, ok ? vsc : FAVAE_OOB, ss);
-                rsh[j] = bload(rsh_d, ok ? vsc : FAVAE_OOB, ss);
-            }
-        }
-        ld_pb += 16;
-        s_ow += 16;
-        if (s_ow >= a.Wout) {
-            s_ow = 0;
-            if (++s_oh >= a.Hout) { s_oh = 0; ++s_n; }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-        uint2 p[NP];
-        if constexpr ((PRE & 1) && SCH == 2) {     // {hi[4], lo[4]} record -> the two planes
-            p[0] = make_uint2(__float_as_uint(ro.x), __float_as_uint(ro.y));
-            p[1] = make_uint2(__float_as_uint(ro.z), __float_as_uint(ro.w));
-        } else S::split4(ro, So, p);
-        sp::store_planes<NP>(Os + buf * OB + spx * sp::RSB + sq * 2, OPL, p);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (j == 1 && !two) continue;
-            if constexpr ((PRE & 2) && SCH == 2) {
-                p[0] = make_uint2(__float_as_uint(ri[j].x), __float_as_uint(ri[j].y));
-                p[1] = make_uint2(__float_as_uint(ri[j].z), __float_as_uint(ri[j].w));
-            } else S::split4(xform4_t<XFORM>(ri[j], rsc[j], rsh[j], a.act), Si, p);
-            sp::store_planes<NP>(Is + buf * IB + (spx + 16 * j) * sp::RSB + sq * 2, IPL, p);
-        }
-    };
-
-    f32x16 acc[3][2];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[k][j][r] = 0.f;
-
-    const int s16 = lane & 15, g = lane >> 4;
-    const int frag_off = (8 * (g >> 1) + (s16 >> 2)) * sp::RSB + (16 * (g & 1) + 4 * (s16 & 3)) * 2;
-    const unsigned char* Ofr = Os + frag_off + wo * 32 * 2;
-    const unsigned char* Ifr = Is + frag_off + wi * 64 * 2;
-
-    if (T > 0) {
-        load_tiles();
-        store_tiles(0);
-    }
-    __syncthreads();
-    for (int it = 0; it < T; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < T) load_tiles();
-        bf16x8_t af[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) af[p] = sp::tr_frag(Ofr + cur * OB + p * OPL);
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bf16x8_t bf[NP];
-#pragma unroll
-                for (int p = 0; p < NP; ++p) bf[p] = sp::tr_frag(Ifr + cur * IB + p * IPL + kw * sp::RSB + j * 64);
-                S::mma(af, bf, acc[kw][j]);
-            }
-        if (it + 1 < T) store_tiles(cur ^ 1);
-        __syncthreads();
-    }
-    float un_o = 1.f, un_i = 1.f;
-    if constexpr (S::SCALED) { un_o = sp::pow2_inv(So); un_i = sp::pow2_inv(Si); }
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ci = ci0 + wi * 64 + j * 32 + (lane & 31);
-            if (ci >= a.Cin) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float v = acc[kw][j][r];
-                if constexpr (S::SCALED) v = v * un_o * un_i;
-                if (co < a.Cout) a.part[(((size_t)z * a.Cout + co) * 9 + kh * 3 + kw) * a.Cin + ci] = v;
-            }
-        }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // 3x3 weight gradient, ALL NINE taps per workgroup, every operand element loaded / transformed / split ONCE (round 3).
 // A workgroup owns (128 co x 64 ci x 9 taps) and walks DOWN 16-pixel-wide column strips of the images: per step it stages one
 // 16-pixel row segment of dy and one 18-pixel (halo) row segment of x; the x rows live in a 4-slot LDS ring, so the three filter
 // rows kh = 0,1,2 of step h read the ring slots of rows h-1, h, h+1 and every x row is fetched from HBM / L2 once instead of by
-// three filter-row workgroups (conv_wgrad_row3_sp_kernel: 3.5x the algorithmic traffic, and GroupNorm+SiLU + plane split of every
+// three filter-row workgroups (the round-1 row kernel, removed in round 6: 3.5x the algorithmic traffic, and GroupNorm+SiLU + plane split of every
 // x element three times).  27 MFMA product blocks (x planes products) per wave and step against one dy float4 and 0.56 x
 // float4 staged per thread: 2.75x less vector-ALU work per MFMA than the row3 kernel.
 // 8 waves = 4 (co) x 2 (ci), each 32 co x 32 ci x 9 taps = 144 accumulator registers.

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void u8_norm_kernel(const unsigned char* __res
 
 }  // namespace
 
-extern "C" int favae_abi_version(void) { return 21; }
+extern "C" int favae_abi_version(void) { return 22; }
 
 // ---- bf16 activation storage: conversion passes at the boundaries of the kernels that have no bf16 instantiation (round 6) ---------
 namespace {

@@ -33,7 +33,7 @@ HW_QUEUES_AT_INIT = None if torch.cuda.is_initialized() else _parse_queues(os.en
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FAVAE_HIP_LIB") or os.path.join(_HERE, "libfavae_hip.so")     # FAVAE_HIP_LIB: same-box A/B of two builds
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 GATHER_PLAIN, GATHER_UPSAMPLE2, GATHER_DILATE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_LEAKY02, ACT_RELU = 0, 1, 2, 3
@@ -141,10 +141,6 @@ SIGNATURES = {
     "favae_conv_dgrad_gnbwd": (c_int, [POINTER(ConvDesc), _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _S]),
     "favae_gn_act_bwd_tiles": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P,
                                        c_size_t, _S]),
-    "favae_conv_planes_ok": (c_int, [POINTER(ConvDesc), c_int]),
-    "favae_conv_wgrad_takes_planes": (c_int, [POINTER(ConvDesc)]),
-    "favae_conv_fwd_split_planes": (c_int, [POINTER(ConvDesc), _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _S]),
-    "favae_conv_wgrad_planes": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _S]),
     "favae_gn_bwd_colsum_blocks": (c_int, [c_int, c_int64, c_int]),
     "favae_gn_act_bwd_colsum": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P,
                                         c_size_t, _P, _P, _S]),

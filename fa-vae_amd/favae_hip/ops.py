@@ -797,15 +797,6 @@ class ConvCfg:
         return Ho, Wo
 
 
-# FAVAE_WGRAD_PLANES=1: the forward / data-gradient 3x3 convs store their staged operands as pre-split fp16 planes and the
-# weight-gradient kernel loads them without any transform / split arithmetic (include/favae_hip.h, favae_conv_*_planes).  Same
-# bits, weight-gradient kernel alone 284 -> 352 TFLOP/s -- but OFF by default: in the training step the weight gradients are
-# already hidden on the second stream, while the plane stores cost the un-overlapped forward kernel 8 % (same-box A/B, batch 32:
-# 180.8 ms/step off, 182.5 on).  A conv that stores planes does not also run the GroupNorm epilogue variants
-# (statistics of its output / backward sums), so with those in place the gap is larger: 175.7 off, 187.8 on.
-_PLANES = os.environ.get("FAVAE_WGRAD_PLANES", "0") == "1"
-
-
 # GroupNorm-backward pass 1 (two tensor reads per GroupNorm) inside the epilogue of the data-gradient conv (A/B switch)
 _GNBWD_FUSE = os.environ.get("FAVAE_GNBWD_FUSE", "1") != "0"
 # Bias gradient + operand range of dy as by-products of the GroupNorm-backward apply pass that WRITES dy (A/B switch).  They ride on
@@ -878,7 +869,7 @@ def _wino_records(w, co, ci, flip, w_amax):
     return wsp
 
 
-def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=None, planes_out=None, gnbwd=None, stats_out=None,
+def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=None, gnbwd=None, stats_out=None,
                  y_amax=None, wino_rec=None, bf16io=False):
     """conv forward / data gradient.  When the library runs this shape on the split-precision matrix path the weights are
     pre-split once per call (instead of once per tile in the K loop); the fp16 scheme (2 planes) also needs the operand
@@ -888,7 +879,7 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
     Returns the device float holding max|w| when pre-split records were made (fp16 scheme), else None."""
     planes = query("favae_conv_wants_split_weights", byref(d), 0 if scale is None else 1)
     w_amax = None
-    if (planes in (1, 2, 4) and planes_out is None and _wino1_wanted(planes, flip_of is not None or gnbwd is not None, d.act)
+    if (planes in (1, 2, 4) and _wino1_wanted(planes, flip_of is not None or gnbwd is not None, d.act)
             and query("favae_conv_wino_ok", byref(d), 0 if scale is None else 1)):
         # dense 3x3 conv of the h3 scheme (and, where Cout % 128 == 0, of the one-plane 16-bit modes h1 / b1): Winograd F(2x2, 3x3) kernel,
         # records = G g G^T in fragment order (csrc/conv_wino.h); h1 reads the head plane of the h3 records, b1 has bf16 ones (flip | 4)
@@ -945,9 +936,6 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
             gx, gmean, grstd, ggw, ggb, ggroups, gact, gws = gnbwd
             call("favae_conv_dgrad_gnbwd", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(y), ptr(gx), ptr(gmean), ptr(grstd),
                  ptr(ggw), ptr(ggb), ggroups, gact, ptr(gws), gws.numel())
-        elif planes_out is not None:
-            call("favae_conv_fwd_split_planes", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
-                 ptr(shift), ptr(y), ptr(planes_out))
         elif stats_out is not None:          # forward + per-tile statistics of the output (pass 1 of the next GroupNorm) + max|y|
             call("favae_conv_fwd_split_stats", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
                  ptr(shift), ptr(y), ptr(stats_out), stats_out.numel() * 8, ptr(y_amax))
@@ -955,8 +943,8 @@ def _conv_launch(d, x, w_ohwi, b, resid, scale, shift, y, x_bound=None, flip_of=
             call("favae_conv_fwd_split", byref(d), ptr(x), ptr(wsp), planes, ptr(x_bound), ptr(b), ptr(resid), ptr(scale),
                  ptr(shift), ptr(y))
     else:
-        if planes_out is not None or gnbwd is not None or stats_out is not None:
-            raise RuntimeError("pre-split planes / fused GroupNorm sums need the split matrix path")
+        if gnbwd is not None or stats_out is not None:
+            raise RuntimeError("fused GroupNorm sums need the split matrix path")
         if w_ohwi is None:
             w_ohwi = _flipped(flip_of)
         call("favae_conv_fwd", byref(d), ptr(x), ptr(w_ohwi), ptr(b), ptr(resid), ptr(scale), ptr(shift), ptr(y))
@@ -1035,23 +1023,17 @@ class FusedConvFn(torch.autograd.Function):
                            per_image)
         if xb is None and query("favae_conv_wants_split_weights", byref(d), 0) in (1, 2):
             xb = absmax(x)
-        # T(x) as the two scaled fp16 planes the weight gradient needs, stored by the forward kernel as a by-product (saved for
-        # backward next to x: +4 bytes per input element, which 288 GB of HBM have room for)
-        xs = None
-        if (_PLANES and ctx.needs_input_grad[1] and query("favae_conv_planes_ok", byref(d), 0 if scale is None else 1)
-                and query("favae_conv_wgrad_takes_planes", byref(d))):
-            xs = torch.empty((N, Hin, Win, Cin), dtype=torch.float32, device=dev)
         # per-tile (sum y, sum y^2) of the output for the GroupNorm that will consume it (almost every 3x3 conv feeds one)
         st_tiles = 0
         st_part = None
-        if _GNSTATS_FUSE and xs is None:
+        if _GNSTATS_FUSE:
             # the tile grid is the kernel's: F(4x4) records (decoder forward under FAVAE_WINO4=2) have their own
             st_tiles = query("favae_conv_stats_tiles", byref(d), 0 if scale is None else 1,
                              PLANES_WINO4 if _wino4_wanted(d, scale is not None, False) else 0)
             if st_tiles:
                 st_part = torch.empty((N * st_tiles * Cout * 2,), dtype=torch.float64, device=dev)
         y_amax = _max_target(dev) if st_part is not None else None
-        w_amax = _conv_launch(d, x, wk, b, resid, scale, shift, y, xb, planes_out=xs, stats_out=st_part, y_amax=y_amax, bf16io=st)
+        w_amax = _conv_launch(d, x, wk, b, resid, scale, shift, y, xb, stats_out=st_part, y_amax=y_amax, bf16io=st)
         if st_part is not None:
             y._favae_gnstats = (st_part, st_tiles, y._version)
             y._favae_amax = (y_amax, y._version, _ARENA["epoch"])
@@ -1079,14 +1061,14 @@ class FusedConvFn(torch.autograd.Function):
         ctx.has_res = resid is not None
         ctx.w_dim = w.dim()
         ctx.params = (w, b, gn_w, gn_b)           # to reach pre-assigned flat-buffer gradients (see _direct_grad)
-        ctx.save_for_backward(x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb, w_amax, xs)
+        ctx.save_for_backward(x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb, w_amax)
         if pass_input:
             return y, x
         return y
 
     @staticmethod
     def backward(ctx, dy, dskip=None):
-        x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb, w_amax, xs = ctx.saved_tensors
+        x, wk, gn_w, gn_b, mean, rstd, scale, shift, xb, w_amax = ctx.saved_tensors
         _check_arena_epoch(ctx, xb)
         st = ctx.st                               # bf16 activation storage: dy, da, dskip, dx are bf16 tensors like x
         adt = torch.bfloat16 if st else torch.float32
@@ -1115,15 +1097,12 @@ class FusedConvFn(torch.autograd.Function):
         # bias gradient + range of dy for the fp16 split scheme: by-products of the pass that wrote dy, else one pass over dy
         want_range = xb is not None and _fp16_planes()
         db, dyb = _bias_grad_and_range(dy, p_b, need_b, want_range, N * Ho * Wo, Cout, dev)
-        # The weight gradient runs AFTER this conv's data gradient: the data-gradient kernel stores dy as pre-split planes on its
-        # way (dys), the forward kernel stored T(x) (xs), and the weight-gradient kernel then loads both without any arithmetic.
+        # The weight gradient is launched AFTER this conv's data gradient (see run_wgrad below)
         run_wgrad = None
-        use_planes = False
         if need_w:
             d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad, gather, act, ctx.per_image)
             ws = workspace(query("favae_conv_wgrad_workspace", byref(d)), dev)
             tgt = _direct_grad(p_w)
-            use_planes = _PLANES and bool(query("favae_conv_wgrad_takes_planes", byref(d)))
             dwk = None
             if tgt is None:
                 dwk = torch.empty((Cout, cfg.kh, cfg.kw, Cin), dtype=torch.float32, device=dev)
@@ -1135,17 +1114,14 @@ class FusedConvFn(torch.autograd.Function):
             wws, wtgt = ws, (tgt if tgt is not None else dwk)
             acc = 1 if tgt is not None else 0
 
-            defer = _DEFER_REDUCE and tgt is not None and _SIDE["on"] and not use_planes
+            defer = _DEFER_REDUCE and tgt is not None and _SIDE["on"]
 
-            def launch_wgrad(dys):
+            def launch_wgrad():
                 if defer:                                     # slabs stay in the workspace until flush_reductions()
                     slabs = ctypes.c_int(0)
                     call("favae_conv_wgrad_slabs", byref(wd), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(wws),
                          wws.numel(), byref(slabs))
                     _defer_reduction(wws, wtgt, Cout * cfg.kh * cfg.kw * Cin, slabs.value, acc)
-                elif use_planes and (xs is not None or dys is not None):
-                    call("favae_conv_wgrad_planes", byref(wd), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(xs),
-                         ptr(dys), ptr(wtgt), acc, ptr(wws), wws.numel())
                 else:
                     call("favae_conv_wgrad", byref(wd), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(wtgt), acc,
                          ptr(wws), wws.numel())
@@ -1154,8 +1130,8 @@ class FusedConvFn(torch.autograd.Function):
                 # launched AFTER this conv's data gradient (below): the side stream then starts it next to the HBM-bound
                 # GroupNorm-backward / bias-gradient kernels that follow instead of next to the other matrix-bound kernel
                 # (measured: 204 -> 196 ms/step; launching it before the data gradient only gave 208 -> 204)
-                def run_wgrad(dys):
-                    _side_launch(lambda: launch_wgrad(dys), (x, dy, scale, shift, xb, dyb, wws, xs, dys))
+                def run_wgrad():
+                    _side_launch(launch_wgrad, (x, dy, scale, shift, xb, dyb, wws))
             else:
                 run_wgrad = launch_wgrad
         if need_x or has_gn:
@@ -1190,15 +1166,12 @@ class FusedConvFn(torch.autograd.Function):
                 g2, pad2 = GATHER_DILATE2, cfg.kh - 1 - cfg.pad
             else:
                 raise RuntimeError("unsupported conv geometry for the data gradient")
-            dys = None
             gn_tiles, gn_ws, act_gn = 0, None, act
             if not phased:
                 da = new_cl(N, Cin, Hv, Wv, dev, adt)
                 d2 = make_conv_desc(N, Ho, Wo, Cout, Hv, Wv, Cin, cfg.kh, cfg.kw, 1, pad2, g2, ACT_NONE, 1)
-                if use_planes and query("favae_conv_planes_ok", byref(d2), 0):
-                    dys = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=dev)
                 gnb = None
-                if (_GNBWD_FUSE and has_gn and cfg.norm == "group" and not cfg.upsample and dys is None and mean is not None
+                if (_GNBWD_FUSE and has_gn and cfg.norm == "group" and not cfg.upsample and mean is not None
                         and (dyb is not None or not _fp16_planes())):
                     # the tile grid is the kernel's, and the kernel is the one the records were made for AT FORWARD TIME (ctx.wflip):
                     # a set_wino4() between forward and backward must not change the grid under the records
@@ -1211,9 +1184,9 @@ class FusedConvFn(torch.autograd.Function):
                     # experiment: the dense data gradient starts only after the weight gradient of the layer behind it has retired
                     torch.cuda.current_stream().wait_stream(_SIDE["stream"])
                 _conv_launch(d2, dy, None, None, None, None, None, da, dyb, flip_of=(wk, Cout, cfg.kh, cfg.kw, Cin, w_amax),
-                             planes_out=dys, gnbwd=gnb, wino_rec=ctx.wflip if dys is None else None, bf16io=st)
+                             gnbwd=gnb, wino_rec=ctx.wflip, bf16io=st)
             if run_wgrad is not None:
-                run_wgrad(dys)
+                run_wgrad()
                 run_wgrad = None
             if cfg.upsample:
                 dlow = new_cl(N, Cin, Hin, Win, dev)
@@ -1258,7 +1231,7 @@ class FusedConvFn(torch.autograd.Function):
             else:
                 dx = da
         if run_wgrad is not None:                             # no data gradient asked for: nothing to wait for
-            run_wgrad(None)
+            run_wgrad()
         if dskip is not None:
             dx = dskip if dx is None else dx + dskip
         dres = dy if ctx.has_res else None

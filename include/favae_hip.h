@@ -147,7 +147,8 @@ int favae_get_wino(void);              /* the current setting, no side effect */
  * FAVAE_WINO4=0 in the environment (favae_set_wino4(0)) makes favae_conv_wino4_ok return 0 for every shape. */
 #define FAVAE_PLANES_WINO4 0x200
 /* bf16 activation STORAGE (ABI 21): with this flag on `planes` (scheme 4 = b1 only) favae_conv_fwd_split / _stats / favae_conv_dgrad_gnbwd /
- * favae_conv_wgrad_planes take x, resid (and the GroupNorm input of the data-gradient epilogue, and dy of the weight gradient) and write
+ * favae_conv_wgrad(_slabs) (flag on the descriptor's `act` there) take x, resid (and the GroupNorm input of the data-gradient epilogue,
+ * and dy of the weight gradient) and write
  * y as bf16 tensors: the same element counts at two bytes each, rounded to nearest even on store, widened exactly on load; products,
  * accumulation, statistics and partial sums stay fp32 / fp64.  favae_conv_bf16io_ok(d, has_affine, kind) says whether the kernel that
  * would run `d` has the bf16 instantiation (kind 0 forward, 1 data gradient with the GroupNorm-backward epilogue, 2 weight gradient);
@@ -503,28 +504,6 @@ int favae_gn_act_bwd_tiles(const float* da, const float* x, const float* gamma, 
                            const float* rstd, int N, int64_t HW, int C, int G, int act, const float* dx_add, float* dx,
                            float* dgamma, float* dbeta, int accumulate, int tiles, void* ws, size_t ws_bytes,
                            favae_stream_t stream);
-
-/* ------------------------------------------------------------------------------------------------------------
- * Pre-split operand planes for the weight gradient (no reference counterpart: the reference's autograd re-reads fp32 tensors).
- * In the default arithmetic the weight-gradient kernel of a 3x3 conv spends a third of its time turning its two fp32 operands into
- * scaled fp16 planes (and re-applying GroupNorm+SiLU to x).  The kernels that ALREADY stage exactly these values -- the forward conv
- * (T(x)) and the data-gradient conv (dy) -- can store them as a by-product: one 16-byte record {hi[4 fp16], lo[4 fp16]} per four
- * channels, at the byte offset of the fp32 quad, i.e. a buffer of the tensor's own size.  Values are bit-identical to what the
- * weight-gradient kernel would compute itself, so results do not change.
- *   favae_conv_planes_ok(d, has_affine)   1 when favae_conv_fwd_split(d, ...) runs the kernel that can store planes
- *   favae_conv_wgrad_takes_planes(d)      1 when the weight gradient of d runs the kernel that can load them
- *   favae_conv_fwd_split_planes           favae_conv_fwd_split + planes_out (N*Hin*Win*Cin*4 bytes, 16-byte aligned; may be NULL)
- *   favae_conv_wgrad_planes               favae_conv_wgrad + x_planes / dy_planes (either may be NULL: that operand is then split
- *                                         on the fly from the fp32 tensor, which must always be passed)
- * ---------------------------------------------------------------------------------------------------------- */
-int favae_conv_planes_ok(const favae_conv_desc* d, int has_affine);
-int favae_conv_wgrad_takes_planes(const favae_conv_desc* d);
-int favae_conv_fwd_split_planes(const favae_conv_desc* d, const float* x, const void* wsplit, int planes, const float* x_absmax,
-                                const float* bias, const float* resid, const float* scale, const float* shift, float* y,
-                                void* planes_out, favae_stream_t stream);
-int favae_conv_wgrad_planes(const favae_conv_desc* d, const float* x, const float* dy, const float* scale, const float* shift,
-                            const float* x_absmax, const float* dy_absmax, const void* x_planes, const void* dy_planes, float* dw,
-                            int accumulate, void* ws, size_t ws_bytes, favae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Launch profiler (measurement only; no reference counterpart -- the reference is timed from outside by its caller).

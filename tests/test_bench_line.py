@@ -14,7 +14,7 @@ def _rec(n, us, gflop, gb):
 
 
 def test_compact_roofline_is_small_and_numeric():
-    name = "conv_wgrad_row3_sp_kernel<2, 2, 0>"
+    name = "conv_wgrad_nine_sp_kernel<2, 2, 128, false, 1, float>"
     r = _rec(268, 927.4123, 177.41, 0.534)
     full = bench.roofline_entry(name, r, 4 * 174000.0, {name: {"hbm_bytes_per_launch_corrected": 1.873e9}}, {name: _rec(134, 672.0, 177.41, 0.534)})
     c = bench.compact_roofline(full)

@@ -359,12 +359,12 @@ def test_side_stream_weight_gradients_are_race_free(mtag, hw):
     from favae_step import TrainStep
     x = O.det_input(2, hw, hw, 31).to(DEV)
 
-    def grads(side_on, delay, planes=False, fuse=True):
+    def grads(side_on, delay, fuse=True):
         model, _, _ = build(mtag)
         ts = TrainStep(model, lr=1e-4)
         model.train()
-        prev = K._SIDE["on"], K._SIDE["delay"], K._PLANES, K._GNBWD_FUSE
-        K._SIDE["on"], K._SIDE["delay"], K._PLANES, K._GNBWD_FUSE = side_on, delay, planes, fuse
+        prev = K._SIDE["on"], K._SIDE["delay"], K._GNBWD_FUSE
+        K._SIDE["on"], K._SIDE["delay"], K._GNBWD_FUSE = side_on, delay, fuse
         try:
             ts.gflat.zero_()
             out = ts.losses(x)
@@ -372,34 +372,25 @@ def test_side_stream_weight_gradients_are_race_free(mtag, hw):
             K.sync_side_stream()
             torch.cuda.synchronize()
         finally:
-            K._SIDE["on"], K._SIDE["delay"], K._PLANES, K._GNBWD_FUSE = prev
+            K._SIDE["on"], K._SIDE["delay"], K._GNBWD_FUSE = prev
         assert not K._SIDE["pending"]
         return ts.gflat.clone()
     ref = grads(False, 0)
     assert torch.isfinite(ref).all() and float(ref.abs().sum()) > 0
     got = grads(True, 400000)                    # ~0.2 ms in front of each of the ~150 side-stream launches
     assert torch.equal(got, ref), "two-stream gradients differ from the single-stream run: %g" % float((got - ref).abs().max())
-    # pre-split operand planes (FAVAE_WGRAD_PLANES=1: forward / data-gradient kernels store their staged operands, the three-tap
-    # weight-gradient kernel loads them): race-free as well (bit-identical between its own two-stream and single-stream runs), and
-    # equal to the default path to rounding -- the default weight gradient is the nine-tap kernel since round 3, which sums the
-    # pixels in another order (column strips instead of image rows).  (The GroupNorm-backward sums of the data-gradient epilogue
-    # are a different summation order than the streaming pass, and a conv uses one or the other: compared with both off.)
-    # (all three on the direct kernels: the pre-split planes are a by-product of the direct LDS-halo kernel, while the default forward /
-    # data gradient is the Winograd kernel since round 3 -- another fp32-grade rounding of the forward, which in a model with a
-    # quantizer may flip a code index; the Winograd path has its own equivalence test in tests/test_gpu_ops.py)
+    # the direct (non-Winograd) kernels with the streaming GroupNorm-backward pass instead of the data-gradient epilogue: race-free as
+    # well (bit-identical between the two-stream and the single-stream run), and the two GroupNorm-backward formulations agree to rounding
     import favae_hip as H
     prev_w = H.query("favae_set_wino", 0)
     try:
         ref1 = grads(False, 0)
-        ref2 = grads(False, 0, planes=False, fuse=False)
-        ref3 = grads(False, 0, planes=True, fuse=False)
-        got = grads(True, 400000, planes=True, fuse=False)
+        ref2 = grads(False, 0, fuse=False)
+        got2 = grads(True, 400000, fuse=False)
     finally:
         H.query("favae_set_wino", prev_w)
-    assert torch.equal(got, ref3), "gradients with pre-split planes differ between one and two streams: %g" % float((got - ref3).abs().max())
+    assert torch.equal(got2, ref2), "direct-kernel gradients differ between one and two streams: %g" % float((got2 - ref2).abs().max())
     scale = float(ref2.abs().max())
-    assert float((ref3 - ref2).abs().max()) < 2e-5 * scale, float((ref3 - ref2).abs().max()) / scale
-    # and the two GroupNorm-backward formulations agree to rounding
     assert float((ref1 - ref2).abs().max()) < 2e-5 * scale, float((ref1 - ref2).abs().max()) / scale
 
 

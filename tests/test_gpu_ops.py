@@ -71,8 +71,8 @@ CONV_CASES = [
     (2, 256, 8, 8, 128, 1, 1, 0, 0, False, None, True),        # 1x1 shortcut + residual
     (1, 8, 6, 7, 8, 3, 1, 1, 1, False, 4, False),              # tiny channels, groups=4
     (3, 40, 17, 13, 200, 3, 1, 1, 1, False, 8, True),          # ragged tiles everywhere
-    # split-precision matrix path (Cin % 16 == 0, Cout > 64): LDS-halo 3x3 kernel, row3 / per-tap weight gradients
-    (2, 128, 16, 32, 128, 3, 1, 1, 1, False, 32, True),        # halo fwd (GN+SiLU) + halo dgrad + row3 wgrad + residual
+    # split-precision matrix path (Cin % 16 == 0, Cout > 64): LDS-halo 3x3 kernel, nine-tap / per-tap weight gradients
+    (2, 128, 16, 32, 128, 3, 1, 1, 1, False, 32, True),        # halo fwd (GN+SiLU) + halo dgrad + nine-tap wgrad + residual
     (1, 128, 24, 16, 256, 3, 1, 1, 1, False, None, False),     # halo, plain operand (range from favae_absmax), 2 Cout tiles
     (1, 144, 8, 16, 160, 3, 1, 1, 1, False, 16, False),        # halo with ragged channel tiles
     (2, 128, 10, 12, 128, 3, 2, 0, 1, False, None, False),     # Downsample at 128 ch: split kernel, data gradient by output parity
@@ -101,7 +101,7 @@ def test_fused_conv_fwd_bwd(K, case):
 @pytest.mark.parametrize("case", CONV_CASES[12:23], ids=[str(i) for i in range(12, 23)])
 def test_conv_mixed_precision_h1(K, case):
     """16-bit mixed-precision mode (one scaled fp16 plane, fp32 accumulation; BASELINE config 5 "bf16"): every split-path
-    kernel family (halo fwd / dgrad, row3 and per-tap wgrad, strided, phase-wise Upsample) within fp16-operand tolerance of
+    kernel family (halo fwd / dgrad, nine-tap and per-tap wgrad, strided, phase-wise Upsample) within fp16-operand tolerance of
     the fp32 reference -- and measurably different from it, i.e. the h1 kernels really ran."""
     prev = K.set_conv_mode("h1")
     try:
