@@ -55,7 +55,8 @@ def test_no_unguarded_128bit_buffer_store(unit_asm, tmp_path):
         blob = text + "".join(open(os.path.join(CSRC, h)).read() for h in incs if h != "common.h" and os.path.exists(os.path.join(CSRC, h)))
         if "bstore(" in blob or "act_store4<" in blob or "raw_buffer_store_b128(" in blob:      # act_store4<float> = bstore (common.h)
             users.append(f)
-    assert "norm.hip" in users and "conv.hip" in users
+    assert "norm.hip" in users        # (conv.hip lost its last 128-bit buffer store with the operand-plane path, round 6; still scanned below)
+    users = sorted(set(users) | {"conv.hip"})
     hits = []
     for f in users:
         hits += S.scan(unit_asm[f])
