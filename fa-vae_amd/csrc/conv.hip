@@ -135,9 +135,6 @@ struct ConvArgs {
     unsigned* gs_amax;        // optional (same variant): max |y| of the output, bit pattern, one atomicMax per workgroup (pre-zeroed)
     // conv3x3_wino_sp_kernel: floor(2^32 / d) + 1 for d = channel tiles, tile columns, tile rows (division by multiply-high)
     unsigned wino_rcp_n, wino_rcp_w, wino_rcp_h;
-#ifdef FAVAE_HALO_ABL
-    int abl;
-#endif
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -1137,20 +1134,6 @@ static int wino_part_tiles(const favae_conv_desc* d, bool has_affine, int planes
 // The tile counts above are the Winograd kernel's; the direct kernel's grid is 16 x 8 pixels, which is the Winograd grid only in the
 // wide tiling.  Where the two differ (Cout % 128 != 0, or FAVAE_WINO_WIDE=0) the direct kernel would write twice the tiles the caller
 // sized `part` for: such a call is refused (tests/test_gpu_ops.py::test_one_plane_direct_stats_call_is_refused_off_the_wide_grid).
-// Tile height of the direct 3x3 kernel in a one-plane scheme (conv_split.h, MI): 4 = 32 x 16 pixels per workgroup where that still gives
-// every CU two workgroups, 2 = 16 x 16, 1 = 8 x 16 with a filter row per barrier; FAVAE_HALO_TALL=0 -> 0 (the 8 x 16 tile, a tap per
-// barrier: rounds 1-5), 1 / 2 / 4 pins an arm (A/B).
-static int halo_tall(const favae_conv_desc* d, int tiles_n) {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FAVAE_HALO_TALL"); v = (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : 9; }
-    if (v == 0) return 0;
-    const long wg = (long)d->N * (d->Hin / 8) * (d->Win / 16) * tiles_n;       // workgroups of the 8 x 16 tiling
-    int mi = 1;
-    if (d->Hin % 32 == 0 && wg / 4 >= 512) mi = 4;
-    else if (d->Hin % 16 == 0 && wg / 2 >= 512) mi = 2;
-    if (v == 1 || v == 2 || v == 4) mi = (d->Hin % (8 * v) == 0) ? v : 1;
-    return mi;
-}
 static bool direct_grid_mismatch(const favae_conv_desc* d, int planes, bool has_affine) {
     return conv_mode() != 2 && !(planes & FAVAE_PLANES_WINO) && wino_ok(d, has_affine) && !wino_wide_ok(d, has_affine);
 }
@@ -1445,39 +1428,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
 #undef FAVAE_LAUNCH_WINO_T
     } else if (halo_ok || halo2_ok) {
         a.tiles_n = cdiv(d->Cout, 128);
-        // one-plane schemes (b1; round 6): tall tiles (8 MI x 16 pixels) and a filter row per barrier, see conv_split.h; `tall` = 0: the
-        // 8 x 16 tile with one tap per barrier (every other scheme, the 2x2 phase convs, the transforms without a tall instantiation)
-#ifdef FAVAE_HALO_ABL
-        { const char* e = getenv("FAVAE_HALO_ABL"); a.abl = e ? atoi(e) : 0; }
-#endif
-        const bool tall_variant = halo_ok && wplanes == 4 && (gb || xf == 0 || xf == 2);
-        const int tall = tall_variant ? halo_tall(d, a.tiles_n) : 0;
-        const dim3 hgrid((unsigned)(d->N * (d->Hin / (8 * (tall ? tall : 1))) * (d->Win / 16) * a.tiles_n));
-#define FAVAE_LAUNCH_HALO_DYN(X, GBV, SEV, ATT, MIV)                                                                        \
-    do {                                                                                                                    \
-        constexpr int LB = halo_lds_bytes<4, 3, MIV, 3>();                                                                  \
-        static bool attr_set = false;                                                                                       \
-        if (!attr_set) {                                                                                                    \
-            (void)hipFuncSetAttribute((const void*)conv3x3_halo_sp_kernel<X, 4, 3, GBV, SEV, ATT, MIV, 3>,                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LB);                                      \
-            attr_set = true;                                                                                                \
-        }                                                                                                                   \
-        FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 4, 3, GBV, SEV, ATT, MIV, 3>), hgrid, dim3(512), LB, s, a);               \
-    } while (0)
-#define FAVAE_LAUNCH_HALO_TALL(X, GBV, SEV, ATT)                                                                            \
-    do {                                                                                                                    \
-        if (tall == 4) FAVAE_LAUNCH_HALO_DYN(X, GBV, SEV, ATT, 4);                                                          \
-        else if (tall == 2) FAVAE_LAUNCH_HALO_DYN(X, GBV, SEV, ATT, 2);                                                     \
-        else FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 4, 3, GBV, SEV, ATT, 1, 3>), hgrid, dim3(512), 0, s, a);             \
-    } while (0)
-#define FAVAE_LAUNCH_HALO_TALL_ALL(ATT)                                                                                     \
-    do {                                                                                                                    \
-        if (gb) FAVAE_LAUNCH_HALO_TALL(0, true, false, ATT);                                                                \
-        else if (stats_part && xf == 0) FAVAE_LAUNCH_HALO_TALL(0, false, true, ATT);                                        \
-        else if (stats_part) FAVAE_LAUNCH_HALO_TALL(2, false, true, ATT);                                                   \
-        else if (xf == 0) FAVAE_LAUNCH_HALO_TALL(0, false, false, ATT);                                                     \
-        else FAVAE_LAUNCH_HALO_TALL(2, false, false, ATT);                                                                  \
-    } while (0)
+        const dim3 hgrid((unsigned)(d->N * (d->Hin / 8) * (d->Win / 16) * a.tiles_n));
 #define FAVAE_LAUNCH_HALO_K(X, KS)                                                                            \
     do {                                                                                                      \
         if (wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 2, KS>), hgrid, dim3(512), 0, s, a);  \
@@ -1489,11 +1440,6 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         if (bf16io) {                       // bf16 activation storage: the dense 3x3 kernel with the bf16 plane
             if (!(halo_ok && wplanes == 4) || (gb && (xf != 0 || bias || resid)) || (stats_part && (gb || !(xf == 0 || xf == 2))))
                 return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-            if (tall) {
-                FAVAE_LAUNCH_HALO_TALL_ALL(bf16_t);
-                FAVAE_CHECK_LAUNCH();
-                return FAVAE_OK;
-            }
 #define FAVAE_LAUNCH_HALO_BF(X, GBV, SEV) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<X, 4, 3, GBV, SEV, bf16_t>), hgrid, dim3(512), 0, s, a)
             if (gb) FAVAE_LAUNCH_HALO_BF(0, true, false);
             else if (stats_part && xf == 0) FAVAE_LAUNCH_HALO_BF(0, false, true);
@@ -1509,8 +1455,7 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         const bool fp16p = wplanes == 2 || wplanes == 1 || wplanes == 4;           // schemes with the epilogue variants
         if (gb && !(halo_ok && fp16p && xf == 0 && !bias && !resid)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
         if (stats_part && !(halo_ok && fp16p && (xf == 0 || xf == 2) && !gb)) return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
-        if (tall) FAVAE_LAUNCH_HALO_TALL_ALL(float);
-        else if (gb && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, true>), hgrid, dim3(512), 0, s, a);
+        if (gb && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, true>), hgrid, dim3(512), 0, s, a);
         else if (gb && wplanes == 4) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 4, 3, true>), hgrid, dim3(512), 0, s, a);
         else if (gb) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 1, 3, true>), hgrid, dim3(512), 0, s, a);
         else if (stats_part && xf == 0 && wplanes == 2) FAVAE_KLAUNCH((conv3x3_halo_sp_kernel<0, 2, 3, false, true>), hgrid, dim3(512), 0, s, a);
@@ -1526,9 +1471,6 @@ static int conv_fwd_impl(const favae_conv_desc* d, const float* x, const float* 
         else FAVAE_LAUNCH_HALO(3);
 #undef FAVAE_LAUNCH_HALO
 #undef FAVAE_LAUNCH_HALO_K
-#undef FAVAE_LAUNCH_HALO_TALL_ALL
-#undef FAVAE_LAUNCH_HALO_TALL
-#undef FAVAE_LAUNCH_HALO_DYN
     } else if (bf16io) {
         return favae_prof_fail_(FAVAE_ERR_UNSUPPORTED);
     } else if (buf_ok && use_b6() && bn == 128) {

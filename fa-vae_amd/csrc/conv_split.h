@@ -412,24 +412,9 @@ __global__ __launch_bounds__(256) void split_w_kernel(const float4* __restrict__
 // SE: per-tile (sum y, sum y^2) of the output in the epilogue (gs_part): pass 1 of the GroupNorm that consumes this conv's output
 // AT (round 6): storage type of the activation tensors x, resid, y (and the GroupNorm input of the GB epilogue) -- float, or bf16_t
 // (common.h: bf16 activation storage, scheme 4 only): a thread's four channels are one 8-byte access, an epilogue lane's channel 2 bytes.
-template <int SCH, int KS, int MI, int TB>
-constexpr int halo_lds_bytes() {        // LDS of conv3x3_halo_sp_kernel<., SCH, KS, ., ., ., MI, TB> (dynamic above 64 KB)
-    constexpr int HW = 16 + KS - 1, HPITCH = (HW * sp::Scheme<SCH>::ROWB + 255) / 256 * 256;
-    return 2 * (8 * MI + KS - 1) * HPITCH + 2 * TB * 128 * sp::Scheme<SCH>::ROWB;
-}
-// MI, TB (round 6, one-plane schemes): a workgroup owns 8 MI x 16 pixels (MI = 1, 2, 4: 128, 256, 512 MFMA rows; a wave 32 MI pixels x
-// 64 channels = 2 MI accumulator blocks) and passes TB taps (1, or one filter row = KS) per barrier.  With ONE product per multiply-add
-// the 32 x 64 wave tile reads 1.5 KB of fragments from LDS per MFMA (192 B per clock and CU against 128 of LDS bandwidth) and runs two
-// MFMAs per wave between barriers with the weight tile's L2 round trip inside every iteration: 20 % of the pipe.  128 x 64 per wave reads
-// 0.75 KB per MFMA, and a filter row per barrier puts 24 MFMAs per wave behind one round trip.  The partial sums of the GB / SE epilogues
-// keep the 8 x 16 grid (a wave or a group of waves is exactly one such sub-tile), so the callers' tile counts do not change.
-template <int XFORM, int SCH, int KS = 3, bool GB = false, bool SE = false, typename AT = float, int MI = 1, int TB = 1>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MI == 4 ? 2 : MI == 2 ? 2 : (SCH != 3 && TB == 1) ? 6 : 4, MI == 4 ? 2 : MI == 2 ? 4 : 8)))
-void conv3x3_halo_sp_kernel(ConvArgs a) {
+template <int XFORM, int SCH, int KS = 3, bool GB = false, bool SE = false, typename AT = float>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SCH != 3 ? 6 : 4, 8))) void conv3x3_halo_sp_kernel(ConvArgs a) {
     static_assert(sizeof(AT) == 4 || SCH == 4, "bf16 activation storage: the one-bf16-plane scheme");
-    static_assert(MI == 1 || MI == 2 || MI == 4, "8, 16 or 32 tile rows");
-    static_assert(MI == 1 || (KS == 3 && sp::Scheme<SCH>::NPL == 1), "tall tiles: the dense 3x3 conv in a one-plane scheme");
-    static_assert(TB == 1 || TB == KS, "taps per barrier: one, or one filter row");
     constexpr unsigned EB = ActT<AT>::B;
     static_assert(!GB || (XFORM == 0 && KS == 3), "GroupNorm-backward sums: plain dense 3x3 data gradient");
     static_assert(!SE || (KS == 3 && !GB && SCH != 3), "output statistics: dense 3x3 forward conv, one or two planes");
@@ -438,25 +423,18 @@ void conv3x3_halo_sp_kernel(ConvArgs a) {
     constexpr int NP = S::NPL;                 // operand planes of the scheme
     // KS = 3: the 3x3 stride-1 pad-1 conv.  KS = 2: a 2x2 phase conv of an Upsample / of the Downsample data gradient (top / left
     // padding a.pad / a.pad_w in {0, 1}, ONE side of the conv on every second pixel of a tensor of twice the size: a.in_* / a.out_*).
-    constexpr int TH = 8 * MI, TW = 16, HW = TW + KS - 1, HROWS = (TH + KS - 1) * HW, TAPS = KS * KS;   // 3x3, MI = 1: 180 halo pixels
+    constexpr int TH = 8, TW = 16, HW = TW + KS - 1, HROWS = (TH + KS - 1) * HW, TAPS = KS * KS;   // 3x3: 180 halo pixels
     // halo row pitch = 18 rows rounded up to a multiple of 256 B: pitch % 256 == 0 puts the second tile row of a wave's 32 MFMA
     // rows on the same bank phase as pixels 16..31 of a contiguous run -> the ds_read_b128 fragment reads are conflict-free
     constexpr int HPITCH = (HW * S::ROWB + 255) / 256 * 256;
     static_assert((16 * S::ROWB) % 256 == 0, "row stride must keep 16-pixel runs bank-periodic");
     constexpr int HALO_B = (TH + KS - 1) * HPITCH, BT_B = 128 * S::ROWB;
-    constexpr int LDS_B = 2 * HALO_B + 2 * TB * BT_B;
-    constexpr bool DYN = LDS_B > 64 * 1024;     // above the static limit: dynamic LDS (the launcher passes halo_lds_bytes)
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_st[DYN ? 16 : LDS_B];
-    unsigned char* lds = DYN ? lds_dyn : lds_st;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO_B + 2 * BT_B];
     unsigned char* Hs = lds;                    // [2][TH + KS - 1][HPITCH]
-    unsigned char* Bs = lds + 2 * HALO_B;       // [2][TB][128][ROWB]
+    unsigned char* Bs = lds + 2 * HALO_B;       // [2][128][ROWB]
 
-#ifdef FAVAE_HALO_ABL
-    if (a.abl & 64) return;
-#endif
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;      // 4 x 2 waves of 32 MI x 64
+    const int wm = wid >> 1, wn = wid & 1;      // 4 x 2 waves of 32 x 64
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = tile % a.tiles_n;
     int spt = tile / a.tiles_n;                 // spatial tile index
@@ -476,12 +454,11 @@ void conv3x3_halo_sp_kernel(ConvArgs a) {
     // halo staging slots of this thread (720 float4 over 512 threads): constant offsets.  The fused-transform operands
     // (scale, shift) depend on (image, channel quad) only: one load per K chunk serves both slots; padding pixels must
     // stay exactly zero after the transform, so they are masked with a select instead of zeroed operands.
-    constexpr int NSL = (HROWS * 4 + 511) / 512;            // staging slots per thread (MI = 1: 720 float4 = 2 slots, the second partial)
-    unsigned vh[NSL];
-    int hoff[NSL];
-    bool hok[NSL];
+    unsigned vh[2];
+    int hoff[2];
+    bool hok[2];
 #pragma unroll
-    for (int j = 0; j < NSL; ++j) {
+    for (int j = 0; j < 2; ++j) {
         const int i = tid + 512 * j;
         const int hrow = i >> 2;
         const int hy = hrow / HW, hx = hrow - hy * HW;
@@ -494,13 +471,13 @@ void conv3x3_halo_sp_kernel(ConvArgs a) {
     const int brow = tid >> 2;                                           // weight row (output channel) staged by this thread
     const unsigned vb = (n0 + brow < a.Cout) ? (unsigned)(((n0 + brow) * TAPS * a.Cin + q4 * 4) / 4 * S::WREC) : FAVAE_OOB;
 
-    float4 rh[NSL], rsc, rsh;
-    uint2 rbp[TB][NP];
+    float4 rh[2], rsc, rsh;
+    uint2 rbp[NP];
     auto load_halo = [&](int kc) {
         const unsigned sk = (unsigned)(kc * 64);
 #pragma unroll
-        for (int j = 0; j < NSL; ++j) {
-            if ((j + 1) * 512 > HROWS * 4 && tid >= HROWS * 4 - 512 * j) continue;   // the last slot is partial (MI = 1: 208 threads)
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1 && tid >= HROWS * 4 - 512) continue;              // second slot exists for the first 208 threads only
             rh[j] = act_load4<AT>(rx, vh[j], (unsigned)(kc * 16) * EB);
         }
         if (XFORM) {
@@ -510,8 +487,8 @@ void conv3x3_halo_sp_kernel(ConvArgs a) {
     };
     auto store_halo = [&](int buf, int kc) {
 #pragma unroll
-        for (int j = 0; j < NSL; ++j) {
-            if ((j + 1) * 512 > HROWS * 4 && tid >= HROWS * 4 - 512 * j) continue;
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1 && tid >= HROWS * 4 - 512) continue;
             uint2 p[NP];
             float4 t = xform4_t<XFORM>(rh[j], rsc, rsh, a.act);
             if (XFORM && !hok[j]) t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -519,25 +496,17 @@ void conv3x3_halo_sp_kernel(ConvArgs a) {
             sp::store_planes<NP>(Hs + buf * HALO_B + hoff[j] + q4 * 8, 32, p);
         }
     };
-    auto load_b = [&](int kc, int g) {          // the TB taps of group g
-#pragma unroll
-        for (int t = 0; t < TB; ++t) sp::load_wrec<NP>(rw, vb, (unsigned)(((g * TB + t) * a.Cin + kc * 16) / 4 * S::WREC), rbp[t]);
-    };
-    auto store_b = [&](int buf) {
-#pragma unroll
-        for (int t = 0; t < TB; ++t) sp::store_planes<NP>(Bs + (buf * TB + t) * BT_B + brow * S::ROWB + q4 * 8, 32, rbp[t]);
-    };
+    auto load_b = [&](int kc, int tap) { sp::load_wrec<NP>(rw, vb, (unsigned)((tap * a.Cin + kc * 16) / 4 * S::WREC), rbp); };
+    auto store_b = [&](int buf) { sp::store_planes<NP>(Bs + buf * BT_B + brow * S::ROWB + q4 * 8, 32, rbp); };
 
-    f32x16 acc[MI][2];
+    f32x16 acc[2];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // fragment addressing: MFMA row of block i = pixel p + 32 i = (wm MI + i) * 32 + (lane&31) of the tile -> halo row (ty+kh), column tx+kw
-    const int p = wm * MI * 32 + (lane & 31);
+    // fragment addressing: MFMA row = pixel p = wm*32 + (lane&31) of the 8x16 tile -> halo row (ty+kh), column tx+kw
+    const int p = wm * 32 + (lane & 31);
     const int fh = (lane >> 5) * 16;
     const unsigned char* Afr = Hs + (p >> 4) * HPITCH + (p & 15) * S::ROWB + fh;
     const unsigned char* Bfr = Bs + (wn * 64 + (lane & 31)) * S::ROWB + fh;
@@ -548,83 +517,34 @@ void conv3x3_halo_sp_kernel(ConvArgs a) {
     store_halo(0, 0);
     store_b(0);
     __syncthreads();
-#ifdef FAVAE_HALO_ABL
-    if (a.abl & 128) return;
-#endif
     int it = 0;
     for (int kc = 0; kc < KC; ++kc) {
         const int hb = kc & 1;
-        constexpr int NG = TAPS / TB;                                     // tap groups (barriers) per K chunk
 #pragma unroll 1
-        for (int g = 0; g < NG; ++g, ++it) {
+        for (int tap = 0; tap < TAPS; ++tap, ++it) {
             const int cur = it & 1;
-            const bool last_g = g == NG - 1, more_kc = kc + 1 < KC;
-#ifdef FAVAE_HALO_ABL
-            const int abl = a.abl;
-            if (!(abl & 16)) {
-#endif
-            if (!last_g) load_b(kc, g + 1);
+            const bool last_tap = tap == TAPS - 1, more_kc = kc + 1 < KC;
+            if (!last_tap) load_b(kc, tap + 1);
             else if (more_kc) load_b(kc + 1, 0);
-#ifdef FAVAE_HALO_ABL
-            }
-            if (!(abl & 8))
-#endif
-            if (g == NG / 2 && more_kc) load_halo(kc + 1);               // in flight over the second half of the taps
+            if (tap == TAPS / 2 && more_kc) load_halo(kc + 1);           // in flight over the second half of the taps
+            const int kh = tap / KS, kw = tap - kh * KS;
+            const unsigned char* Ab = Afr + hb * HALO_B + kh * HPITCH + kw * S::ROWB;
+            const unsigned char* Bb = Bfr + cur * BT_B;
+            bf16x8_t af[NP], bf[2][NP];
 #pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                const int tap = g * TB + t;
-                const int kh = TB == KS ? g : tap / KS, kw = TB == KS ? t : tap - kh * KS;
-                const unsigned char* Ab = Afr + hb * HALO_B + kh * HPITCH + kw * S::ROWB;
-                const unsigned char* Bb = Bfr + (cur * TB + t) * BT_B;
-                bf16x8_t af[MI][NP], bf[2][NP];
-#ifdef FAVAE_HALO_ABL
-                if (abl & 32) {
+            for (int pl = 0; pl < NP; ++pl) af[pl] = *reinterpret_cast<const bf16x8_t*>(Ab + pl * 32);
 #pragma unroll
-                    for (int i = 0; i < MI; ++i)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int pl = 0; pl < NP; ++pl)
+                for (int pl = 0; pl < NP; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8_t*>(Bb + j * 32 * S::ROWB + pl * 32);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) af[i][pl][e] = (__bf16)(float)(lane + i);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) bf[j][pl][e] = (__bf16)(float)(lane + j);
-                } else {
-#endif
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8_t*>(Ab + i * 2 * HPITCH + pl * 32);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8_t*>(Bb + j * 32 * S::ROWB + pl * 32);
-#ifdef FAVAE_HALO_ABL
-                }
-                if (!(abl & 1))
-#endif
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) S::mma(af[i], bf[j], acc[i][j]);
-            }
-#ifdef FAVAE_HALO_ABL
-            if (!(abl & 16))
-#endif
-            if (!last_g || more_kc) store_b(cur ^ 1);
-#ifdef FAVAE_HALO_ABL
-            if (!(abl & 8))
-#endif
-            if (last_g && more_kc) store_halo(hb ^ 1, kc + 1);
+            for (int j = 0; j < 2; ++j) S::mma(af, bf[j], acc[j]);
+            if (!last_tap || more_kc) store_b(cur ^ 1);
+            if (last_tap && more_kc) store_halo(hb ^ 1, kc + 1);
             __syncthreads();
         }
     }
 
-#ifdef FAVAE_HALO_ABL
-    if ((a.abl & 4) && acc[0][0][0] != 12345.f) return;
-#endif
     float un_a = 1.f, un_w = 1.f;
     if constexpr (S::SCALED) { un_a = sp::pow2_inv(Sa); un_w = sp::pow2_inv(sp::pow2_scale(a.w_amax)); }
     double gs1[2] = {0.0, 0.0}, gs2[2] = {0.0, 0.0};
@@ -636,7 +556,17 @@ void conv3x3_halo_sp_kernel(ConvArgs a) {
         const float bv = a.bias ? a.bias[col] : 0.f;
         // output offsets of this lane's 16 rows: tile row pr >> 4 = 2 wm + (r >> 3), column (r & 3) + 8 ((r >> 2) & 1) + 4 (lane >> 5)
         const size_t obase = ((size_t)n * a.out_img + (size_t)ty0 * a.out_step * a.out_row + tx0 * a.out_step + a.out_off) * a.Cout + col;
-        float g_mu = 0.f, g_rs = 0.f, g_ga = 0.f, g_be = 0.f;
+        float xg[GB ? 16 : 1];
+        if constexpr (GB) {              // the 16 x values first: one batch of independent loads in flight (32-bit offsets)
+            const auto rgx = make_rsrc(a.gb_x, (unsigned)((size_t)a.N * a.out_img * a.Cout * EB));
+            const unsigned ob32 = (unsigned)obase * EB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                xg[r] = act_load1<AT>(rgx, ob32 + (unsigned)(((pr >> 4) * a.out_row + (pr & 15)) * a.Cout) * EB, 0);
+            }
+        }
+        float g_mu = 0.f, g_rs = 0.f, g_ga = 0.f, g_be = 0.f, f1 = 0.f, f2 = 0.f;
         if constexpr (GB) {
             const int grp = col / (a.Cout / a.gb_groups);
             g_mu = a.gb_mean[n * a.gb_groups + grp];
@@ -645,29 +575,13 @@ void conv3x3_halo_sp_kernel(ConvArgs a) {
             g_be = a.gb_beta[col];
         }
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        float xg[GB ? 16 : 1];
-        if constexpr (GB) {              // the 16 x values first: one batch of independent loads in flight (32-bit offsets)
-            const auto rgx = make_rsrc(a.gb_x, (unsigned)((size_t)a.N * a.out_img * a.Cout * EB));
-            const unsigned ob32 = (unsigned)obase * EB;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pr = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                xg[r] = act_load1<AT>(rgx, ob32 + (unsigned)(((pr >> 4) * a.out_row + (pr & 15)) * a.Cout) * EB, 0);
-            }
-        }
-        float f1 = 0.f, f2 = 0.f;
-#pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int pr = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);          // pixel of the tile
+            const int pr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);          // pixel of the tile
             const size_t o = obase + ((size_t)(pr >> 4) * a.out_step * a.out_row + (pr & 15) * a.out_step) * a.Cout;
-            float v = acc[i][j][r];
+            float v = acc[j][r];
             if constexpr (S::SCALED) v = v * un_a * un_w;
             v += bv;
             if (a.resid) v += act_get<AT>(a.resid, o);
-#ifdef FAVAE_HALO_ABL
-            if (!(a.abl & 2) || v == 12345.f)
-#endif
             if constexpr (!GB) act_put<AT>(a.y, o, v);
             if constexpr (GB) {          // v = da at (pixel, channel col); the conv input x has the same shape
                 const float xh = (xg[r] - g_mu) * g_rs;
@@ -682,12 +596,11 @@ void conv3x3_halo_sp_kernel(ConvArgs a) {
                 se_amax = fmaxf(se_amax, fabsf(v));
             }
         }
-        if constexpr (GB) { gs1[j] += (double)f1; gs2[j] += (double)f2; }
-      }
+        if constexpr (GB) { gs1[j] = (double)f1; gs2[j] = (double)f2; }
     }
     if constexpr (GB || SE) {
-        // fixed summation order: 16 MI rows per lane, the two half-waves, then the 4 / MI pixel-row waves of an 8x16 sub-tile -> one (S1,
-        // S2) pair per channel and sub-tile, reduced over the tiles of the image by gn_bwd_finalize_kernel (deterministic)
+        // fixed summation order: 16 rows per lane, the two half-waves, then the four pixel-row waves -> one (S1, S2) pair per
+        // channel of this 8x16-pixel tile, reduced over the tiles of the image by gn_bwd_finalize_kernel (deterministic)
         double* red = reinterpret_cast<double*>(lds);                // [4 wm][128 channels][2]
         __syncthreads();                                             // the main loop's last LDS reads are done
 #pragma unroll
@@ -714,15 +627,13 @@ void conv3x3_halo_sp_kernel(ConvArgs a) {
                 }
             }
         }
-        const int sub = tid >> 7, ch = tid & 127;                   // 8x16 sub-tile of the workgroup's tile, channel
-        if (sub < MI && n0 + ch < a.Cout) {
-            constexpr int WPS = 4 / MI;                                // pixel-row waves per sub-tile
+        if (tid < 128 && n0 + tid < a.Cout) {
             double u = 0.0, w2 = 0.0;
 #pragma unroll
-            for (int q = 0; q < WPS; ++q) { u += red[((sub * WPS + q) * 128 + ch) * 2]; w2 += red[((sub * WPS + q) * 128 + ch) * 2 + 1]; }
-            const int tpi = tiles_w * (a.Hout / 8);
-            const int ti = (ty0 / 8 + sub) * tiles_w + tx0 / TW;
-            double* out = (GB ? a.gb_part : a.gs_part) + (((size_t)n * tpi + ti) * a.Cout + n0 + ch) * 2;
+            for (int q = 0; q < 4; ++q) { u += red[(q * 128 + tid) * 2]; w2 += red[(q * 128 + tid) * 2 + 1]; }
+            const int tpi = tiles_w * tiles_h;
+            const int ti = (ty0 / TH) * tiles_w + tx0 / TW;
+            double* out = (GB ? a.gb_part : a.gs_part) + (((size_t)n * tpi + ti) * a.Cout + n0 + tid) * 2;
             out[0] = u;
             out[1] = w2;
         }

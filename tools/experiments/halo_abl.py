@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timing ablations of conv3x3_halo_sp_kernel in the b1 mode (library built with -DFAVAE_HALO_ABL): forward conv with GroupNorm+SiLU on
-load and the statistics epilogue, pieces of the kernel switched off at run time (results are wrong then).  One process per FAVAE_HALO_TALL arm."""
+load and the statistics epilogue, pieces of the kernel switched off at run time (results are wrong then).  One process per FAVAE_HALO_TALL arm.
+The instrumented kernel and the FAVAE_HALO_TALL switch exist at commit 0230533 only (profiles/REJECTED.md, r06_halo_tall.txt)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

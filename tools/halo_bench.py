@@ -2,7 +2,8 @@
 """The conv kernels of the b1 mode (one bf16 plane, bf16 activation storage) on a ResnetBlock-like chain, per shape: forward + backward
 of two blocks (GroupNorm+SiLU+conv3x3 twice, residual) under the library's launch profiler -> average time of every conv kernel.
 Arms are process-wide environment switches (read once by the library): run once per arm, e.g.
-    FAVAE_HALO_TALL=0 python tools/halo_bench.py ; python tools/halo_bench.py ; FAVAE_WINO1=0 python tools/halo_bench.py
+    python tools/halo_bench.py ; FAVAE_WINO1=0 python tools/halo_bench.py          (data gradient on the direct kernel too)
+(FAVAE_HALO_TALL: the tall-tile experiment of commit 0230533, profiles/r06_halo_tall.txt; the shipped library ignores it)
 usage: python tools/halo_bench.py [batch]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
