@@ -47,6 +47,111 @@ def _flatten(params, dev):
     return pflat, gflat, mflat, vflat
 
 
+class FlatAdam(torch.optim.Optimizer):
+    """`torch.optim.Adam(params, lr, betas, eps)` (no weight decay, no amsgrad: what train_favae.py:297-305 builds) over flat buffers --
+    the one-line swap for a training loop that is not `TrainStep` (the reference's own `train()`, train_favae.py:68-119): per parameter
+    group, the parameters, their `.grad`s and both moments become views into four flat fp32 buffers; `step()` is ONE `favae_adam_step`
+    launch per group instead of torch's multi-tensor passes over ~400 tensors; `zero_grad()` zeroes the flat gradient buffers and keeps
+    the views (`set_to_none` is ignored: a `None` gradient would cut the view).  Parameter groups keep their own `lr` (the pair-wise
+    `model.sigmas` group of train_favae.py:297-299; `group["lr"]` may be changed by a scheduler), `state_dict()` /
+    `load_state_dict()` speak `torch.optim.Adam`'s format, so checkpoints move between the two (train_favae.py:366-374).
+
+    direct_grads=True lets the conv / GroupNorm / blur backward kernels ACCUMULATE straight into these `.grad` views and hand autograd
+    `None` -- what TrainStep does, and where the time is: only then do the weight gradients run on the second stream beside the
+    data-gradient chain, with their split-K slab reductions grouped (a gradient returned to autograd has to be finished in main-stream
+    order).  Measured on the reference's loop at batch 32 (profiles/r06_ref_loop.txt): torch.optim.Adam 147.7 ms/step, FlatAdam with
+    direct_grads=False 148.1 (the multi-tensor Adam was never the cost), with direct_grads=True 133.0 (TrainStep: 129.7).
+    Direct accumulation bypasses the AccumulateGrad hooks that `torch.nn.parallel.DistributedDataParallel`'s reducer is driven by, so
+    it is refused when a process group with more than one rank exists (use `TrainStep(distributed=True)` there, or pass False and
+    keep DDP); the default (None) is True exactly when there is no such group -- one process, or `accelerate` on one GPU, wraps nothing.
+    Every parameter must be a CUDA fp32 tensor; there is no CPU path."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, direct_grads=None):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if direct_grads and multi:
+            raise RuntimeError("FlatAdam(direct_grads=True) with a %d-rank process group: gradients accumulated by the kernels never reach "
+                               "DDP's reducer (no AccumulateGrad hook fires) -- use TrainStep(distributed=True), or direct_grads=False "
+                               "under DDP" % dist.get_world_size())
+        self.direct_grads = (not multi) if direct_grads is None else bool(direct_grads)
+        self._flat = []                          # per group: [pflat, gflat, mflat, vflat, grad views]
+        for group in self.param_groups:
+            ps = group["params"]
+            if not ps:
+                raise ValueError("FlatAdam: empty parameter group")
+            dev = ps[0].device
+            for p in ps:
+                if p.device != dev or p.device.type != "cuda" or p.dtype != torch.float32:
+                    raise RuntimeError("FlatAdam: parameters of a group must be fp32 tensors on one CUDA device (no CPU path)")
+            pf, gf, mf, vf = _flatten(ps, dev)
+            for p in ps:
+                p._favae_flat = self.direct_grads
+            self._flat.append([pf, gf, mf, vf, [p.grad for p in ps]])
+            group.setdefault("step", 0)
+
+    def zero_grad(self, set_to_none=True):
+        for group, fl in zip(self.param_groups, self._flat):
+            fl[1].zero_()
+            for p, view in zip(group["params"], fl[4]):
+                if p.grad is not view:           # someone set it to None / replaced it: the view goes back in
+                    p.grad = view
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group, fl in zip(self.param_groups, self._flat):
+            for p, view in zip(group["params"], fl[4]):
+                if p.grad is not view:           # autograd assigned a fresh tensor (the view had been dropped): take it over
+                    if p.grad is not None:
+                        view.copy_(p.grad)
+                    p.grad = view
+            group["step"] += 1
+            K.adam_step(fl[0], fl[1], fl[2], fl[3], group["step"], group["lr"], group["betas"], group["eps"], 1.0)
+        return loss
+
+    def state_dict(self):
+        state, pgroups, idx = {}, [], 0
+        for group, fl in zip(self.param_groups, self._flat):
+            ids, off = [], 0
+            for p in group["params"]:
+                n = p.numel()
+                if group["step"] > 0:
+                    state[idx] = {"step": torch.tensor(float(group["step"])),
+                                  "exp_avg": fl[2][off:off + n].as_strided(p.shape, p.stride()).clone(),
+                                  "exp_avg_sq": fl[3][off:off + n].as_strided(p.shape, p.stride()).clone()}
+                ids.append(idx)
+                idx += 1
+                off += n
+            pgroups.append({"lr": group["lr"], "betas": tuple(group["betas"]), "eps": group["eps"], "weight_decay": 0, "amsgrad": False,
+                            "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                            "decoupled_weight_decay": False, "params": ids})
+        return {"state": state, "param_groups": pgroups}
+
+    def load_state_dict(self, sd):
+        if len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError("FlatAdam.load_state_dict: %d parameter groups, the optimizer has %d" % (len(sd["param_groups"]), len(self.param_groups)))
+        for group, fl, sg in zip(self.param_groups, self._flat, sd["param_groups"]):
+            if len(sg["params"]) != len(group["params"]):
+                raise ValueError("FlatAdam.load_state_dict: a parameter group of a different size")
+            off, step = 0, 0
+            for p, i in zip(group["params"], sg["params"]):
+                n = p.numel()
+                st = sd["state"].get(i)
+                if st is not None:
+                    fl[2][off:off + n].as_strided(p.shape, p.stride()).copy_(st["exp_avg"])
+                    fl[3][off:off + n].as_strided(p.shape, p.stride()).copy_(st["exp_avg_sq"])
+                    step = max(step, int(st["step"]))
+                else:
+                    fl[2][off:off + n].zero_()
+                    fl[3][off:off + n].zero_()
+                off += n
+            group["step"] = step
+            group["lr"], group["betas"], group["eps"] = sg["lr"], tuple(sg["betas"]), sg["eps"]
+
+
 class _GradMark(torch.autograd.Function):
     """Identity whose backward runs a callback: placed on a module input, it fires once the gradient with respect to that input is
     being formed, i.e. after every autograd node downstream of it in the forward pass has run its backward -- the point at which

@@ -349,3 +349,41 @@ def test_grad_exchange_rejects_bad_tilings():
     with pytest.raises(ValueError):
         GradExchange(g, [[(0, 9)]])
     GradExchange(g, [[(4, 10)], [(0, 4), (10, 10)]])
+
+
+def _flat_adam_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from favae_step import FlatAdam
+    p = [torch.nn.Parameter(torch.zeros(4))]
+    try:
+        FlatAdam(p, lr=1e-3, direct_grads=True)
+        msg = "accepted"
+    except RuntimeError as e:
+        msg = str(e)
+    try:                                   # the default falls back to ordinary gradients there; on the CPU it then stops at the device check
+        FlatAdam(p, lr=1e-3)
+        msg2 = "accepted"
+    except RuntimeError as e:
+        msg2 = str(e)
+    q.put((rank, msg, msg2, hasattr(p[0], "_favae_flat")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_adam_refuses_direct_accumulation_in_a_multi_rank_group():
+    """gradients the kernels accumulate straight into the flat buffer never pass an AccumulateGrad hook, i.e. never reach DDP's reducer:
+    with more than one rank FlatAdam(direct_grads=True) must not be constructible (TrainStep(distributed=True) owns that case)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_adam_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg, msg2, marked in got:
+        assert "2-rank process group" in msg and "TrainStep(distributed=True)" in msg, msg
+        assert "no CPU path" in msg2, msg2          # direct_grads=None resolved to False, then the (CPU) parameters were refused
+        assert not marked, "a refused construction leaves the parameters untouched"

@@ -37,29 +37,14 @@ def build_model(dev, codebook=16384, n_embed=256, sync_codebook=False, **mk):
                     commitment_weight=1.0, kernel_size=9, dsl_init_sigma=3.0, device=dev, **mk).to(dev)
 
 
-class _Flat:
-    """itemisation arm only: parameters / gradients / Adam moments as views into flat buffers and ONE Adam launch (favae_step._flatten)"""
-
-    def __init__(self, params, dev):
-        from favae_step import _flatten
-        self.p, self.g, self.m, self.v = _flatten(params, dev)
-        self.t = 0
-
-    def zero_grad(self):
-        self.g.zero_()
-
-    def adam_step(self, lr, betas, eps):
-        from favae_hip import ops as K
-        self.t += 1
-        K.adam_step(self.p, self.g, self.m, self.v, self.t, lr, betas, eps, 1.0)
-
-
 def reference_loop(model, xs, steps, warmup=2, lr=4.5e-6 * 32, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, ddp=True,
-                   item_sync=True, fused_adam=False, sync_fn=None):
+                   item_sync=True, optimizer="adam", sync_fn=None):
     """Times `steps` iterations of train_favae.py:68-119 on `model` (a VQGANFCM of this package) over the device batches `xs`.
     ddp: wrap in torch DDP(find_unused_parameters=True) as accelerate.prepare does (train_favae.py:28,239-240,344); needs an
-    initialised process group.  item_sync: the ten-scalar host read-back of train_favae.py:118-119.  fused_adam: replace
-    torch.optim.Adam by ONE favae_adam_step launch over flat views (what TrainStep does) -- an itemisation arm, not the reference loop.
+    initialised process group.  item_sync: the ten-scalar host read-back of train_favae.py:118-119.  optimizer: "adam" =
+    torch.optim.Adam as the script builds it (:297-305); "flat" = favae_step.FlatAdam, the one-line swap (flat buffers, ONE Adam launch
+    per group; safe under DDP); "flat_direct" = FlatAdam(direct_grads=True): the backward kernels accumulate straight into the flat
+    gradient buffer as in TrainStep (not under DDP).
     Returns {"ms_per_step", "images_per_s", "loss_g"}."""
     import torch
     from focal_frequency_loss import FocalFrequencyLoss as FFL
@@ -72,14 +57,17 @@ def reference_loop(model, xs, steps, warmup=2, lr=4.5e-6 * 32, codebook_weight=1
         net = DDP(model, device_ids=[dev.index], find_unused_parameters=True)          # train_favae.py:28, accelerate's DDP kwargs
     inner = net.module if ddp else net
     g_params = list(inner.encoder.parameters()) + list(inner.decoder.parameters()) + list(inner.quantizer.parameters())
-    flat = None
-    if fused_adam:
-        flat = _Flat(g_params, dev)
-        opt_g = None
-    elif hasattr(inner, "sigmas"):
-        opt_g = torch.optim.Adam([{"params": g_params}, {"params": inner.sigmas, "lr": 2.0e-7}], lr=lr, betas=(0.5, 0.9))
+    if optimizer == "adam":
+        make = torch.optim.Adam
     else:
-        opt_g = torch.optim.Adam(g_params, lr=lr, betas=(0.5, 0.9))                    # train_favae.py:297-302
+        if ddp and optimizer == "flat_direct":
+            raise ValueError("direct accumulation bypasses the AccumulateGrad hooks DDP's reducer is driven by")
+        from favae_step import FlatAdam
+        make = (lambda g, **kw: FlatAdam(g, direct_grads=optimizer == "flat_direct", **kw))
+    if hasattr(inner, "sigmas"):
+        opt_g = make([{"params": g_params}, {"params": inner.sigmas, "lr": 2.0e-7}], lr=lr, betas=(0.5, 0.9))
+    else:
+        opt_g = make(g_params, lr=lr, betas=(0.5, 0.9))                                # train_favae.py:297-302
     ffl_func = FFL(loss_weight=ffl_weight, alpha=1.0)                                  # train_favae.py:313
     dsl_feature_func = FFL(loss_weight=dsl_weight, alpha=1.0)                          # train_favae.py:318
     net.train()
@@ -87,10 +75,7 @@ def reference_loop(model, xs, steps, warmup=2, lr=4.5e-6 * 32, codebook_weight=1
     out = {}
 
     def iteration(x):
-        if opt_g is not None:
-            opt_g.zero_grad()
-        else:
-            flat.zero_grad()
+        opt_g.zero_grad()
         x_recon, loss_quant, logits_fake, _, enc_feats, dec_feats = net(x, stage=0)    # :75
         loss_l1 = (x - x_recon).abs().mean()                                           # :76
         loss_perceptual = zero                                                         # :77 left out (see the module docstring)
@@ -102,10 +87,7 @@ def reference_loop(model, xs, steps, warmup=2, lr=4.5e-6 * 32, codebook_weight=1
         loss_dsl_features, _ = recon_ffl_features_loss(dsl_feature_func, enc_feats, dec_feats, dev)   # :99
         loss_g = loss_g + loss_dsl_features
         loss_g.sum().backward()                                                        # :105 accelerator.backward(loss_g)
-        if opt_g is not None:
-            opt_g.step()                                                               # :106
-        else:
-            flat.adam_step(lr, (0.5, 0.9), 1e-8)
+        opt_g.step()                                                                   # :106
         loss_d = torch.tensor(0.).to(dev)                                              # :110
         if item_sync:                                                                  # :118-119
             losses = torch.tensor([loss_g, loss_recon, loss_l1, loss_perceptual, loss_ffl, loss_dsl_features, zero, loss_quant,
@@ -172,8 +154,10 @@ def main():
     torch.cuda.empty_cache()
     arms = [("reference loop (DDP, torch.optim.Adam, .item() x 10)" if use_ddp else "reference loop without DDP", dict(ddp=use_ddp)),
             ("  ... without the ten .item() read-backs", dict(ddp=use_ddp, item_sync=False)),
-            ("  ... without DDP", dict(ddp=False)),
-            ("  ... one fused Adam launch over flat buffers instead of torch.optim.Adam", dict(ddp=False, fused_adam=True))]
+            ("  ... with favae_step.FlatAdam for torch.optim.Adam (one-line swap, DDP-safe)", dict(ddp=use_ddp, optimizer="flat")),
+            ("reference loop without DDP (one process: accelerate wraps nothing)", dict(ddp=False)),
+            ("  ... with favae_step.FlatAdam", dict(ddp=False, optimizer="flat")),
+            ("  ... with favae_step.FlatAdam(direct_grads=True)", dict(ddp=False, optimizer="flat_direct"))]
     for name, kw in arms:
         rows[name] = reference_loop(fresh(), xs, args.steps, lr=lr, **kw)
         torch.cuda.empty_cache()
