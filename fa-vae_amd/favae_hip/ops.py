@@ -764,11 +764,30 @@ class no_direct_grad:
         _DIRECT_GRAD = self.prev
 
 
+# favae_step.FlatAdam(direct_grads=True) turns this on: a training loop that is not TrainStep may call torch.autograd.grad() on its own
+# (the adaptive weight of train_favae.py:32-39) without knowing about no_direct_grad -- every direct accumulation then first asks the
+# engine what the running graph task does with that parameter's gradient.  (TrainStep wraps its own autograd.grad() calls and leaves
+# the check off: one engine query per parameter and backward pass is host time its step does not need to spend.)
+_ENGINE_CHECK = False
+
+
+def _engine_accumulates(p):
+    """does the running graph task ACCUMULATE the gradient of leaf `p` into p.grad (.backward(), backward(inputs=[..p..]))?  False inside
+    torch.autograd.grad(): w.r.t. p the engine captures the returned tensor (the query raises for a leaf there), w.r.t. anything else
+    p's gradient is not wanted at all -- in both cases .grad must not be touched and `None` must not stand in for a gradient."""
+    try:
+        return bool(torch._C._will_engine_execute_node(torch.autograd.graph.get_gradient_edge(p).node))
+    except RuntimeError:
+        return False
+
+
 def _direct_grad(p):
     """Gradient target for parameter `p` when its .grad is a pre-zeroed view of a flat gradient buffer owned by
-    favae_step.TrainStep (marked `_favae_flat`): the reduction kernels then ACCUMULATE into it and autograd is handed
+    favae_step.TrainStep / FlatAdam (marked `_favae_flat`): the reduction kernels then ACCUMULATE into it and autograd is handed
     None, which removes one AccumulateGrad add kernel per parameter.  None -> ordinary autograd path."""
     if not _DIRECT_GRAD or p is None or not getattr(p, "_favae_flat", False) or p.grad is None:
+        return None
+    if _ENGINE_CHECK and not _engine_accumulates(p):
         return None
     g = p.grad
     if g.dim() == 4:

@@ -64,6 +64,8 @@ class FlatAdam(torch.optim.Optimizer):
     Direct accumulation bypasses the AccumulateGrad hooks that `torch.nn.parallel.DistributedDataParallel`'s reducer is driven by, so
     it is refused when a process group with more than one rank exists (use `TrainStep(distributed=True)` there, or pass False and
     keep DDP); the default (None) is True exactly when there is no such group -- one process, or `accelerate` on one GPU, wraps nothing.
+    `torch.autograd.grad()` calls of the loop (the adaptive weight of train_favae.py:32-39) keep working: inside one the kernels return
+    ordinary gradient tensors and leave `.grad` alone (ops._engine_accumulates).
     Every parameter must be a CUDA fp32 tensor; there is no CPU path."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, direct_grads=None):
@@ -74,6 +76,8 @@ class FlatAdam(torch.optim.Optimizer):
                                "DDP's reducer (no AccumulateGrad hook fires) -- use TrainStep(distributed=True), or direct_grads=False "
                                "under DDP" % dist.get_world_size())
         self.direct_grads = (not multi) if direct_grads is None else bool(direct_grads)
+        if self.direct_grads:
+            K._ENGINE_CHECK = True               # the loop may call torch.autograd.grad() itself (train_favae.py:32-39): ops._direct_grad
         self._flat = []                          # per group: [pflat, gflat, mflat, vflat, grad views]
         for group in self.param_groups:
             ps = group["params"]

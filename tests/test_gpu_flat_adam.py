@@ -125,3 +125,39 @@ def test_flat_adam_on_the_drop_in_modules(direct):
     opt.step()
     for p, q in zip(net.parameters(), ref_net.parameters()):
         assert (p - q).abs().max() <= 1e-5 * q.abs().max() + 2e-6
+
+
+def test_autograd_grad_inside_a_flat_adam_loop_leaves_the_flat_gradients_alone():
+    """the adaptive weight of the GAN stage (favae_scripts/train_favae.py:32-39) is a torch.autograd.grad() w.r.t. a conv weight in the
+    middle of the user's loop: with FlatAdam's direct accumulation on, that call must get a real gradient tensor and must not add
+    anything to the flat gradient buffer; the .backward() that follows accumulates as usual"""
+    from favae_step import FlatAdam
+    from models import codec as C
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(C.ResnetBlock(64, 128, 0.0), C.ResnetBlock(128, 128, 0.0)).to(DEV)
+    ref_net = copy.deepcopy(net)
+    x = torch.randn(2, 64, 32, 32, device=DEV)
+    gy = torch.randn(2, 128, 32, 32, device=DEV)
+    w_ref = ref_net[1].block[6].weight
+    want_w = torch.autograd.grad(ref_net(x), w_ref, gy)[0]
+    ref_net(x).backward(gy)
+    want = [p.grad.detach().clone() for p in ref_net.parameters()]
+    opt = FlatAdam(net.parameters(), lr=1e-3, betas=(0.5, 0.9), direct_grads=True)
+    opt.zero_grad()
+    out = net(x)
+    got_w = torch.autograd.grad(out, net[1].block[6].weight, gy, retain_graph=True)[0]
+    assert got_w is not None and (got_w - want_w).abs().max() <= 1e-5 * want_w.abs().max()
+    torch.cuda.synchronize()
+    assert float(opt._flat[0][1].abs().max()) == 0.0, "autograd.grad() must not touch .grad"
+    out.backward(gy)
+    for p, w in zip(net.parameters(), want):
+        assert p.grad is not None and (p.grad - w).abs().max() <= 1e-5 * w.abs().max() + 1e-7
+    # backward(inputs=[...]) accumulates into exactly those parameters
+    opt.zero_grad()
+    net(x).backward(gy, inputs=[net[0].block[2].weight])
+    torch.cuda.synchronize()
+    for (name, p), w in zip(net.named_parameters(), want):
+        if name == "0.block.2.weight":
+            assert (p.grad - w).abs().max() <= 1e-5 * w.abs().max()
+        else:
+            assert float(p.grad.abs().max()) == 0.0, name
