@@ -205,3 +205,29 @@ def test_package_asks_for_eight_hardware_queues_before_hip_is_initialised():
         assert out.returncode == 0 and out.stdout.strip() == want, (val, out.stdout, out.stderr[-500:])
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert src.index('os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")') < src.index('dist.init_process_group("nccl"')
+
+
+def test_direct_accumulation_asks_the_engine_what_the_pass_does_with_a_gradient():
+    """ops._engine_accumulates (host logic, runs on the CPU): True in .backward() and for the named leaves of backward(inputs=...), False
+    inside torch.autograd.grad() -- for the differentiated leaf (the engine captures the returned tensor there) and for every other one
+    (its gradient is not wanted): favae_step.FlatAdam's direct mode returns ordinary tensors and leaves .grad alone in those cases"""
+    import torch
+    from favae_hip import ops as K
+    w = torch.ones(3, requires_grad=True)
+    b = torch.ones(3, requires_grad=True)
+    seen = []
+
+    class F(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, y):
+            return x * 2 + y
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append((K._engine_accumulates(w), K._engine_accumulates(b)))
+            return g * 2, g
+    F.apply(w, b).sum().backward()
+    torch.autograd.grad(F.apply(w, b).sum(), w)
+    torch.autograd.grad(F.apply(w, b).sum(), [w, b])
+    F.apply(w, b).sum().backward(inputs=[w])
+    assert seen == [(True, True), (False, False), (False, False), (True, False)], seen
