@@ -781,6 +781,15 @@ def _engine_accumulates(p):
         return False
 
 
+def _engine_runs(node):
+    """will the running graph task execute `node` (a non-leaf's grad_fn)?  False inside torch.autograd.grad() / backward(inputs=...) for
+    a node that leads to none of the requested inputs: a gradient flowing there is dropped by the engine, so it need not be formed."""
+    try:
+        return node is None or bool(torch._C._will_engine_execute_node(node))
+    except RuntimeError:
+        return True
+
+
 def _direct_grad(p):
     """Gradient target for parameter `p` when its .grad is a pre-zeroed view of a flat gradient buffer owned by
     favae_step.TrainStep / FlatAdam (marked `_favae_flat`): the reduction kernels then ACCUMULATE into it and autograd is handed
@@ -793,6 +802,53 @@ def _direct_grad(p):
     if g.dim() == 4:
         return g if _is_cl(g) else None
     return g if g.is_contiguous() else None
+
+
+# ---- weight gradients of a training loop that is NOT TrainStep / FlatAdam(direct): ordinary tensors, still on the second stream --------
+# A gradient RETURNED to autograd has to be finished in main-stream order: AccumulateGrad (and, under DDP, the reducer's bucket copy)
+# consumes it on the main stream right behind the node that returned it -- the engine runs AccumulateGrad nodes first.  Weight gradients
+# handed back that way therefore ran on the MAIN stream in rounds 1-5 and such a loop paid the single-stream step (profiles/
+# r06_ref_loop.txt: 147.7 ms against 129.7).  Round 6: at the START of a forward pass (VQGANFCM.forward) every dense conv weight is passed
+# through an identity node (_LateGradFn); the convs take that alias.  The engine orders ready nodes by creation sequence, latest first,
+# so these nodes -- created before anything else of the pass -- run LAST: a conv's backward launches its weight gradient on the side
+# stream into a fresh tensor and hands it to its identity node, where it waits untouched until the rest of the backward pass has been
+# queued; the first identity node to run makes the main stream wait for the side stream, and only then do AccumulateGrad / DDP's hooks see
+# the tensors.  (DDP's bucket all-reduces then all start at the end of backward: 331 MB over xGMI, a few ms, against 15 ms regained.)
+# A weight used twice in one pass takes the alias only the first time (two gradients meeting at one node would be added by the engine
+# on the main stream while the side stream may still be writing them).  FAVAE_LATE_GRADS=0: off (A/B switch).
+_LATE = {"map": {}, "on": os.environ.get("FAVAE_LATE_GRADS", "1") != "0"}
+
+
+class _LateGradFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p):
+        return p.view_as(p)
+
+    @staticmethod
+    def backward(ctx, g):
+        sync_side_stream()                 # main stream behind every weight gradient of the side stream (later calls: nothing left)
+        return g
+
+
+def late_weights(params):
+    """Start of a forward pass of a module that owns dense conv weights: aliases (see above) for those of `params` that are ordinary
+    trainable 4-D parameters (not views of a flat gradient buffer with direct accumulation: TrainStep / FlatAdam have their own path)."""
+    m = {}
+    if _LATE["on"] and _SIDE["on"] and torch.is_grad_enabled():
+        for p in params:
+            if p.requires_grad and p.dim() == 4 and p.is_cuda and not getattr(p, "_favae_flat", False):
+                w = _LateGradFn.apply(p)
+                w._favae_late = True
+                m[id(p)] = [w, False]
+    _LATE["map"] = m
+
+
+def _late_alias(w):
+    ent = _LATE["map"].get(id(w)) if _LATE["map"] else None
+    if ent is None or ent[1] or not torch.is_grad_enabled():
+        return w
+    ent[1] = True
+    return ent[0]
 
 
 class ConvCfg:
@@ -1118,6 +1174,10 @@ class FusedConvFn(torch.autograd.Function):
         db, dyb = _bias_grad_and_range(dy, p_b, need_b, want_range, N * Ho * Wo, Cout, dev)
         # The weight gradient is launched AFTER this conv's data gradient (see run_wgrad below)
         run_wgrad = None
+        if need_w and getattr(p_w, "_favae_late", False) and not _engine_runs(p_w.grad_fn):
+            # torch.autograd.grad() for something else (the adaptive weight, train_favae.py:32-39): needs_input_grad says "requires
+            # grad", the engine knows that nobody waits for this one
+            need_w = False
         if need_w:
             d = make_conv_desc(N, Hin, Win, Cin, Ho, Wo, Cout, cfg.kh, cfg.kw, cfg.stride, cfg.pad, gather, act, ctx.per_image)
             ws = workspace(query("favae_conv_wgrad_workspace", byref(d)), dev)
@@ -1145,7 +1205,11 @@ class FusedConvFn(torch.autograd.Function):
                     call("favae_conv_wgrad", byref(wd), ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(xb), ptr(dyb), ptr(wtgt), acc,
                          ptr(wws), wws.numel())
 
-            if tgt is not None and _SIDE["on"]:               # flat gradient buffer, side stream (see _SIDE)
+            late = tgt is None and getattr(p_w, "_favae_late", False) and _SIDE["on"]
+            if late:                                          # ordinary gradient tensor, delivered at the end of backward (_LateGradFn)
+                def run_wgrad():
+                    _side_launch(launch_wgrad, (x, dy, scale, shift, xb, dyb, wws, dwk))
+            elif tgt is not None and _SIDE["on"]:             # flat gradient buffer, side stream (see _SIDE)
                 # launched AFTER this conv's data gradient (below): the side stream then starts it next to the HBM-bound
                 # GroupNorm-backward / bias-gradient kernels that follow instead of next to the other matrix-bound kernel
                 # (measured: 204 -> 196 ms/step; launching it before the data gradient only gave 208 -> 204)
@@ -1345,7 +1409,7 @@ def fused_conv(x, w, b=None, gn_w=None, gn_b=None, resid=None, cfg=None, pass_in
             and cfg.pad == 1 and w.dim() == 4
             and query("favae_conv_subpixel_ok", x.shape[0], x.shape[2], x.shape[3], x.shape[1], w.shape[0])):
         return UpsampleConvFn.apply(x, w, b)
-    return FusedConvFn.apply(x, w, b, gn_w, gn_b, resid, cfg, pass_input, stats)
+    return FusedConvFn.apply(x, _late_alias(w), b, gn_w, gn_b, resid, cfg, pass_input, stats)
 
 
 @torch.no_grad()

@@ -57,10 +57,9 @@ class FlatAdam(torch.optim.Optimizer):
     `load_state_dict()` speak `torch.optim.Adam`'s format, so checkpoints move between the two (train_favae.py:366-374).
 
     direct_grads=True lets the conv / GroupNorm / blur backward kernels ACCUMULATE straight into these `.grad` views and hand autograd
-    `None` -- what TrainStep does, and where the time is: only then do the weight gradients run on the second stream beside the
-    data-gradient chain, with their split-K slab reductions grouped (a gradient returned to autograd has to be finished in main-stream
-    order).  Measured on the reference's loop at batch 32 (profiles/r06_ref_loop.txt): torch.optim.Adam 147.7 ms/step, FlatAdam with
-    direct_grads=False 148.1 (the multi-tensor Adam was never the cost), with direct_grads=True 133.0 (TrainStep: 129.7).
+    `None` -- what TrainStep does: no AccumulateGrad per parameter, the split-K slab reductions of the weight gradients grouped on the
+    second stream.  Measured on the reference's loop at batch 32 (profiles/r06_ref_loop.txt): torch.optim.Adam 134.8 ms/step, FlatAdam
+    with direct_grads=False 134.8 (the multi-tensor Adam was never the cost), with direct_grads=True 132.4 (TrainStep: 129.1).
     Direct accumulation bypasses the AccumulateGrad hooks that `torch.nn.parallel.DistributedDataParallel`'s reducer is driven by, so
     it is refused when a process group with more than one rank exists (use `TrainStep(distributed=True)` there, or pass False and
     keep DDP); the default (None) is True exactly when there is no such group -- one process, or `accelerate` on one GPU, wraps nothing.

@@ -83,6 +83,12 @@ class VQGANFCM(nn.Module):
 
     def forward(self, x, stage=0, inference=False):
         if stage == 0:                                              # train E + G + Q
+            # a loop with ordinary gradient tensors (not TrainStep / FlatAdam's direct accumulation): the dense conv weights go through
+            # identity nodes created HERE, before anything else of the pass, so that their gradients can be formed on the second stream
+            # and are delivered at the end of backward (favae_hip/ops.py, _LateGradFn)
+            if getattr(self, "_late_params", None) is None:
+                self._late_params = [p for m in (self.encoder, self.decoder) for p in m.parameters() if p.dim() == 4]
+            K.late_weights(self._late_params if self.training and torch.is_grad_enabled() else ())
             z, loss_q, _, enc_feats = self.encode(x)
             x_recon, dec_feats = self.decode(z)
             logits_fake = self.discriminator(x_recon)

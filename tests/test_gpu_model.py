@@ -1008,3 +1008,72 @@ def test_backward_across_an_arena_reset_fails_loudly():
     K.reset_side_state()
     ts.step(x)                                            # and the object still trains afterwards
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("mtag,hw", [("cfg1_k3", 64), ("f4_same_conv", 32)])
+def test_late_weight_gradients_of_a_foreign_loop_are_race_free(mtag, hw):
+    """A loop that is not TrainStep gets ordinary gradient tensors.  Their weight gradients still run on the second stream: the dense
+    conv weights pass through identity nodes created at the start of VQGANFCM.forward, which the engine runs last, so the tensors reach
+    AccumulateGrad only after the main stream has waited for the side stream (ops._LateGradFn).  With an artificially slow side stream
+    every gradient must be bit-identical to the run that keeps them on the main stream."""
+    from favae_hip import ops as K
+    x = O.det_input(2, hw, hw, 31).to(DEV)
+
+    def grads(late, delay):
+        model, _, _ = build(mtag)
+        model.train()
+        prev = K._LATE["on"], K._SIDE["delay"]
+        K._LATE["on"], K._SIDE["delay"] = late, delay
+        try:
+            x_recon, loss_q, _, _, enc_feats, dec_feats = model(x, stage=0)
+            n_alias = len(K._LATE["map"])
+            loss = (x - x_recon).abs().mean() + loss_q.sum() + sum(f.float().square().mean() for f in list(enc_feats) + list(dec_feats))
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            K._LATE["on"], K._SIDE["delay"] = prev
+        assert not K._SIDE["jobs"]
+        named = [(n, p) for n, p in model.named_parameters() if n.startswith(("encoder.", "decoder.", "quantizer.")) and p.requires_grad]
+        assert all(p.grad is not None for n, p in named if p.dim() == 4), "every conv weight got its gradient"
+        return n_alias, {n: p.grad.detach().clone() for n, p in named if p.grad is not None}
+    n0, ref = grads(False, 0)
+    n1, got = grads(True, 400000)
+    assert n0 == 0 and n1 > 20, (n0, n1)
+    assert ref.keys() == got.keys()
+    for n in ref:
+        assert torch.equal(ref[n], got[n]), "%s: %g" % (n, float((ref[n] - got[n]).abs().max()))
+
+
+def test_autograd_grad_in_a_foreign_loop_forms_only_the_weight_gradient_it_asks_for():
+    """torch.autograd.grad() w.r.t. ONE conv weight in the middle of a user's loop (the adaptive weight of the GAN stage,
+    favae_scripts/train_favae.py:32-39, asks for the last layer's; here an early encoder weight, so that the whole conv chain lies on
+    the way).  Every conv node on the way sees needs_input_grad = True for its weight (it requires grad); the conv nodes ask the
+    engine whether their weight's identity node will run at all and skip the weight gradient otherwise."""
+    import favae_hip as H
+    from bench import Prof
+    from favae_hip import ops as K
+    x = O.det_input(2, 64, 64, 31).to(DEV)
+    prof = Prof(H)
+
+    def run(late):
+        model, _, _ = build("cfg1_k3")               # a training-mode forward moves the EMA codebook: a fresh model per arm
+        model.train()
+        last = [p for n, p in model.encoder.named_parameters() if p.dim() == 4 and tuple(p.shape[1:]) == (p.shape[0], 3, 3)][0]
+        prev = K._LATE["on"]
+        K._LATE["on"] = late
+        try:
+            x_recon = model(x, stage=0)[0]
+            loss = (x - x_recon).abs().mean()
+            torch.cuda.synchronize()
+            prof.start(2)
+            g = torch.autograd.grad(loss, last, retain_graph=False)[0]
+            torch.cuda.synchronize()
+            t = prof.stop()
+        finally:
+            K._LATE["on"] = prev
+        assert all(p.grad is None for p in model.parameters()), "autograd.grad() leaves .grad alone"
+        return g, sum(v["launches"] for k, v in t.items() if "wgrad" in k)
+    g0, n0 = run(False)
+    g1, n1 = run(True)
+    assert (g0 - g1).abs().max() <= 1e-6 * g0.abs().max()
+    assert n0 > 60 and n1 <= n0 // 3, (n0, n1)     # what remains: the convs outside FusedConvFn (Up / Downsample, attention, conv_in / out)
