@@ -1371,7 +1371,8 @@ class UpsampleConvFn(torch.autograd.Function):
         dx = dw = db = None
         db, dyb = _bias_grad_and_range(dy, p_b, ctx.has_b and ctx.needs_input_grad[2], planes in (1, 2), N * 4 * H * W, Cout, dev)
         late = None
-        if ctx.needs_input_grad[1]:
+        late_w = getattr(p_w, "_favae_late", False) and _SIDE["on"]       # ordinary gradient, delivered at the end of backward (_LateGradFn)
+        if ctx.needs_input_grad[1] and not (late_w and not _engine_runs(p_w.grad_fn)):
             tgt = _direct_grad(p_w)
             dweff = torch.empty((16 * Cout * Cin,), dtype=torch.float32, device=dev)
             d0 = _phase_desc(N, H, W, Cin, Cout, 0)
@@ -1384,9 +1385,11 @@ class UpsampleConvFn(torch.autograd.Function):
                          ptr(dyb), dweff.data_ptr() + ph * 4 * Cout * 4 * Cin, 0, ptr(wss), wss.numel())
                 call("favae_upsample_wgrad_fold", ptr(dweff), ptr(tgt if tgt is not None else dwk), Cout, Cin,
                      1 if tgt is not None else 0)
-            if tgt is not None and _SIDE["on"]:
+            if (tgt is not None or late_w) and _SIDE["on"]:
                 def late():
-                    _side_launch(wgrad, (x, dy, xb, dyb, wss, dweff))
+                    _side_launch(wgrad, (x, dy, xb, dyb, wss, dweff, dwk))
+                if dwk is not None:
+                    dw = dwk.permute(0, 3, 1, 2)
             else:
                 wgrad()
                 if dwk is not None:
@@ -1408,7 +1411,7 @@ def fused_conv(x, w, b=None, gn_w=None, gn_b=None, resid=None, cfg=None, pass_in
     if (cfg.upsample and gn_w is None and resid is None and not pass_input and cfg.kh == 3 and cfg.kw == 3 and cfg.stride == 1
             and cfg.pad == 1 and w.dim() == 4
             and query("favae_conv_subpixel_ok", x.shape[0], x.shape[2], x.shape[3], x.shape[1], w.shape[0])):
-        return UpsampleConvFn.apply(x, w, b)
+        return UpsampleConvFn.apply(x, _late_alias(w), b)
     return FusedConvFn.apply(x, _late_alias(w), b, gn_w, gn_b, resid, cfg, pass_input, stats)
 
 
