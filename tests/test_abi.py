@@ -231,3 +231,40 @@ def test_direct_accumulation_asks_the_engine_what_the_pass_does_with_a_gradient(
     torch.autograd.grad(F.apply(w, b).sum(), [w, b])
     F.apply(w, b).sum().backward(inputs=[w])
     assert seen == [(True, True), (False, False), (False, False), (True, False)], seen
+
+
+def test_identity_nodes_created_first_run_last_in_backward():
+    """what the late gradients lean on (favae_hip/ops.py _LateGradFn): the autograd engine runs ready nodes latest-created first, so an
+    identity node made before anything else of the forward pass runs after every other node of the backward pass -- a weight gradient
+    parked at it is not looked at until the rest of backward has been queued.  (If a torch release changed that order the gradients
+    would still be right -- the node waits for the side stream before it hands its tensor on -- but the overlap would be gone.)"""
+    import torch
+    from favae_hip import ops as K
+    order = []
+
+    class Mark(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, tag):
+            ctx.tag = tag
+            return x * w.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            order.append(ctx.tag)
+            return g, g.sum().expand(3), None
+
+    ws = [torch.ones(3, requires_grad=True) for _ in range(4)]
+    seen = []
+    for i, w in enumerate(ws):
+        w.register_hook(lambda g, i=i: seen.append((i, list(order))))
+    alias = [K._LateGradFn.apply(w) for w in ws]              # start of the forward pass
+    assert all(a.data_ptr() == w.data_ptr() and a.requires_grad for a, w in zip(alias, ws))
+    h = torch.ones(3, requires_grad=True)
+    x = h * 1.0
+    for i, a in enumerate(alias):
+        x = Mark.apply(x, a, i)
+    x.sum().backward()
+    assert order == [3, 2, 1, 0]
+    # every parameter's gradient arrived only after ALL the conv-like nodes had run, the alias made last first
+    assert [i for i, _ in seen] == [3, 2, 1, 0] and all(o == [3, 2, 1, 0] for _, o in seen), seen
+    assert all(w.grad is not None for w in ws) and h.grad is not None
