@@ -1532,3 +1532,36 @@ def test_spectrum_loss_fixed_sigma(K):
         g_got = torch.autograd.grad(got.sum(), en_d + de_d)
         for i, (a, b) in enumerate(zip(g_got, g_ref)):
             check(a, b, 2e-4, "SL gradient %d" % i)
+
+
+def test_late_gradients_accumulate_over_two_backward_passes():
+    """gradient accumulation in a loop with ordinary gradient tensors: the second pass finds p.grad set, so AccumulateGrad ADDS in place
+    on the main stream -- after the identity node has made it wait for the (artificially slow) side stream.  g + g is exact in fp32:
+    the result must be twice the single-stream gradient bit for bit."""
+    import copy
+    from favae_hip import ops as K
+    from models import codec as C
+    DEV = "cuda:0"
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(C.ResnetBlock(64, 128, 0.0), C.ResnetBlock(128, 128, 0.0)).to(DEV)
+    ref_net = copy.deepcopy(net)
+    x = torch.randn(2, 64, 32, 32, device=DEV)
+    gy = torch.randn(2, 128, 32, 32, device=DEV)
+    prev = K._LATE["on"], K._SIDE["delay"]
+    try:
+        K._LATE["on"] = False
+        K.late_weights(())
+        ref_net(x).backward(gy)
+        torch.cuda.synchronize()
+        K._LATE["on"], K._SIDE["delay"] = True, 400000
+        convs = [p for p in net.parameters() if p.dim() == 4]
+        for _ in range(2):
+            K.late_weights(convs)
+            assert len(K._LATE["map"]) == len(convs)
+            net(x).backward(gy)
+        torch.cuda.synchronize()
+    finally:
+        K._LATE["on"], K._SIDE["delay"] = prev
+        K.late_weights(())
+    for (n, p), q in zip(net.named_parameters(), ref_net.parameters()):
+        assert torch.equal(p.grad, 2 * q.grad), n
