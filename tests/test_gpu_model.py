@@ -1077,3 +1077,57 @@ def test_autograd_grad_in_a_foreign_loop_forms_only_the_weight_gradient_it_asks_
     g1, n1 = run(True)
     assert (g0 - g1).abs().max() <= 1e-6 * g0.abs().max()
     assert n0 > 60 and n1 <= n0 // 3, (n0, n1)     # what remains: the convs outside FusedConvFn (Up / Downsample, attention, conv_in / out)
+
+
+def test_gan_iteration_of_the_reference_loop_matches_trainstep():
+    """the GAN-stage iteration as the reference writes it (favae_scripts/train_favae.py:75-105: hinge generator term, adaptive weight from
+    two torch.autograd.grad() calls w.r.t. decoder.final[2].weight with retain_graph, one loss_g.backward()) on the drop-in modules --
+    ordinary gradient tensors, weight gradients on the second stream and delivered late -- against TrainStep(train_disc=True), which
+    restates the same step with the x_recon gradients reused: same adaptive weight, same generator gradients."""
+    from favae_hip import ops as K
+    from favae_step import TrainStep
+    from focal_frequency_loss import FocalFrequencyLoss as FFL
+    from losses.hinge import hinge_g_loss
+    from losses.vqgan_losses import recon_ffl_features_loss, recon_ffl_loss
+    x = O.det_input(2, 64, 64, 31).to(DEV)
+    keep = ("encoder.", "decoder.", "quantizer.")
+    # A: TrainStep
+    mA, _, _ = build("cfg1_k3")
+    ts = TrainStep(mA, lr=1e-4, codebook_weight=1.0, ffl_weight=1.0, dsl_weight=0.01, train_disc=True, disc_weight=0.75)
+    mA.train()
+    ts.gflat.zero_()
+    out = ts.losses(x)
+    ts.backward(out)
+    K.sync_side_stream()
+    torch.cuda.synchronize()
+    w_a = float(out["weight_d"])
+    g_a = {n: p.grad.detach().clone() for n, p in mA.named_parameters() if n.startswith(keep)}
+    # B: the reference's lines, on a second copy of the model
+    mB, _, _ = build("cfg1_k3")
+    mB.train()
+    ffl_func, dsl_func = FFL(loss_weight=1.0, alpha=1.0), FFL(loss_weight=0.01, alpha=1.0)
+    x_recon, loss_quant, logits_fake, _, enc_feats, dec_feats = mB(x, stage=0)
+    assert len(K._LATE["map"]) > 20, "ordinary parameters: the dense conv weights went through their identity nodes"
+    loss_recon = (x - x_recon).abs().mean()
+    loss_g = loss_recon + 1.0 * loss_quant
+    loss_disc = hinge_g_loss(logits_fake)
+    last = mB.decoder.final[2].weight
+    grad_disc = torch.autograd.grad(loss_disc, last, retain_graph=True)[0]
+    grad_recon = torch.autograd.grad(loss_recon, last, retain_graph=True)[0]
+    w_b = torch.clamp(torch.norm(grad_recon) / (torch.norm(grad_disc) + 1e-4), 0.0, 1e4).item()
+    assert all(p.grad is None for p in mB.parameters())
+    loss_g = loss_g + w_b * 0.75 * loss_disc + recon_ffl_loss(ffl_func, x, x_recon)
+    loss_g = loss_g + recon_ffl_features_loss(dsl_func, enc_feats, dec_feats, torch.device(DEV))[0]
+    loss_g.sum().backward()
+    torch.cuda.synchronize()
+    assert abs(w_a - w_b) <= 1e-4 * abs(w_b), (w_a, w_b)
+    margins.record("reference GAN loop vs TrainStep: weight_d", abs(w_a - w_b) / abs(w_b), 1e-4)
+    worst = 0.0
+    for n, p in mB.named_parameters():
+        if not n.startswith(keep) or not p.requires_grad:
+            continue
+        assert p.grad is not None, n
+        e = float((p.grad - g_a[n]).abs().max()) / (float(g_a[n].abs().max()) + 1e-30)
+        worst = max(worst, e)
+        assert e <= 1e-4, (n, e)
+    margins.record("reference GAN loop vs TrainStep: generator gradients (worst tensor)", worst, 1e-4)
