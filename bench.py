@@ -606,7 +606,11 @@ def main():
             extras["reference_loop"] = {"images_per_s": rnd(args.batch * world * 1e3 / ms_ref), "ms_per_step": rnd(ms_ref), "steps": n_ref,
                                         "what": "train_favae.py:68-119 on the drop-in modules: DDP(find_unused_parameters), "
                                                 "torch.optim.Adam, 10 x .item() per step (tools/ref_loop_bench.py)"}
-            # the same loop, one process (accelerate wraps nothing on one GPU), favae_step.FlatAdam for torch.optim.Adam: the one-line swap
+            # the same loop in one process without the DDP wrapper (what accelerate builds on one GPU) ...
+            r1 = reference_loop(ref_model, xs, n_ref, warmup=1, lr=4.5e-6 * args.batch * world, ddp=False, sync_fn=sync)
+            extras["reference_loop"]["one_process"] = {"images_per_s": rnd(args.batch * 1e3 / r1["ms_per_step"]),
+                                                       "ms_per_step": rnd(r1["ms_per_step"]), "what": "no DDP wrapper, torch.optim.Adam"}
+            # ... and with favae_step.FlatAdam for torch.optim.Adam: the one-line swap
             r2 = reference_loop(ref_model, xs, n_ref, warmup=2, lr=4.5e-6 * args.batch * world, ddp=False, optimizer="flat_direct", sync_fn=sync)
             extras["reference_loop"]["with_flat_adam"] = {"images_per_s": rnd(args.batch * 1e3 / r2["ms_per_step"]),
                                                           "ms_per_step": rnd(r2["ms_per_step"]),
@@ -686,9 +690,9 @@ def main():
             res["reference_loop"] = extras["reference_loop"]
             if "images_per_s" in res["reference_loop"]:
                 res["reference_loop"]["vs_trainstep"] = rnd(res["reference_loop"]["images_per_s"] / res["value"], 4)
-                if "with_flat_adam" in res["reference_loop"]:
-                    res["reference_loop"]["with_flat_adam"]["vs_trainstep"] = rnd(
-                        res["reference_loop"]["with_flat_adam"]["images_per_s"] / res["value"], 4)
+                for k in ("one_process", "with_flat_adam"):
+                    if k in res["reference_loop"]:
+                        res["reference_loop"][k]["vs_trainstep"] = rnd(res["reference_loop"][k]["images_per_s"] / res["value"], 4)
         if comm is not None:
             res["comm"] = comm
         if world == 1 and not use_dist and not args.no_cpu_baseline:
